@@ -1,0 +1,203 @@
+/*
+ * mpmhip.h -- C ABI of libmpmhip.so, the MI355X (gfx950) MPM substep solver.
+ *
+ * Drop-in boundary for the hot path of KAISTChangmin/MPMAvatar: one MPM substep,
+ * `MPMWARP.p2g2p` (/root/reference/warp_mpm/mpm_solver.py:229-536) and the solver
+ * state it advances.  The reference has no FFI for this path (it is NVIDIA-Warp DSL
+ * called from Python); the entry points below are what a ctypes
+ * binding of `warp_mpm/mpm_solver.py` + `mpm_data_structure.py` needs, one group per
+ * reference interface.  The Python shim `mpmavatar_amd/warp_mpm/` is that binding.
+ *
+ * Conventions
+ *   - every pointer marked [dev] is a device pointer on `config.device` (e.g.
+ *     torch.Tensor.data_ptr() of a ROCm tensor); [host] pointers are read during the
+ *     call and not retained.  No torch types cross this boundary.
+ *   - particle arrays use the reference's layout: AoS fp32, vec3 = 3 floats,
+ *     mat33 = 9 floats row-major; index classes [0,n_elements) elements,
+ *     [n_elements,n_nv) traditional, [n_nv,n_particles) vertices,
+ *     n_nv = n_particles - n_vertices (mpm_solver.py:19-26, SURVEY.md 8 layout).
+ *   - calls are asynchronous on the context's stream unless stated; every function
+ *     returns MPMHIP_OK (0) or a negative error code, mpmhip_last_error() has the text.
+ *   - a context is bound to one GPU and is not thread-safe; distinct contexts are
+ *     independent (one per rank in multi-GPU runs).
+ */
+#ifndef MPMHIP_H
+#define MPMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPMHIP_VERSION 100
+
+enum {
+  MPMHIP_OK = 0,
+  MPMHIP_ERR_INVALID = -1,   /* bad argument / inconsistent sizes  (reference: assert / RuntimeError) */
+  MPMHIP_ERR_NO_DEVICE = -2, /* no HIP device visible: the solver never falls back to a CPU path */
+  MPMHIP_ERR_HIP = -3,       /* a HIP runtime call failed */
+  MPMHIP_ERR_STATE = -4,     /* called before the state/model were bound */
+  MPMHIP_ERR_LIMIT = -5      /* too many colliders / boundary conditions */
+};
+
+enum { MPMHIP_MODE_FAST = 0,      /* cell-sorted SoA particles + block-sparse grid + LDS-tiled transfers */
+       MPMHIP_MODE_BASELINE = 1   /* reference-structured kernels on the caller's AoS arrays, dense grid */ };
+
+typedef struct mpmhip_ctx mpmhip_ctx;
+
+/* MPMWARP.__init__/initialize arguments, mpm_solver.py:14-26 */
+typedef struct {
+  int32_t n_particles, n_elements, n_vertices;
+  int32_t n_grid;
+  float grid_lim;
+  int32_t num_joint_t, num_joint_v, num_joint_f;
+  int32_t device;         /* HIP device ordinal */
+  int32_t mode;           /* MPMHIP_MODE_* */
+  int32_t rebin_interval; /* fast mode: substeps between particle re-sorts; 0 = default */
+  int32_t own_stream;     /* 1: create a private non-blocking stream and ignore `stream` */
+  void *stream;           /* own_stream == 0: hipStream_t to launch on (NULL = the HIP null stream), e.g.
+                             torch.cuda.current_stream().cuda_stream so that solver work is ordered with the
+                             caller's tensor ops the way Warp's stream is with torch's */
+} mpmhip_config;
+
+/* MPMStateStruct fields the substep touches, mpm_data_structure.py:13-49.  All [dev]. */
+typedef struct {
+  float *particle_x;        /* [n_particles*3] */
+  float *particle_v;        /* [n_particles*3] */
+  float *particle_C;        /* [n_particles*9] */
+  float *particle_F;        /* [n_nv*9] */
+  float *particle_F_trial;  /* [n_nv*9] */
+  float *particle_stress;   /* [n_nv*9] */
+  float *particle_d;        /* [n_elements*9] */
+  float *particle_R_inv;    /* [n_elements*3] */
+  const float *faces;       /* [n_elements*3] float-encoded vertex ids (quirk Q8) */
+  float *vertex_force;      /* [n_vertices*3] */
+  const float *particle_vol;  /* [n_particles] */
+  const float *particle_mass; /* [n_particles] */
+  const int32_t *particle_selection; /* [n_particles], 0 = simulate */
+} mpmhip_state_ptrs;
+
+/* MPMModelStruct arrays, mpm_data_structure.py:621-630.  All [dev], [n_particles]. */
+typedef struct {
+  float *mu, *lam, *gamma, *kappa, *yield_stress;
+} mpmhip_model_ptrs;
+
+/* MPMModelStruct scalars, mpm_data_structure.py:627-645 + init_other_params :686-715 */
+typedef struct {
+  int32_t material; /* 0 jelly 1 metal 2 sand 3 foam 4 snow 5 plasticine 6 neo-hookean 7 cloth */
+  float friction_coeff, alpha;
+  float g[3];
+  float hardening, xi, plastic_viscosity, softening;
+  float rpic_damping, grid_v_damping_scale;
+} mpmhip_model_scalars;
+
+typedef struct {
+  int64_t substeps;        /* p2g2p calls since creation */
+  int64_t rebins;          /* particle re-sorts (fast mode) */
+  int32_t n_active_blocks; /* 4x4x4-node grid blocks currently swept (fast mode) */
+  int32_t n_active_nodes;  /* nodes with mass > 0 after the last p2g (filled by mpmhip_measure) */
+  int32_t n_collider_nodes;
+  int32_t n_mover_nodes;
+  int32_t n_fallback_particles; /* particles that left their tile margin since the last re-sort */
+  int32_t reserved;
+} mpmhip_stats;
+
+/* ---- lifetime ----------------------------------------------------------------- */
+int mpmhip_version(void);
+int mpmhip_device_count(void); /* 0 when no GPU is visible (never an error) */
+/* MPMWARP(...) constructor, mpm_solver.py:14-51 */
+int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out);
+void mpmhip_destroy(mpmhip_ctx *ctx);
+/* text of the last error on ctx (ctx may be NULL for mpmhip_create failures) */
+const char *mpmhip_last_error(const mpmhip_ctx *ctx);
+
+/* ---- state / model binding ------------------------------------------------------ */
+/* MPMStateStruct.from_torch / reset_state / continue_from_torch rebind arrays
+ * (mpm_data_structure.py:158-419): call again whenever any pointer changes.  The caller's
+ * arrays are taken as the authoritative state at the next step. */
+int mpmhip_bind_state(mpmhip_ctx *ctx, const mpmhip_state_ptrs *p);
+/* MPMModelStruct.init + set_E_nu + prepare_mu_lam results, mpm_solver.py:128-227 */
+int mpmhip_bind_model(mpmhip_ctx *ctx, const mpmhip_model_ptrs *p);
+/* MPMWARP.set_parameters_dict scalars, mpm_solver.py:57-126 */
+int mpmhip_set_model_scalars(mpmhip_ctx *ctx, const mpmhip_model_scalars *s);
+/* The caller changed bound arrays in place (particle or model): re-import before the next step. */
+int mpmhip_push_state(mpmhip_ctx *ctx);
+/* Make the caller's particle_x/v/C/F/F_trial/stress/d/vertex_force current (the equivalent of the
+ * zero-copy wp.to_torch(mpm_state.particle_x) read, run_demo.py:532).  No-op in baseline mode. */
+int mpmhip_pull_state(mpmhip_ctx *ctx);
+
+/* ---- body mesh, colliders, boundary conditions ----------------------------------- */
+/* wp.Mesh(points, velocities=0, indices), mpm_solver.py:45-51.  verts/faces are [host]. */
+int mpmhip_set_body_mesh(mpmhip_ctx *ctx, int32_t n_verts, int32_t n_faces, const float *verts,
+                         const int32_t *faces);
+/* MPMWARP.add_mesh_collider, mpm_solver.py:805-919 */
+int mpmhip_add_mesh_collider(mpmhip_ctx *ctx, float friction);
+/* MPMWARP.add_particle_mover, mpm_solver.py:661-802 */
+int mpmhip_add_particle_mover(mpmhip_ctx *ctx);
+/* MPMWARP.add_surface_collider, mpm_solver.py:564-658; normal already normalised,
+ * surface_type 0 sticky / 1 slip / 11 cut / 2 other */
+int mpmhip_add_surface_collider(mpmhip_ctx *ctx, const float point[3], const float normal[3],
+                                int32_t surface_type, float friction, float start_time, float end_time);
+/* MPMWARP.set_velocity_on_cuboid, mpm_solver.py:929-984 (the host-side `modify` is applied inside step) */
+int mpmhip_add_velocity_cuboid(mpmhip_ctx *ctx, const float point[3], const float size[3],
+                               const float velocity[3], float start_time, float end_time, int32_t reset);
+/* MPMWARP.add_bounding_box, mpm_solver.py:986-1053 */
+int mpmhip_add_bounding_box(mpmhip_ctx *ctx, float start_time, float end_time);
+/* MPMWARP.enforce_grid_velocity_by_mask, mpm_solver.py:1330-1355; mask [dev] int32 [n_grid^3] */
+int mpmhip_add_grid_mask(mpmhip_ctx *ctx, const int32_t *mask);
+
+/* ---- pre-p2g particle operations (mpm_solver.py:1058-1417) ------------------------ */
+/* selection kernels, mpm_utils.py:1198-1248: write 0/1 into mask [dev] int32 [n_particles] */
+int mpmhip_select_box(mpmhip_ctx *ctx, const float point[3], const float size[3], int32_t *mask);
+int mpmhip_select_cylinder(mpmhip_ctx *ctx, const float point[3], const float normal[3],
+                           float half_height, float radius, int32_t *mask);
+/* add_impulse_on_particles (per_mass=1: v += force/mass*dt where mask==1, :1093-1104) and
+ * add_impulse_on_particles_with_mask (per_mass=0: v += force*dt where mask>=1, :1399-1415) */
+int mpmhip_add_impulse(mpmhip_ctx *ctx, const float force[3], const int32_t *mask, int32_t per_mass,
+                       float start_time, float end_time);
+/* enforce_particle_velocity_translation / _by_mask, :1138-1149, :1315-1326 */
+int mpmhip_add_velocity_set(mpmhip_ctx *ctx, const float velocity[3], const int32_t *mask,
+                            float start_time, float end_time);
+/* enforce_particle_velocity_rotation, :1156-1257 */
+int mpmhip_add_velocity_rotation(mpmhip_ctx *ctx, const float point[3], const float normal[3],
+                                 const float axis1[3], const float axis2[3], float rotation_scale,
+                                 float translation_scale, const int32_t *mask, float start_time,
+                                 float end_time);
+
+/* ---- the substep --------------------------------------------------------------------- */
+/* MPMWARP.p2g2p, mpm_solver.py:229-536.  mesh_x, mesh_v [dev][num_mesh_v*3]; joint_traditional_v
+ * [dev][n_joint_t*3]; joint_verts_v [dev][num_joint_v*3]; joint_faces_v [dev][num_joint_f*3];
+ * NULL = the Python argument None. */
+int mpmhip_step(mpmhip_ctx *ctx, float dt, const float *mesh_x, const float *mesh_v,
+                const float *joint_traditional_v, int32_t n_joint_t, const float *joint_verts_v,
+                const float *joint_faces_v);
+/* n substeps with the caller's per-substep mesh advection mesh_x + k*dt*mesh_v fused on the device
+ * (the loop at train_material_params.py:622-626 / run_demo.py:526-530) */
+int mpmhip_steps(mpmhip_ctx *ctx, float dt, int32_t n, const float *mesh_x, const float *mesh_v,
+                 const float *joint_traditional_v, int32_t n_joint_t, const float *joint_verts_v,
+                 const float *joint_faces_v);
+int mpmhip_synchronize(mpmhip_ctx *ctx);
+/* MPMWARP.time (never reset by reset_state, quirk Q3) */
+double mpmhip_get_time(const mpmhip_ctx *ctx);
+int mpmhip_set_time(mpmhip_ctx *ctx, double t);
+
+/* ---- introspection ---------------------------------------------------------------------- */
+/* dense reference-layout copies of grid_m [G^3], grid_v_in [G^3*3], grid_v_out [G^3*3] as they
+ * stand after the last substep's grid stage ([dev] outputs, any may be NULL).  Synchronous. */
+int mpmhip_export_grid(mpmhip_ctx *ctx, float *grid_m, float *grid_v_in, float *grid_v_out);
+/* counts for the algorithmic-bytes formula; synchronous, runs small count kernels */
+int mpmhip_get_stats(mpmhip_ctx *ctx, mpmhip_stats *out);
+/* MPMWARP.time_profile / print_time_profile, mpm_solver.py:16,538-541: when enabled every phase is
+ * bracketed by hipEvents (forces a sync per substep, like ScopedTimer(synchronize=True)). */
+int mpmhip_profile_enable(mpmhip_ctx *ctx, int32_t on);
+int mpmhip_profile_count(const mpmhip_ctx *ctx);
+/* i-th phase: name, accumulated milliseconds, number of samples */
+int mpmhip_profile_get(const mpmhip_ctx *ctx, int32_t i, const char **name, double *total_ms,
+                       int64_t *samples);
+int mpmhip_profile_reset(mpmhip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPMHIP_H */

@@ -1,0 +1,62 @@
+"""Build libmpmhip.so in-tree with hipcc for gfx950 (no CMake, no JIT cache).
+
+    python -m mpmavatar_amd.build [--force]
+
+The .so lands in mpmavatar_amd/lib/ (git-ignored, travels to the GPU box with the snapshot).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libmpmhip.so")
+SOURCES = ["api.hip", "common.hip", "baseline.hip", "fast.hip"]
+HEADERS = ["ctx.hpp", "mpm_math.hpp", "bc.hpp", os.path.join("..", "..", "include", "mpmhip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJDIR, s.replace(".hip", ".o"))
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for warn in ex.map(run, jobs):
+            if verbose and warn:
+                print(warn)
+    objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

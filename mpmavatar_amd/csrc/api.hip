@@ -1,0 +1,444 @@
+// api.hip -- the extern "C" boundary of libmpmhip.so (declared in include/mpmhip.h).
+// Host-side orchestration only: argument validation, context lifetime, dispatch to the fast or
+// baseline back end.  There is deliberately no CPU fallback: without a HIP device
+// mpmhip_create() fails with MPMHIP_ERR_NO_DEVICE.
+#include <cstring>
+
+#include "bc.hpp"
+#include "ctx.hpp"
+
+using namespace mpm;
+
+namespace {
+std::string g_create_error;
+
+__global__ void k_advect(const float *x0, const float *v, float f, float *out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = x0[i] + f * v[i];
+}
+
+bool fast_mode(const mpmhip_ctx *c) { return c->cfg.mode == MPMHIP_MODE_FAST; }
+}  // namespace
+
+extern "C" {
+
+int mpmhip_version(void) { return MPMHIP_VERSION; }
+
+int mpmhip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *mpmhip_last_error(const mpmhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
+  if (!cfg || !out) { g_create_error = "mpmhip_create: null argument"; return MPMHIP_ERR_INVALID; }
+  *out = nullptr;
+  if (cfg->n_particles < 0 || cfg->n_elements < 0 || cfg->n_vertices < 0 ||
+      cfg->n_elements + cfg->n_vertices > cfg->n_particles || cfg->n_grid < 8 || !(cfg->grid_lim > 0.f) ||
+      cfg->num_joint_v > cfg->n_vertices || cfg->num_joint_f > cfg->n_elements) {
+    g_create_error = "mpmhip_create: inconsistent sizes";
+    return MPMHIP_ERR_INVALID;
+  }
+  if (cfg->mode != MPMHIP_MODE_FAST && cfg->mode != MPMHIP_MODE_BASELINE) {
+    g_create_error = "mpmhip_create: unknown mode";
+    return MPMHIP_ERR_INVALID;
+  }
+  int ndev = mpmhip_device_count();
+  if (ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+    g_create_error = "mpmhip_create: no HIP device " + std::to_string(cfg->device) + " (visible devices: " +
+                     std::to_string(ndev) + "); libmpmhip has no CPU fallback";
+    return MPMHIP_ERR_NO_DEVICE;
+  }
+  mpmhip_ctx *c = new mpmhip_ctx();
+  c->cfg = *cfg;
+  c->n_nv = cfg->n_particles - cfg->n_vertices;
+  c->n_trad = c->n_nv - cfg->n_elements;
+  // MPMModelStruct.init_other_params, mpm_data_structure.py:692-697 (python doubles -> fp32 fields)
+  c->dx = (float)((double)cfg->grid_lim / (double)cfg->n_grid);
+  c->inv_dx = (float)((double)cfg->n_grid / (double)cfg->grid_lim);
+  c->sc.material = 0;
+  c->sc.softening = 0.1f;
+  c->sc.grid_v_damping_scale = 1.1f;
+  auto bail = [&](int code, const std::string &m) {
+    g_create_error = m;
+    mpmhip_destroy(c);
+    return code;
+  };
+  if (hipSetDevice(cfg->device) != hipSuccess) return bail(MPMHIP_ERR_HIP, "hipSetDevice failed");
+  if (!cfg->own_stream) {
+    c->stream = (hipStream_t)cfg->stream;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+      return bail(MPMHIP_ERR_HIP, "hipStreamCreate failed");
+    c->own_stream = true;
+  }
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
+    return bail(MPMHIP_ERR_HIP, "hipEventCreate failed");
+  int rc = fast_mode(c) ? fast_init(c) : baseline_init(c);
+  if (rc) return bail(rc, c->err);
+  *out = c;
+  return MPMHIP_OK;
+}
+
+void mpmhip_destroy(mpmhip_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->fast) fast_destroy(c);
+  for (float *p : {c->grid_m, c->grid_v_in, c->grid_v_out, c->mesh_points, c->mesh_vel, c->mesh_scratch})
+    if (p) (void)hipFree(p);
+  if (c->mesh_idx) (void)hipFree(c->mesh_idx);
+  if (!fast_mode(c)) {
+    for (auto &mc : c->colliders)
+      for (float *p : {mc.weight, mc.v_in, mc.normal})
+        if (p) (void)hipFree(p);
+    for (auto &mv : c->movers)
+      for (float *p : {mv.weight, mv.velocity})
+        if (p) (void)hipFree(p);
+  }
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+#define CHECK_CTX(c)                       \
+  if (!(c)) return MPMHIP_ERR_INVALID;     \
+  (void)hipSetDevice((c)->cfg.device)
+
+int mpmhip_bind_state(mpmhip_ctx *c, const mpmhip_state_ptrs *p) {
+  CHECK_CTX(c);
+  if (!p) return fail(c, MPMHIP_ERR_INVALID, "bind_state: null");
+  const int n_p = c->cfg.n_particles, n_e = c->cfg.n_elements, n_v = c->cfg.n_vertices;
+  bool ok = (n_p == 0) || (p->particle_x && p->particle_v && p->particle_C && p->particle_vol && p->particle_mass &&
+                           p->particle_selection);
+  if (c->n_nv > 0) ok = ok && p->particle_F && p->particle_F_trial && p->particle_stress;
+  if (n_e > 0) ok = ok && p->particle_d && p->particle_R_inv && p->faces;
+  if (n_v > 0) ok = ok && p->vertex_force;
+  if (!ok) return fail(c, MPMHIP_ERR_INVALID, "bind_state: a required array pointer is null");
+  // pending results of the internal state belong to the *old* arrays: flush them first
+  if (fast_mode(c) && c->st_bound && c->internal_dirty) {
+    int rc = fast_pull(c);
+    if (rc) return rc;
+  }
+  c->st = *p;
+  c->st_bound = true;
+  c->caller_dirty = true;
+  c->internal_dirty = false;
+  return MPMHIP_OK;
+}
+
+int mpmhip_bind_model(mpmhip_ctx *c, const mpmhip_model_ptrs *p) {
+  CHECK_CTX(c);
+  if (!p || (c->cfg.n_particles > 0 && !(p->mu && p->lam && p->gamma && p->kappa && p->yield_stress)))
+    return fail(c, MPMHIP_ERR_INVALID, "bind_model: a required array pointer is null");
+  if (fast_mode(c) && c->st_bound && c->internal_dirty) {
+    int rc = fast_pull(c);
+    if (rc) return rc;
+  }
+  c->md = *p;
+  c->md_bound = true;
+  c->caller_dirty = true;
+  return MPMHIP_OK;
+}
+
+int mpmhip_set_model_scalars(mpmhip_ctx *c, const mpmhip_model_scalars *s) {
+  CHECK_CTX(c);
+  if (!s) return fail(c, MPMHIP_ERR_INVALID, "set_model_scalars: null");
+  if (s->material < 0 || s->material > 7) return fail(c, MPMHIP_ERR_INVALID, "Undefined material type");
+  c->sc = *s;
+  return MPMHIP_OK;
+}
+
+int mpmhip_push_state(mpmhip_ctx *c) {
+  CHECK_CTX(c);
+  if (fast_mode(c) && c->st_bound && c->internal_dirty) {
+    // the caller is about to overwrite (part of) the arrays: make them current first so that
+    // fields it does not touch keep the simulated values
+    int rc = fast_pull(c);
+    if (rc) return rc;
+  }
+  c->caller_dirty = true;
+  return MPMHIP_OK;
+}
+
+int mpmhip_pull_state(mpmhip_ctx *c) {
+  CHECK_CTX(c);
+  if (!c->st_bound) return fail(c, MPMHIP_ERR_STATE, "pull_state: state not bound");
+  if (fast_mode(c) && c->internal_dirty) return fast_pull(c);
+  return MPMHIP_OK;
+}
+
+int mpmhip_set_body_mesh(mpmhip_ctx *c, int32_t n_verts, int32_t n_faces, const float *verts, const int32_t *faces) {
+  CHECK_CTX(c);
+  if (n_verts <= 0 || n_faces <= 0 || !verts || !faces) return fail(c, MPMHIP_ERR_INVALID, "set_body_mesh: bad mesh");
+  for (int i = 0; i < 3 * n_faces; ++i)
+    if (faces[i] < 0 || faces[i] >= n_verts) return fail(c, MPMHIP_ERR_INVALID, "set_body_mesh: face index out of range");
+  if (c->mesh_points) return fail(c, MPMHIP_ERR_INVALID, "set_body_mesh: mesh already set");
+  size_t nb = (size_t)n_verts * 3 * sizeof(float);
+  MPM_HIP_CHECK(c, hipMalloc(&c->mesh_points, nb));
+  MPM_HIP_CHECK(c, hipMalloc(&c->mesh_vel, nb));
+  MPM_HIP_CHECK(c, hipMalloc(&c->mesh_scratch, nb));
+  MPM_HIP_CHECK(c, hipMalloc(&c->mesh_idx, (size_t)n_faces * 3 * sizeof(int32_t)));
+  MPM_HIP_CHECK(c, hipMemcpy(c->mesh_points, verts, nb, hipMemcpyHostToDevice));
+  MPM_HIP_CHECK(c, hipMemset(c->mesh_vel, 0, nb));
+  MPM_HIP_CHECK(c, hipMemcpy(c->mesh_idx, faces, (size_t)n_faces * 3 * sizeof(int32_t), hipMemcpyHostToDevice));
+  c->num_mesh_v = n_verts;
+  c->num_mesh_f = n_faces;
+  return MPMHIP_OK;
+}
+
+int mpmhip_add_mesh_collider(mpmhip_ctx *c, float friction) {
+  CHECK_CTX(c);
+  if (!c->mesh_points) return fail(c, MPMHIP_ERR_STATE, "add_mesh_collider: no body mesh set");
+  if (c->colliders.size() >= 4) return fail(c, MPMHIP_ERR_LIMIT, "add_mesh_collider: at most 4 mesh colliders");
+  MeshCollider mc{};
+  mc.friction = friction;
+  int rc = fast_mode(c) ? fast_add_collider_storage(c, mc) : baseline_add_collider_storage(c, mc);
+  if (rc) return rc;
+  c->colliders.push_back(mc);
+  return MPMHIP_OK;
+}
+
+int mpmhip_add_particle_mover(mpmhip_ctx *c) {
+  CHECK_CTX(c);
+  if (c->movers.size() >= 2) return fail(c, MPMHIP_ERR_LIMIT, "add_particle_mover: at most 2 movers");
+  Mover mv{};
+  int rc = fast_mode(c) ? fast_add_mover_storage(c, mv) : baseline_add_mover_storage(c, mv);
+  if (rc) return rc;
+  c->movers.push_back(mv);
+  return MPMHIP_OK;
+}
+
+static int push_bc(mpmhip_ctx *c, const BC &bc) {
+  if ((int)c->bcs.size() >= MAX_BC) return fail(c, MPMHIP_ERR_LIMIT, "too many grid boundary conditions");
+  c->bcs.push_back(bc);
+  return MPMHIP_OK;
+}
+
+int mpmhip_add_surface_collider(mpmhip_ctx *c, const float point[3], const float normal[3], int32_t surface_type,
+                                float friction, float start_time, float end_time) {
+  CHECK_CTX(c);
+  if (surface_type == 0 && friction != 0.0f) return fail(c, MPMHIP_ERR_INVALID, "friction must be 0 on sticky surfaces.");
+  BC bc{};
+  bc.type = BC_SURFACE;
+  bc.surface_type = surface_type;
+  bc.friction = friction;
+  bc.start_time = start_time;
+  bc.end_time = end_time;
+  memcpy(bc.point, point, sizeof bc.point);
+  memcpy(bc.normal, normal, sizeof bc.normal);
+  return push_bc(c, bc);
+}
+
+int mpmhip_add_velocity_cuboid(mpmhip_ctx *c, const float point[3], const float size[3], const float velocity[3],
+                               float start_time, float end_time, int32_t reset) {
+  CHECK_CTX(c);
+  BC bc{};
+  bc.type = BC_CUBOID;
+  bc.reset = reset;
+  bc.start_time = start_time;
+  bc.end_time = end_time;
+  memcpy(bc.point, point, sizeof bc.point);
+  memcpy(bc.size, size, sizeof bc.size);
+  memcpy(bc.velocity, velocity, sizeof bc.velocity);
+  return push_bc(c, bc);
+}
+
+int mpmhip_add_bounding_box(mpmhip_ctx *c, float start_time, float end_time) {
+  CHECK_CTX(c);
+  BC bc{};
+  bc.type = BC_BBOX;
+  bc.start_time = start_time;
+  bc.end_time = end_time;
+  return push_bc(c, bc);
+}
+
+int mpmhip_add_grid_mask(mpmhip_ctx *c, const int32_t *mask) {
+  CHECK_CTX(c);
+  if (!mask) return fail(c, MPMHIP_ERR_INVALID, "add_grid_mask: null mask");
+  BC bc{};
+  bc.type = BC_GRIDMASK;
+  bc.mask = mask;
+  return push_bc(c, bc);
+}
+
+int mpmhip_select_box(mpmhip_ctx *c, const float point[3], const float size[3], int32_t *mask) {
+  CHECK_CTX(c);
+  if (!c->st_bound || !mask) return fail(c, MPMHIP_ERR_STATE, "select_box: state not bound / null mask");
+  int rc = mpmhip_pull_state(c);
+  if (rc) return rc;
+  return launch_select_box(c, c->st.particle_x, point, size, mask);
+}
+
+int mpmhip_select_cylinder(mpmhip_ctx *c, const float point[3], const float normal[3], float half_height, float radius,
+                           int32_t *mask) {
+  CHECK_CTX(c);
+  if (!c->st_bound || !mask) return fail(c, MPMHIP_ERR_STATE, "select_cylinder: state not bound / null mask");
+  int rc = mpmhip_pull_state(c);
+  if (rc) return rc;
+  return launch_select_cylinder(c, c->st.particle_x, point, normal, half_height, radius, mask);
+}
+
+static int push_pre(mpmhip_ctx *c, const PreOp &op) {
+  if (!op.mask) return fail(c, MPMHIP_ERR_INVALID, "particle operation: null mask");
+  if (c->pre.size() >= 256) return fail(c, MPMHIP_ERR_LIMIT, "too many particle operations");
+  c->pre.push_back(op);
+  return MPMHIP_OK;
+}
+
+int mpmhip_add_impulse(mpmhip_ctx *c, const float force[3], const int32_t *mask, int32_t per_mass, float start_time,
+                       float end_time) {
+  CHECK_CTX(c);
+  PreOp op{};
+  op.type = per_mass ? PRE_IMPULSE : PRE_IMPULSE_MASK;
+  op.start_time = start_time;
+  op.end_time = end_time;
+  op.mask = mask;
+  memcpy(op.force, force, sizeof op.force);
+  return push_pre(c, op);
+}
+
+int mpmhip_add_velocity_set(mpmhip_ctx *c, const float velocity[3], const int32_t *mask, float start_time,
+                            float end_time) {
+  CHECK_CTX(c);
+  PreOp op{};
+  op.type = PRE_VEL_SET;
+  op.start_time = start_time;
+  op.end_time = end_time;
+  op.mask = mask;
+  memcpy(op.velocity, velocity, sizeof op.velocity);
+  return push_pre(c, op);
+}
+
+int mpmhip_add_velocity_rotation(mpmhip_ctx *c, const float point[3], const float normal[3], const float axis1[3],
+                                 const float axis2[3], float rotation_scale, float translation_scale,
+                                 const int32_t *mask, float start_time, float end_time) {
+  CHECK_CTX(c);
+  PreOp op{};
+  op.type = PRE_VEL_ROTATE;
+  op.start_time = start_time;
+  op.end_time = end_time;
+  op.mask = mask;
+  op.rotation_scale = rotation_scale;
+  op.translation_scale = translation_scale;
+  memcpy(op.point, point, sizeof op.point);
+  memcpy(op.normal, normal, sizeof op.normal);
+  memcpy(op.axis1, axis1, sizeof op.axis1);
+  memcpy(op.axis2, axis2, sizeof op.axis2);
+  return push_pre(c, op);
+}
+
+static int step_checked(mpmhip_ctx *c, const StepArgs &a) {
+  if (!c->st_bound || !c->md_bound) return fail(c, MPMHIP_ERR_STATE, "step: state/model not bound");
+  if (a.n_joint_t < 0 || a.n_joint_t > c->n_trad) return fail(c, MPMHIP_ERR_INVALID, "step: n_joint_t out of range");
+  if ((a.mesh_x || a.mesh_v) && !c->mesh_points) return fail(c, MPMHIP_ERR_STATE, "step: mesh_x/mesh_v given but no body mesh");
+  size_t nb = (size_t)c->num_mesh_v * 3 * sizeof(float);
+  {
+    // set_vec3_to_vec3(mesh.points, mesh_x), (mesh.velocities, mesh_v): mpm_solver.py:285-315.
+    // Device-to-device; the reference's .cpu().numpy() round trip is not reproduced.
+    if (a.mesh_x) {
+      ScopedPhase ph(c, "update_mesh_positions");
+      MPM_HIP_CHECK(c, hipMemcpyAsync(c->mesh_points, a.mesh_x, nb, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (a.mesh_v) {
+      ScopedPhase ph(c, "update_mesh_velocities");
+      MPM_HIP_CHECK(c, hipMemcpyAsync(c->mesh_vel, a.mesh_v, nb, hipMemcpyDeviceToDevice, c->stream));
+    }
+  }
+  int rc = fast_mode(c) ? fast_step(c, a) : baseline_step(c, a);
+  if (rc) return rc;
+  c->time = c->time + (double)a.dt;  // mpm_solver.py:536
+  c->substeps += 1;
+  return MPMHIP_OK;
+}
+
+int mpmhip_step(mpmhip_ctx *c, float dt, const float *mesh_x, const float *mesh_v, const float *joint_traditional_v,
+                int32_t n_joint_t, const float *joint_verts_v, const float *joint_faces_v) {
+  CHECK_CTX(c);
+  StepArgs a{dt, mesh_x, mesh_v, joint_traditional_v, joint_traditional_v ? n_joint_t : 0, joint_verts_v, joint_faces_v};
+  return step_checked(c, a);
+}
+
+int mpmhip_steps(mpmhip_ctx *c, float dt, int32_t n, const float *mesh_x, const float *mesh_v,
+                 const float *joint_traditional_v, int32_t n_joint_t, const float *joint_verts_v,
+                 const float *joint_faces_v) {
+  CHECK_CTX(c);
+  if (n < 0) return fail(c, MPMHIP_ERR_INVALID, "steps: n < 0");
+  size_t nm = (size_t)c->num_mesh_v * 3;
+  for (int k = 0; k < n; ++k) {
+    const float *mx = mesh_x;
+    if (mesh_x && mesh_v && k > 0) {
+      // mesh_x + substep_size*substep_local*mesh_v, train_material_params.py:623
+      hipLaunchKernelGGL(k_advect, (unsigned)((nm + 255) / 256), 256, 0, c->stream, mesh_x, mesh_v,
+                         (float)((double)dt * (double)k), c->mesh_scratch, nm);
+      mx = c->mesh_scratch;
+    }
+    StepArgs a{dt, mx, mesh_v, joint_traditional_v, joint_traditional_v ? n_joint_t : 0, joint_verts_v, joint_faces_v};
+    int rc = step_checked(c, a);
+    if (rc) return rc;
+  }
+  return MPMHIP_OK;
+}
+
+int mpmhip_synchronize(mpmhip_ctx *c) {
+  CHECK_CTX(c);
+  MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return MPMHIP_OK;
+}
+
+double mpmhip_get_time(const mpmhip_ctx *c) { return c ? c->time : 0.0; }
+int mpmhip_set_time(mpmhip_ctx *c, double t) {
+  if (!c) return MPMHIP_ERR_INVALID;
+  c->time = t;
+  return MPMHIP_OK;
+}
+
+int mpmhip_export_grid(mpmhip_ctx *c, float *grid_m, float *grid_v_in, float *grid_v_out) {
+  CHECK_CTX(c);
+  if (fast_mode(c)) return fast_export_grid(c, grid_m, grid_v_in, grid_v_out);
+  size_t n = G3(c);
+  if (grid_m) MPM_HIP_CHECK(c, hipMemcpyAsync(grid_m, c->grid_m, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  if (grid_v_in) MPM_HIP_CHECK(c, hipMemcpyAsync(grid_v_in, c->grid_v_in, 3 * n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  if (grid_v_out) MPM_HIP_CHECK(c, hipMemcpyAsync(grid_v_out, c->grid_v_out, 3 * n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return MPMHIP_OK;
+}
+
+int mpmhip_get_stats(mpmhip_ctx *c, mpmhip_stats *out) {
+  CHECK_CTX(c);
+  if (!out) return fail(c, MPMHIP_ERR_INVALID, "get_stats: null");
+  memset(out, 0, sizeof *out);
+  out->substeps = c->substeps;
+  if (fast_mode(c)) return fast_stats(c, out);
+  size_t n = G3(c);
+  int rc = count_nonzero(c, c->grid_m, n, 0.0f, &out->n_active_nodes);
+  if (rc) return rc;
+  if (!c->colliders.empty()) rc = count_nonzero(c, c->colliders[0].weight, n, 1e-15f, &out->n_collider_nodes);
+  if (rc) return rc;
+  if (!c->movers.empty()) rc = count_nonzero(c, c->movers[0].weight, n, 1e-15f, &out->n_mover_nodes);
+  return rc;
+}
+
+int mpmhip_profile_enable(mpmhip_ctx *c, int32_t on) {
+  if (!c) return MPMHIP_ERR_INVALID;
+  c->profiling = on != 0;
+  return MPMHIP_OK;
+}
+int mpmhip_profile_count(const mpmhip_ctx *c) { return c ? (int)c->phases.size() : 0; }
+int mpmhip_profile_get(const mpmhip_ctx *c, int32_t i, const char **name, double *total_ms, int64_t *samples) {
+  if (!c || i < 0 || i >= (int)c->phases.size()) return MPMHIP_ERR_INVALID;
+  if (name) *name = c->phases[i].name;
+  if (total_ms) *total_ms = c->phases[i].total_ms;
+  if (samples) *samples = c->phases[i].samples;
+  return MPMHIP_OK;
+}
+int mpmhip_profile_reset(mpmhip_ctx *c) {
+  if (!c) return MPMHIP_ERR_INVALID;
+  c->phases.clear();
+  return MPMHIP_OK;
+}
+
+}  // extern "C"

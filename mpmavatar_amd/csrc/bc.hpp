@@ -1,0 +1,67 @@
+// bc.hpp -- grid boundary conditions evaluated per node (shared by both back ends).
+// Reference: the `collide` closures registered by add_surface_collider (mpm_solver.py:600-655),
+// set_velocity_on_cuboid (:950-973), add_bounding_box (:993-1050), enforce_grid_velocity_by_mask
+// (:1341-1352).  Node position = index * dx.
+#pragma once
+#include "ctx.hpp"
+#include "mpm_math.hpp"
+
+namespace mpm {
+
+// returns true when v was (re)written
+__device__ __forceinline__ bool apply_bc(const BC &bc, V3 &v, int gx, int gy, int gz, int G, float dx, float time,
+                                         float dt, size_t dense_index) {
+  if (bc.type == BC_GRIDMASK) {
+    if (bc.mask[dense_index] >= 1) { v = v3(0, 0, 0); return true; }
+    return false;
+  }
+  bool in_window = time >= bc.start_time && time < bc.end_time;
+  if (bc.type == BC_SURFACE) {
+    if (!in_window) return false;
+    V3 off = v3((float)gx * dx - bc.point[0], (float)gy * dx - bc.point[1], (float)gz * dx - bc.point[2]);
+    float dp = off.x * bc.normal[0] + off.y * bc.normal[1] + off.z * bc.normal[2];
+    if (!(dp < 0.0f)) return false;
+    if (bc.surface_type == 11) {
+      float z = (float)gz * dx;
+      if (z < 0.4f || z > 0.53f) v = v3(0, 0, 0);
+      else v = v3(v.x * 0.3f, 0.0f, v.z * 0.3f);
+    } else {
+      // sticky; slip / frictional surfaces also end in a zero write (quirk Q1, mpm_solver.py:653-655)
+      v = v3(0, 0, 0);
+    }
+    return true;
+  }
+  if (bc.type == BC_CUBOID) {
+    if (in_window) {
+      V3 off = v3((float)gx * dx - bc.point[0], (float)gy * dx - bc.point[1], (float)gz * dx - bc.point[2]);
+      if (fabsf(off.x) < bc.size[0] && fabsf(off.y) < bc.size[1] && fabsf(off.z) < bc.size[2]) {
+        v = v3(bc.velocity[0], bc.velocity[1], bc.velocity[2]);
+        return true;
+      }
+      return false;
+    }
+    if (bc.reset == 1 && time < bc.end_time + 15.0f * dt) { v = v3(0, 0, 0); return true; }
+    return false;
+  }
+  if (bc.type == BC_BBOX) {
+    if (!in_window) return false;
+    const int padding = 3;
+    bool ch = false;
+    if (gx < padding && v.x < 0.0f) { v.x = 0.0f; ch = true; }
+    if (gx >= G - padding && v.x > 0.0f) { v.x = 0.0f; ch = true; }
+    if (gy < padding && v.y < 0.0f) { v.y = 0.0f; ch = true; }
+    if (gy >= G - padding && v.y > 0.0f) { v.y = 0.0f; ch = true; }
+    if (gz < padding && v.z < 0.0f) { v.z = 0.0f; ch = true; }
+    if (gz >= G - padding && v.z > 0.0f) { v.z = 0.0f; ch = true; }
+    return ch;
+  }
+  return false;
+}
+
+// host-side `modify` of set_velocity_on_cuboid, mpm_solver.py:975-981
+inline void bc_host_modify(BC &bc, float time, float dt) {
+  if (bc.type == BC_CUBOID && time >= bc.start_time && time < bc.end_time)
+    for (int a = 0; a < 3; ++a) bc.point[a] = bc.point[a] + dt * bc.velocity[a];
+}
+
+}  // namespace mpm

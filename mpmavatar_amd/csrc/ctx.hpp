@@ -1,0 +1,165 @@
+// ctx.hpp -- solver context shared by the C-ABI layer and the two kernel back ends.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/mpmhip.h"
+
+namespace mpm {
+
+enum BCType { BC_SURFACE = 0, BC_CUBOID = 1, BC_BBOX = 2, BC_GRIDMASK = 3 };
+enum PreType { PRE_IMPULSE = 0, PRE_IMPULSE_MASK = 1, PRE_VEL_SET = 2, PRE_VEL_ROTATE = 3 };
+
+struct BC {  // POD, passed to kernels by value
+  int type, surface_type, reset, pad_;
+  float point[3], normal[3], size[3], velocity[3];
+  float friction, start_time, end_time;
+  const int32_t *mask;
+};
+constexpr int MAX_BC = 8;
+struct BCList {
+  int n;
+  BC bc[MAX_BC];
+};
+
+struct PreOp {
+  int type;
+  float start_time, end_time;
+  float force[3], velocity[3], point[3], normal[3], axis1[3], axis2[3];
+  float rotation_scale, translation_scale;
+  const int32_t *mask;
+};
+
+struct MeshCollider {
+  float friction;
+  float *weight, *v_in, *normal;  // dense [G^3], [G^3*3] (baseline) or blocked (fast)
+};
+struct Mover {
+  float *weight, *velocity;
+};
+
+struct StepArgs {
+  float dt;
+  const float *mesh_x, *mesh_v;
+  const float *joint_t_v;
+  int n_joint_t;
+  const float *joint_v_v, *joint_f_v;
+};
+
+struct Phase {
+  const char *name;
+  double total_ms = 0.0;
+  int64_t samples = 0;
+};
+
+struct FastState;  // defined in fast.hip
+
+}  // namespace mpm
+
+struct mpmhip_ctx {
+  mpmhip_config cfg{};
+  int n_nv = 0, n_trad = 0;
+  float dx = 0.f, inv_dx = 0.f;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+
+  mpmhip_state_ptrs st{};
+  bool st_bound = false;
+  mpmhip_model_ptrs md{};
+  bool md_bound = false;
+  mpmhip_model_scalars sc{};
+
+  // dense reference-layout grid (baseline mode; fast mode allocates it lazily for export only)
+  float *grid_m = nullptr, *grid_v_in = nullptr, *grid_v_out = nullptr;
+
+  // body mesh (wp.Mesh): points/velocities updated every substep
+  int num_mesh_v = 0, num_mesh_f = 0;
+  float *mesh_points = nullptr, *mesh_vel = nullptr;
+  int32_t *mesh_idx = nullptr;
+  float *mesh_scratch = nullptr;  // advected mesh_x for mpmhip_steps
+
+  std::vector<mpm::MeshCollider> colliders;
+  std::vector<mpm::Mover> movers;
+  std::vector<mpm::BC> bcs;
+  std::vector<mpm::PreOp> pre;
+
+  double time = 0.0;
+  int64_t substeps = 0;
+  std::string err;
+
+  bool profiling = false;
+  std::vector<mpm::Phase> phases;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  mpm::FastState *fast = nullptr;
+  bool caller_dirty = true;    // caller arrays newer than the internal state (fast mode)
+  bool internal_dirty = false; // internal state newer than the caller arrays (fast mode)
+};
+
+namespace mpm {
+
+inline int fail(mpmhip_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#define MPM_HIP_CHECK(ctx, expr)                                                              \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return mpm::fail(ctx, MPMHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+inline size_t G3(const mpmhip_ctx *c) { return (size_t)c->cfg.n_grid * c->cfg.n_grid * c->cfg.n_grid; }
+
+// profiling brackets: no-ops unless enabled (then one sync per phase, like ScopedTimer(synchronize=True))
+struct ScopedPhase {
+  mpmhip_ctx *c;
+  int idx;
+  ScopedPhase(mpmhip_ctx *ctx, const char *name) : c(ctx), idx(-1) {
+    if (!c->profiling) return;
+    for (size_t i = 0; i < c->phases.size(); ++i)
+      if (c->phases[i].name == name || std::string(c->phases[i].name) == name) idx = (int)i;
+    if (idx < 0) {
+      c->phases.push_back(Phase{name});
+      idx = (int)c->phases.size() - 1;
+    }
+    (void)hipEventRecord(c->ev0, c->stream);
+  }
+  ~ScopedPhase() {
+    if (idx < 0) return;
+    (void)hipEventRecord(c->ev1, c->stream);
+    (void)hipEventSynchronize(c->ev1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->phases[idx].total_ms += ms;
+    c->phases[idx].samples += 1;
+  }
+};
+
+int baseline_init(mpmhip_ctx *ctx);
+int baseline_step(mpmhip_ctx *ctx, const StepArgs &a);
+int baseline_add_collider_storage(mpmhip_ctx *ctx, MeshCollider &mc);
+int baseline_add_mover_storage(mpmhip_ctx *ctx, Mover &mv);
+
+int fast_init(mpmhip_ctx *ctx);
+void fast_destroy(mpmhip_ctx *ctx);
+int fast_step(mpmhip_ctx *ctx, const StepArgs &a);
+int fast_pull(mpmhip_ctx *ctx);
+int fast_export_grid(mpmhip_ctx *ctx, float *m, float *v_in, float *v_out);
+int fast_stats(mpmhip_ctx *ctx, mpmhip_stats *out);
+int fast_add_collider_storage(mpmhip_ctx *ctx, MeshCollider &mc);
+int fast_add_mover_storage(mpmhip_ctx *ctx, Mover &mv);
+
+// shared small kernels (common.hip)
+int launch_pre_ops(mpmhip_ctx *ctx, float dt, float *v, const float *x, const float *mass, int n);
+int launch_select_box(mpmhip_ctx *ctx, const float *x, const float point[3], const float size[3], int32_t *mask);
+int launch_select_cylinder(mpmhip_ctx *ctx, const float *x, const float point[3], const float normal[3],
+                           float half_height, float radius, int32_t *mask);
+int count_nonzero(mpmhip_ctx *ctx, const float *a, size_t n, float thresh, int *out);
+
+}  // namespace mpm

@@ -1,0 +1,121 @@
+"""GPU parity: the HIP solver (through the C ABI via the warp_mpm shim) against the serial fp32 CPU oracle
+on identical seeded inputs.  PARITY UNPINNED with respect to the reference itself (Warp not runnable here);
+the oracle is pinned by tests/test_oracle_*.py.
+
+Tolerances (BASELINE.json north_star: particle x / v within 1e-4 relative after N substeps):
+  rel(a, b) = max|a-b| / max(max|b|, 1e-3).
+Cloth scenes carry a documented caveat: the reference's anisotropic return mapping is discontinuous at
+R22 == 1 (mpm_utils.py:196-204: shear kept above, projected to ~0 just below), so fp32 rounding-order
+differences flip branches and velocities decorrelate at the 1e-3..1e-2 level while positions stay < 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from mpmavatar_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+MODES = ["baseline", "fast"]
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-3))
+
+
+def _run_pair(sc, n_steps, mode, fused=False):
+    from mpmavatar_amd import harness
+    from oracle.scene_adapter import oracle_from_scene, run_scene
+    o = oracle_from_scene(sc)
+    run_scene(o, sc, n_steps)
+    sim = harness.build_solver(sc, "cuda:0", mode=mode)
+    harness.run(sim, n_steps, fused=fused)
+    st = sim.state
+    out = {k: getattr(st, k).detach().cpu().numpy() for k in
+           ("particle_x", "particle_v", "particle_C", "particle_F_trial", "particle_d")}
+    return o, out, sim
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("material", ["jelly", "sand", "metal", "foam", "plasticine"])
+def test_cube_materials(mode, material, oracle_lib):
+    params = {"friction_angle": 40.0} if material == "sand" else {}
+    if material in ("metal", "foam", "plasticine"):
+        params.update({"yield_stress": 2.0, "hardening": 1, "xi": 0.1, "plastic_viscosity": 0.5})
+    sc = scenes.small_cube(material=material, params=params)
+    o, g, _ = _run_pair(sc, 100, mode)
+    assert np.isfinite(g["particle_x"]).all()
+    assert rel(g["particle_x"], o.x) < 1e-4
+    assert rel(g["particle_v"], o.v) < 1e-4
+    assert rel(g["particle_F_trial"], o.F_trial) < 1e-4
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_sheet_over_sphere(mode, oracle_lib):
+    sc = scenes.small_sheet()
+    o, g, _ = _run_pair(sc, 200, mode)
+    assert np.isfinite(g["particle_x"]).all()
+    assert rel(g["particle_x"], o.x) < 1e-4
+    assert rel(g["particle_v"], o.v) < 5e-2   # see module docstring: branch flips at R22 == 1
+    assert rel(g["particle_d"], o.d) < 5e-2
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_sheet_short_strict(mode, oracle_lib):
+    """Few substeps: before branch flips decorrelate velocities the strict 1e-4 bound holds on everything."""
+    sc = scenes.small_sheet()
+    o, g, _ = _run_pair(sc, 1, mode)
+    assert rel(g["particle_x"], o.x) < 1e-6
+    assert rel(g["particle_v"], o.v) < 1e-4
+    assert rel(g["particle_C"], o.C) < 1e-4
+    assert rel(g["particle_d"], o.d) < 1e-5
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_garment_with_mover(mode, oracle_lib):
+    sc = scenes.small_garment()
+    o, g, _ = _run_pair(sc, 100, mode)
+    assert rel(g["particle_x"], o.x) < 1e-4
+    assert rel(g["particle_v"], o.v) < 5e-2
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_demo_mix(mode, oracle_lib):
+    sc = scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8))
+    o, g, _ = _run_pair(sc, 100, mode)
+    assert rel(g["particle_x"], o.x) < 1e-4
+    assert rel(g["particle_v"], o.v) < 5e-3
+    assert rel(g["particle_F_trial"], o.F_trial) < 1e-4
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_fused_steps_match_single_steps(mode, oracle_lib):
+    sc = scenes.small_garment()
+    from mpmavatar_amd import harness
+    a = harness.build_solver(sc, "cuda:0", mode=mode)
+    b = harness.build_solver(sc, "cuda:0", mode=mode)
+    harness.run(a, 20, fused=False)
+    harness.run(b, 20, fused=True)
+    xa, xb = a.state.particle_x.cpu().numpy(), b.state.particle_x.cpu().numpy()
+    assert rel(xa, xb) < 1e-5
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_grid_fields_after_one_step(mode, oracle_lib):
+    """Grid-level parity: dense exports of grid_m / grid_v_out against the oracle's arrays."""
+    sc = scenes.small_sheet()
+    o, g, sim = _run_pair(sc, 1, mode)
+    m, vi, vo = sim.solver.export_grid()
+    G = sc.n_grid
+    om = o.grid_m.reshape(G, G, G)
+    assert rel(m.cpu().numpy(), om) < 1e-5
+    act = om > 1e-14  # away from the 1e-15 mass threshold
+    assert rel(vo.cpu().numpy()[act], o.grid_v_out.reshape(G, G, G, 3)[act]) < 1e-4
+
+
+def test_no_device_is_loud():
+    from mpmavatar_amd.warp_mpm import MPMWARP
+    from mpmavatar_amd._lib import MPMHipError
+    with pytest.raises(MPMHipError):
+        MPMWARP(8, 0, 0, n_grid=16, grid_lim=2.0, device="cpu")
