@@ -1,13 +1,1068 @@
-// placeholder, replaced below
+// fast.hip -- MPMHIP_MODE_FAST: the MI355X-native substep.
+//
+// Data layout:
+//   * particles live in a solver-owned SoA copy (component-major fp32 arrays), ordered class-major
+//     (elements | traditional | vertices) and, inside each class, by (4x4x4-cell grid block, cell).  The
+//     order is rebuilt every `rebin_interval` substeps (rocPRIM radix sort of 30-bit keys + one gather
+//     pass); between rebuilds a particle may drift by up to one cell, which the transfer tiles absorb.
+//   * the grid is stored block-major: block b = (x>>2,y>>2,z>>2) owns 64 nodes, channel-major inside the
+//     block ([block][channel][64 nodes]) so one wavefront reads one channel of one block as 256 B.
+//     Only blocks on the active list (27-neighbourhoods of particle blocks) are ever swept or zeroed.
+// Kernels per substep:
+//   stress (per-particle map)  ->  p2g (one workgroup per particle block chunk: LDS 8x8x8-node tile,
+//   ds_add_f32 accumulation, coalesced flush)  [+ body-face / joint splats]  ->  grid (normalise, gravity,
+//   collider, mover, BCs, re-zero)  ->  g2p (LDS-staged 8x8x8 v_out tile)  ->  element finalise.
+// Reference semantics: /root/reference/warp_mpm/mpm_utils.py, mpm_solver.py:229-536 (cited per kernel).
+#include <algorithm>
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "bc.hpp"
 #include "ctx.hpp"
+#include "mpm_math.hpp"
+
 namespace mpm {
-struct FastState {};
-int fast_init(mpmhip_ctx *c) { return fail(c, MPMHIP_ERR_INVALID, "fast mode not built yet"); }
-void fast_destroy(mpmhip_ctx *) {}
-int fast_step(mpmhip_ctx *c, const StepArgs &) { return fail(c, MPMHIP_ERR_INVALID, "fast mode not built yet"); }
-int fast_pull(mpmhip_ctx *c) { return MPMHIP_OK; }
-int fast_export_grid(mpmhip_ctx *c, float *, float *, float *) { return fail(c, MPMHIP_ERR_INVALID, "n/a"); }
-int fast_stats(mpmhip_ctx *c, mpmhip_stats *) { return MPMHIP_OK; }
-int fast_add_collider_storage(mpmhip_ctx *c, MeshCollider &) { return MPMHIP_OK; }
-int fast_add_mover_storage(mpmhip_ctx *c, Mover &) { return MPMHIP_OK; }
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int CHUNK = 256;     // particles per class handled by one workgroup of p2g / g2p
+constexpr int TILE = 8;        // tile edge in nodes: block (4) + 1 below + 3 above
+constexpr int TILE3 = TILE * TILE * TILE;
+inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+
+// component-major array view: comp c of item i at p[c*n + i]
+struct Soa {
+  float *p;
+  int n;
+  __device__ __forceinline__ float &at(int c, int i) const { return p[(size_t)c * n + i]; }
+};
+__device__ __forceinline__ V3 ld3(const Soa &a, int c0, int i) { return v3(a.at(c0, i), a.at(c0 + 1, i), a.at(c0 + 2, i)); }
+__device__ __forceinline__ void st3(const Soa &a, int c0, int i, V3 v) {
+  a.at(c0, i) = v.x; a.at(c0 + 1, i) = v.y; a.at(c0 + 2, i) = v.z;
 }
+__device__ __forceinline__ M3 ld9(const Soa &a, int c0, int i) {
+  return M3{a.at(c0, i), a.at(c0 + 1, i), a.at(c0 + 2, i), a.at(c0 + 3, i), a.at(c0 + 4, i),
+            a.at(c0 + 5, i), a.at(c0 + 6, i), a.at(c0 + 7, i), a.at(c0 + 8, i)};
+}
+__device__ __forceinline__ void st9(const Soa &a, int c0, int i, const M3 &m) {
+  a.at(c0, i) = m.a00; a.at(c0 + 1, i) = m.a01; a.at(c0 + 2, i) = m.a02; a.at(c0 + 3, i) = m.a10;
+  a.at(c0 + 4, i) = m.a11; a.at(c0 + 5, i) = m.a12; a.at(c0 + 6, i) = m.a20; a.at(c0 + 7, i) = m.a21;
+  a.at(c0 + 8, i) = m.a22;
+}
+
+// component indices
+enum { A_X = 0, A_V = 3, A_C = 6, A_MASS = 15, A_NC = 16 };                       // all particles
+enum { N_STRESS = 0, N_VOL = 9, N_MU = 10, N_LAM = 11, N_NC = 12 };                // elements + traditional
+enum { E_D = 0, E_RINV = 9, E_GAMMA = 12, E_KAPPA = 13, E_NC = 14 };               // elements
+enum { T_F = 0, T_FT = 9, T_YS = 18, T_NC = 19 };                                  // traditional
+enum { GCH_MV = 4, GCH_VOUT = 4, GCH_COL = 8, GCH_MOV = 4 };                       // grid channels per block
+
+struct Bufs {
+  Soa all, nv, el, tr;
+  int *face_orig;  // [3][n_e] component-major original vertex-local ids
+  int *sel;        // [n_p]
+};
+
+struct Dims {
+  int n_p, n_e, n_nv, n_v, n_t;
+  int G, NB;
+  float dx, inv_dx, grid_lim;
+};
+
+__device__ __forceinline__ int blk_of(int x, int y, int z, int NB) { return ((x >> 2) * NB + (y >> 2)) * NB + (z >> 2); }
+__device__ __forceinline__ int loc_of(int x, int y, int z) { return ((x & 3) << 4) | ((y & 3) << 2) | (z & 3); }
+__device__ __forceinline__ bool in_grid(int x, int y, int z, int G) {
+  return (unsigned)x < (unsigned)G && (unsigned)y < (unsigned)G && (unsigned)z < (unsigned)G;
+}
+// XCD-aware remap: consecutive workgroup ids land on different XCDs (observed: id % 8), so give each XCD a
+// contiguous slice of the (block-sorted) work list and keep neighbouring tiles in one L2.
+__device__ __forceinline__ int xcd_slice(int w, int n) {
+  int per = (n + 7) >> 3;
+  int i = (w & 7) * per + (w >> 3);
+  return i < n ? i : -1;
+}
+inline unsigned xcd_grid(int n) { return (unsigned)(((n + 7) / 8) * 8); }
+
+// ------------------------------------------------------------------------------------------------
+// import / export between the caller's AoS arrays (reference layout) and the sorted SoA state
+// ------------------------------------------------------------------------------------------------
+__global__ void k_import(mpmhip_state_ptrs st, mpmhip_model_ptrs md, Bufs b, const int *perm, Dims d) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.n_p) return;
+  int o = perm[s];
+  for (int c = 0; c < 3; ++c) b.all.at(A_X + c, s) = st.particle_x[3 * (size_t)o + c];
+  for (int c = 0; c < 3; ++c) b.all.at(A_V + c, s) = st.particle_v[3 * (size_t)o + c];
+  for (int c = 0; c < 9; ++c) b.all.at(A_C + c, s) = st.particle_C[9 * (size_t)o + c];
+  b.all.at(A_MASS, s) = st.particle_mass[o];
+  b.sel[s] = st.particle_selection[o];
+  if (s < d.n_nv) {
+    for (int c = 0; c < 9; ++c) b.nv.at(N_STRESS + c, s) = st.particle_stress[9 * (size_t)o + c];
+    b.nv.at(N_VOL, s) = st.particle_vol[o];
+    b.nv.at(N_MU, s) = md.mu[o];
+    b.nv.at(N_LAM, s) = md.lam[o];
+    if (s < d.n_e) {
+      for (int c = 0; c < 9; ++c) b.el.at(E_D + c, s) = st.particle_d[9 * (size_t)o + c];
+      for (int c = 0; c < 3; ++c) b.el.at(E_RINV + c, s) = st.particle_R_inv[3 * (size_t)o + c];
+      b.el.at(E_GAMMA, s) = md.gamma[o];
+      b.el.at(E_KAPPA, s) = md.kappa[o];
+      for (int c = 0; c < 3; ++c) b.face_orig[c * d.n_e + s] = (int)st.faces[3 * (size_t)o + c];
+    } else {
+      int t = s - d.n_e;
+      for (int c = 0; c < 9; ++c) b.tr.at(T_F + c, t) = st.particle_F[9 * (size_t)o + c];
+      for (int c = 0; c < 9; ++c) b.tr.at(T_FT + c, t) = st.particle_F_trial[9 * (size_t)o + c];
+      b.tr.at(T_YS, t) = md.yield_stress[o];
+    }
+  }
+}
+
+__global__ void k_export(mpmhip_state_ptrs st, mpmhip_model_ptrs md, Bufs b, const float *vforce, const int *perm,
+                         Dims d, int export_model) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.n_p) return;
+  int o = perm[s];
+  for (int c = 0; c < 3; ++c) st.particle_x[3 * (size_t)o + c] = b.all.at(A_X + c, s);
+  for (int c = 0; c < 3; ++c) st.particle_v[3 * (size_t)o + c] = b.all.at(A_V + c, s);
+  for (int c = 0; c < 9; ++c) st.particle_C[9 * (size_t)o + c] = b.all.at(A_C + c, s);
+  if (s < d.n_nv) {
+    for (int c = 0; c < 9; ++c) st.particle_stress[9 * (size_t)o + c] = b.nv.at(N_STRESS + c, s);
+    if (s < d.n_e) {
+      for (int c = 0; c < 9; ++c) st.particle_d[9 * (size_t)o + c] = b.el.at(E_D + c, s);
+    } else {
+      int t = s - d.n_e;
+      for (int c = 0; c < 9; ++c) st.particle_F[9 * (size_t)o + c] = b.tr.at(T_F + c, t);
+      for (int c = 0; c < 9; ++c) st.particle_F_trial[9 * (size_t)o + c] = b.tr.at(T_FT + c, t);
+      if (export_model) {
+        md.yield_stress[o] = b.tr.at(T_YS, t);
+        md.mu[o] = b.nv.at(N_MU, s);
+        md.lam[o] = b.nv.at(N_LAM, s);
+      }
+    }
+  } else {
+    int v = s - d.n_nv;
+    for (int c = 0; c < 3; ++c) st.vertex_force[3 * (size_t)(o - d.n_nv) + c] = vforce[(size_t)c * d.n_v + v];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rebin: keys, permutation, block tables
+// ------------------------------------------------------------------------------------------------
+// key = class | inactive | block | cell-in-block ; the low 6 bits order particles of a block by cell
+__device__ __forceinline__ unsigned make_key(V3 x, int cls, int inactive, const Dims &d, int blk_bits) {
+  int bx = (int)(x.x * d.inv_dx - 0.5f), by = (int)(x.y * d.inv_dx - 0.5f), bz = (int)(x.z * d.inv_dx - 0.5f);
+  bx = min(max(bx, 0), d.G - 3); by = min(max(by, 0), d.G - 3); bz = min(max(bz, 0), d.G - 3);
+  unsigned blk = (unsigned)blk_of(bx, by, bz, d.NB);
+  unsigned cell = (unsigned)loc_of(bx, by, bz);
+  return ((unsigned)cls << (blk_bits + 7)) | ((unsigned)inactive << (blk_bits + 6)) | (blk << 6) | cell;
+}
+
+__global__ void k_keys(Bufs b, Dims d, int blk_bits, unsigned *keys, int *iota) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.n_p) return;
+  int cls = s < d.n_e ? 0 : (s < d.n_nv ? 1 : 2);
+  V3 x = ld3(b.all, A_X, s);
+  keys[s] = make_key(x, cls, b.sel[s] != 0 ? 1 : 0, d, blk_bits);
+  iota[s] = s;
+}
+
+__global__ void k_permute(Bufs src, Bufs dst, const int *order, const int *perm_src, int *perm_dst, int *inv, Dims d) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.n_p) return;
+  int o = order[s];  // same class as s: the class is the key's most significant field
+  for (int c = 0; c < A_NC; ++c) dst.all.at(c, s) = src.all.at(c, o);
+  dst.sel[s] = src.sel[o];
+  int po = perm_src[o];
+  perm_dst[s] = po;
+  inv[po] = s;
+  if (s < d.n_nv) {
+    for (int c = 0; c < N_NC; ++c) dst.nv.at(c, s) = src.nv.at(c, o);
+    if (s < d.n_e) {
+      for (int c = 0; c < E_NC; ++c) dst.el.at(c, s) = src.el.at(c, o);
+      for (int c = 0; c < 3; ++c) dst.face_orig[c * d.n_e + s] = src.face_orig[c * d.n_e + o];
+    } else {
+      for (int c = 0; c < T_NC; ++c) dst.tr.at(c, s - d.n_e) = src.tr.at(c, o - d.n_e);
+    }
+  }
+}
+
+// sorted slot (vertex-local) of each element's three vertices
+__global__ void k_face_slots(Bufs b, const int *inv, int *face_slot, Dims d) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d.n_e) return;
+  for (int c = 0; c < 3; ++c) face_slot[c * d.n_e + e] = inv[d.n_nv + b.face_orig[c * d.n_e + e]] - d.n_nv;
+}
+
+__device__ __forceinline__ int key_block(unsigned k, int blk_bits) { return (int)((k >> 6) & ((1u << blk_bits) - 1u)); }
+__device__ __forceinline__ bool key_inactive(unsigned k, int blk_bits) { return (k >> (blk_bits + 6)) & 1u; }
+
+__global__ void k_mark_blocks(const unsigned *keys, int n, int blk_bits, int *pb_flag) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  unsigned k = keys[s];
+  if (!key_inactive(k, blk_bits)) pb_flag[key_block(k, blk_bits)] = 1;
+}
+
+__global__ void k_compact(const int *flag, const int *index, int n, int *list) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < n && flag[b]) list[index[b]] = b;
+}
+
+// ranges[(cls*2+0)*n_P + slot] = first sorted index, [(cls*2+1)*n_P + slot] = one past the last
+__global__ void k_ranges(const unsigned *keys, Dims d, int blk_bits, const int *pb_index, int n_P, int *ranges) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.n_p) return;
+  unsigned k = keys[s];
+  if (key_inactive(k, blk_bits)) return;
+  int cls = s < d.n_e ? 0 : (s < d.n_nv ? 1 : 2);
+  int c0 = cls == 0 ? 0 : (cls == 1 ? d.n_e : d.n_nv), c1 = cls == 0 ? d.n_e : (cls == 1 ? d.n_nv : d.n_p);
+  int slot = pb_index[key_block(k, blk_bits)];
+  if (s == c0 || (keys[s - 1] >> 6) != (k >> 6)) ranges[(cls * 2 + 0) * n_P + slot] = s;
+  if (s == c1 - 1 || (keys[s + 1] >> 6) != (k >> 6)) ranges[(cls * 2 + 1) * n_P + slot] = s + 1;
+}
+
+__global__ void k_dilate(const int *plist, int n_P, int NB, int *ab_flag) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int p = t / 27, nb = t % 27;
+  if (p >= n_P) return;
+  int b = plist[p];
+  int bz = b % NB, by = (b / NB) % NB, bx = b / (NB * NB);
+  int x = bx + nb / 9 - 1, y = by + (nb / 3) % 3 - 1, z = bz + nb % 3 - 1;
+  if ((unsigned)x < (unsigned)NB && (unsigned)y < (unsigned)NB && (unsigned)z < (unsigned)NB)
+    ab_flag[(x * NB + y) * NB + z] = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stress (compute_stress_from_F_trial, mpm_utils.py:1017-1105) on the sorted SoA state
+// ------------------------------------------------------------------------------------------------
+__global__ void k_stress_elem(Bufs b, const int *face_slot, float *vforce, Dims d, float friction_coeff) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d.n_e) return;
+  if (b.sel[e] != 0) return;
+  M3 dm = ld9(b.el, E_D, e);
+  QR3 q = qr_cloth(dm);
+  float gamma = b.el.at(E_GAMMA, e), kappa = b.el.at(E_KAPPA, e);
+  float r02, r12, r22;
+  V3 d3 = anisotropy_return_mapping(q, gamma, kappa, friction_coeff, r02, r12, r22);
+  b.el.at(E_D + 2, e) = d3.x; b.el.at(E_D + 5, e) = d3.y; b.el.at(E_D + 8, e) = d3.z;
+  M3 stress;
+  V3 f1, f2, f3;
+  kirchhoff_anisotropy(q, r02, r12, r22, d3, ld3(b.el, E_RINV, e), b.nv.at(N_VOL, e), b.nv.at(N_MU, e),
+                       b.nv.at(N_LAM, e), gamma, kappa, stress, f1, f2, f3);
+  st9(b.nv, N_STRESS, e, stress);
+  int v1 = face_slot[e], v2 = face_slot[d.n_e + e], v3i = face_slot[2 * d.n_e + e];
+  int nv = d.n_v;
+  atomicAdd(vforce + v1, f1.x); atomicAdd(vforce + nv + v1, f1.y); atomicAdd(vforce + 2 * nv + v1, f1.z);
+  atomicAdd(vforce + v2, f2.x); atomicAdd(vforce + nv + v2, f2.y); atomicAdd(vforce + 2 * nv + v2, f2.z);
+  atomicAdd(vforce + v3i, f3.x); atomicAdd(vforce + nv + v3i, f3.y); atomicAdd(vforce + 2 * nv + v3i, f3.z);
+}
+
+__global__ void k_stress_trad(Bufs b, Dims d, mpmhip_model_scalars sc, float dt) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= d.n_t) return;
+  int s = t + d.n_e;
+  if (b.sel[s] != 0) return;
+  M3 Ft = ld9(b.tr, T_FT, t), F = Ft;
+  float mu = b.nv.at(N_MU, s), lam = b.nv.at(N_LAM, s);
+  int m = sc.material;
+  if (m == 1 || m == 5) {
+    float ys = b.tr.at(T_YS, t);
+    F = von_mises_return_mapping(Ft, ys, mu, lam, sc.hardening, sc.xi, sc.softening, m == 5);
+    b.tr.at(T_YS, t) = ys;
+    if (m == 5) { b.nv.at(N_MU, s) = mu; b.nv.at(N_LAM, s) = lam; }
+  } else if (m == 2) {
+    F = sand_return_mapping(Ft, mu, lam, sc.alpha);
+  } else if (m == 3) {
+    F = viscoplasticity_return_mapping(Ft, b.tr.at(T_YS, t), mu, sc.plastic_viscosity, dt);
+  }
+  st9(b.tr, T_F, t, F);
+  M3 stress = m3_zero();
+  if (m == 0 || m == 1 || m == 2 || m == 3 || m == 5) {
+    float J = det(F);
+    M3 U, V;
+    V3 sig;
+    svd3(F, U, sig, V);
+    if (m == 0 || m == 5) stress = kirchhoff_FCR(F, U, V, J, mu, lam);
+    else if (m == 2) stress = kirchhoff_drucker_prager(F, U, V, sig, mu, lam);
+    else stress = kirchhoff_StVK(F, U, V, sig, mu, lam);
+    stress = 0.5f * (stress + transpose(stress));
+  }
+  st9(b.nv, N_STRESS, s, stress);
+}
+
+// ------------------------------------------------------------------------------------------------
+// p2g (p2g_apic_with_stress, mpm_utils.py:484-557): LDS tile accumulation per particle-block chunk
+// ------------------------------------------------------------------------------------------------
+struct GridPtrs {
+  float *mv;        // [block][4][64]: m, momentum xyz
+  float *vout;      // [block][4][64]: v_out xyz, m (copy kept for introspection)
+  float *col;       // [block][8][64]: weight, v_in xyz, normal xyz, pad
+  float *mov;       // [block][4][64]: weight, velocity xyz
+  const int *ab_flag;
+  int *counters;    // [0] particles outside their tile margin, [1] dropped contributions (inactive block)
+};
+
+// slow path for a particle that drifted out of its tile margin: straight to the global grid
+__device__ __noinline__ void p2g_scatter_global(const Stencil &s, float mass, V3 v, const M3 &C, const M3 &S,
+                                                V3 vforce, bool is_vert, float dt, const Dims &d, GridPtrs g) {
+  atomicAdd(g.counters + 0, 1);
+  for (int n = 0; n < 27; ++n) {
+    int i = n / 9, j = (n / 3) % 3, k = n % 3;
+    float wx = sel3(i, s.w0.x, s.w1.x, s.w2.x), wy = sel3(j, s.w0.y, s.w1.y, s.w2.y), wz = sel3(k, s.w0.z, s.w1.z, s.w2.z);
+    float dwx = sel3(i, s.dw0.x, s.dw1.x, s.dw2.x), dwy = sel3(j, s.dw0.y, s.dw1.y, s.dw2.y), dwz = sel3(k, s.dw0.z, s.dw1.z, s.dw2.z);
+    float weight = wx * wy * wz;
+    V3 dweight = d.inv_dx * v3(dwx * wy * wz, wx * dwy * wz, wx * wy * dwz);
+    V3 dpos = d.dx * v3((float)i - s.fx.x, (float)j - s.fx.y, (float)k - s.fx.z);
+    V3 force = is_vert ? weight * vforce : -1.0f * (S * dweight);
+    V3 add = (weight * mass) * (v + C * dpos) + dt * force;
+    int x = s.bx + i, y = s.by + j, z = s.bz + k;
+    if (!in_grid(x, y, z, d.G)) continue;
+    int blk = blk_of(x, y, z, d.NB);
+    if (!g.ab_flag[blk]) { atomicAdd(g.counters + 1, 1); continue; }
+    float *p = g.mv + ((size_t)blk * GCH_MV) * 64 + loc_of(x, y, z);
+    atomicAdd(p, weight * mass);
+    atomicAdd(p + 64, add.x); atomicAdd(p + 128, add.y); atomicAdd(p + 192, add.z);
+  }
+}
+
+__device__ __forceinline__ void p2g_particle(float *tile, int ox, int oy, int oz, V3 x, float mass, V3 v, M3 C,
+                                             const M3 &S, V3 vforce, bool is_vert, float rpic, float dt, const Dims &d,
+                                             GridPtrs g) {
+  C = (1.0f - rpic) * C + (rpic / 2.0f) * (C - transpose(C));
+  if (rpic < -0.001f) C = m3_zero();
+  Stencil s = make_stencil(x, d.inv_dx);
+  int lx = s.bx - ox, ly = s.by - oy, lz = s.bz - oz;
+  if ((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u) {
+    p2g_scatter_global(s, mass, v, C, S, vforce, is_vert, dt, d, g);
+    return;
+  }
+  int base = (lx * TILE + ly) * TILE + lz;
+  // v + C*dpos = a0 + dx*(i*Ccol0 + j*Ccol1 + k*Ccol2)
+  V3 a0 = v - d.dx * (C * s.fx);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float wx = sel3(i, s.w0.x, s.w1.x, s.w2.x), dwx = sel3(i, s.dw0.x, s.dw1.x, s.dw2.x);
+    V3 ai = a0 + (d.dx * (float)i) * col0(C);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float wy = sel3(j, s.w0.y, s.w1.y, s.w2.y), dwy = sel3(j, s.dw0.y, s.dw1.y, s.dw2.y);
+      V3 aij = ai + (d.dx * (float)j) * col1(C);
+      float wxy = wx * wy;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float wz = sel3(k, s.w0.z, s.w1.z, s.w2.z), dwz = sel3(k, s.dw0.z, s.dw1.z, s.dw2.z);
+        float weight = wxy * wz;
+        V3 vel = aij + (d.dx * (float)k) * col2(C);
+        V3 force;
+        if (is_vert) force = weight * vforce;
+        else force = -1.0f * (S * (d.inv_dx * v3(dwx * wy * wz, wx * dwy * wz, wxy * dwz)));
+        float wm = weight * mass;
+        V3 add = wm * vel + dt * force;
+        int t = base + (i * TILE + j) * TILE + k;
+        atomicAdd(tile + t, wm);
+        atomicAdd(tile + TILE3 + t, add.x);
+        atomicAdd(tile + 2 * TILE3 + t, add.y);
+        atomicAdd(tile + 3 * TILE3 + t, add.z);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_p2g(Bufs b, const float *vforce, const int *plist, const int *ranges,
+                                             const int *chunks, int n_chunks, int n_P, Dims d, float rpic, float dt,
+                                             GridPtrs g) {
+  __shared__ float tile[4 * TILE3];
+  int w = xcd_slice(blockIdx.x, n_chunks);
+  if (w < 0) return;
+  int slot = chunks[2 * w], chunk = chunks[2 * w + 1];
+  int blk = plist[slot];
+  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
+  int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
+  for (int t = threadIdx.x; t < 4 * TILE3; t += TPB) tile[t] = 0.0f;
+  __syncthreads();
+  // elements: S = stress (already times vol)
+  {
+    int s0 = ranges[0 * n_P + slot] + chunk * CHUNK, s1 = min(ranges[1 * n_P + slot], s0 + CHUNK);
+    for (int s = s0 + threadIdx.x; s < s1; s += TPB)
+      p2g_particle(tile, ox, oy, oz, ld3(b.all, A_X, s), b.all.at(A_MASS, s), ld3(b.all, A_V, s), ld9(b.all, A_C, s),
+                   ld9(b.nv, N_STRESS, s), v3(0, 0, 0), false, rpic, dt, d, g);
+  }
+  // traditional: S = vol * stress
+  {
+    int s0 = ranges[2 * n_P + slot] + chunk * CHUNK, s1 = min(ranges[3 * n_P + slot], s0 + CHUNK);
+    for (int s = s0 + threadIdx.x; s < s1; s += TPB)
+      p2g_particle(tile, ox, oy, oz, ld3(b.all, A_X, s), b.all.at(A_MASS, s), ld3(b.all, A_V, s), ld9(b.all, A_C, s),
+                   b.nv.at(N_VOL, s) * ld9(b.nv, N_STRESS, s), v3(0, 0, 0), false, rpic, dt, d, g);
+  }
+  // vertices: force = weight * vertex_force
+  {
+    int s0 = ranges[4 * n_P + slot] + chunk * CHUNK, s1 = min(ranges[5 * n_P + slot], s0 + CHUNK);
+    for (int s = s0 + threadIdx.x; s < s1; s += TPB) {
+      int vl = s - d.n_nv;
+      p2g_particle(tile, ox, oy, oz, ld3(b.all, A_X, s), b.all.at(A_MASS, s), ld3(b.all, A_V, s), ld9(b.all, A_C, s),
+                   m3_zero(), v3(vforce[vl], vforce[d.n_v + vl], vforce[2 * d.n_v + vl]), true, rpic, dt, d, g);
+    }
+  }
+  __syncthreads();
+  // flush: skip untouched nodes; every touched node lies in an active block by construction
+  for (int t = threadIdx.x; t < TILE3; t += TPB) {
+    float m = tile[t], px = tile[TILE3 + t], py = tile[2 * TILE3 + t], pz = tile[3 * TILE3 + t];
+    if (m == 0.0f && px == 0.0f && py == 0.0f && pz == 0.0f) continue;
+    int x = ox + (t >> 6), y = oy + ((t >> 3) & 7), z = oz + (t & 7);
+    if (!in_grid(x, y, z, d.G)) continue;
+    float *p = g.mv + ((size_t)blk_of(x, y, z, d.NB) * GCH_MV) * 64 + loc_of(x, y, z);
+    atomicAdd(p, m);
+    atomicAdd(p + 64, px); atomicAdd(p + 128, py); atomicAdd(p + 192, pz);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// body-face splat (compute_mesh, mpm_solver.py:829-880) and joint splat (:677-788) into active blocks
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool splat_ok(int G, const Stencil &s) {
+  return s.bx >= 0 && s.bx < G - 3 && s.by >= 0 && s.by < G - 3 && s.bz >= 0 && s.bz < G - 3;
+}
+
+__global__ void k_face_splat(const float *pts, const float *vel, const int32_t *idx, int n_f, Dims d, GridPtrs g) {
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_f) return;
+  int i0 = idx[3 * f], i1 = idx[3 * f + 1], i2 = idx[3 * f + 2];
+  V3 p0 = load_v3(pts + 3 * i0), p1 = load_v3(pts + 3 * i1), p2 = load_v3(pts + 3 * i2);
+  V3 fp = v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
+  Stencil s = make_stencil(fp, d.inv_dx);
+  if (!splat_ok(d.G, s)) return;
+  // cull faces whose 3x3x3 nodes touch no active block: those nodes are never read by g2p
+  bool any = false;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    int x = s.bx + ((c & 1) ? 2 : 0), y = s.by + ((c & 2) ? 2 : 0), z = s.bz + ((c & 4) ? 2 : 0);
+    any = any || g.ab_flag[blk_of(x, y, z, d.NB)];
+  }
+  if (!any) return;
+  V3 u0 = load_v3(vel + 3 * i0), u1 = load_v3(vel + 3 * i1), u2 = load_v3(vel + 3 * i2);
+  V3 fv = v3((u0.x + u1.x + u2.x) / 3.0f, (u0.y + u1.y + u2.y) / 3.0f, (u0.z + u1.z + u2.z) / 3.0f);
+  V3 fn = normalize(cross(p1 - p0, p2 - p0));
+  for (int n = 0; n < 27; ++n) {
+    int i = n / 9, j = (n / 3) % 3, k = n % 3;
+    float w = sel3(i, s.w0.x, s.w1.x, s.w2.x) * sel3(j, s.w0.y, s.w1.y, s.w2.y) * sel3(k, s.w0.z, s.w1.z, s.w2.z);
+    int x = s.bx + i, y = s.by + j, z = s.bz + k;
+    int blk = blk_of(x, y, z, d.NB);
+    if (!g.ab_flag[blk]) continue;
+    float *p = g.col + ((size_t)blk * GCH_COL) * 64 + loc_of(x, y, z);
+    atomicAdd(p, w);
+    atomicAdd(p + 64, w * fv.x); atomicAdd(p + 128, w * fv.y); atomicAdd(p + 192, w * fv.z);
+    atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
+  }
+}
+
+// particle with ORIGINAL index (off + t) gets prescribed velocity vel[t]
+__global__ void k_mover_splat(Bufs b, const int *inv, const float *vel, int n, int off, Dims d, GridPtrs g) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  int sidx = inv[off + t];
+  Stencil s = make_stencil(ld3(b.all, A_X, sidx), d.inv_dx);
+  if (!splat_ok(d.G, s)) return;
+  V3 pv = load_v3(vel + 3 * (size_t)t);
+  for (int nn = 0; nn < 27; ++nn) {
+    int i = nn / 9, j = (nn / 3) % 3, k = nn % 3;
+    float w = sel3(i, s.w0.x, s.w1.x, s.w2.x) * sel3(j, s.w0.y, s.w1.y, s.w2.y) * sel3(k, s.w0.z, s.w1.z, s.w2.z);
+    int x = s.bx + i, y = s.by + j, z = s.bz + k;
+    int blk = blk_of(x, y, z, d.NB);
+    if (!g.ab_flag[blk]) { atomicAdd(g.counters + 1, 1); continue; }
+    float *p = g.mov + ((size_t)blk * GCH_MOV) * 64 + loc_of(x, y, z);
+    atomicAdd(p, w);
+    atomicAdd(p + 64, w * pv.x); atomicAdd(p + 128, w * pv.y); atomicAdd(p + 192, w * pv.z);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid stage over active blocks: grid_normalization_and_gravity (mpm_utils.py:561-572), damping
+// (:1162-1174), mesh collide (mpm_solver.py:882-917), mover overwrite (:790-799), BCs in registration
+// order (:487-501); then re-zero the accumulators for the next substep (replaces zero_grid, :411-417).
+// One wavefront per block, lane = node.
+// ------------------------------------------------------------------------------------------------
+struct GridParams {
+  float dt, gx, gy, gz, damping, time;
+  int has_col, has_mov, mov_on;
+  float col_friction;
+  int count;
+};
+
+__global__ __launch_bounds__(TPB) void k_grid(const int *alist, int n_A, Dims d, GridPtrs g, GridParams gp, BCList bcl) {
+  int w = xcd_slice(blockIdx.x, (n_A + 3) / 4);
+  if (w < 0) return;
+  int a = w * 4 + (threadIdx.x >> 6);
+  if (a >= n_A) return;
+  int blk = alist[a], l = threadIdx.x & 63;
+  float *pm = g.mv + ((size_t)blk * GCH_MV) * 64 + l;
+  float m = pm[0], px = pm[64], py = pm[128], pz = pm[192];
+  V3 v = v3(0, 0, 0);
+  int ncol = 0, nmov = 0;
+  if (m > 1e-15f) {
+    float inv = 1.0f / m;
+    v = v3(px * inv + gp.dt * gp.gx, py * inv + gp.dt * gp.gy, pz * inv + gp.dt * gp.gz);
+  }
+  if (gp.damping < 1.0f) v = v - (1.0f - gp.damping) * v;
+  if (m != 0.0f || px != 0.0f || py != 0.0f || pz != 0.0f) { pm[0] = 0.0f; pm[64] = 0.0f; pm[128] = 0.0f; pm[192] = 0.0f; }
+  if (gp.has_col) {
+    float *pc = g.col + ((size_t)blk * GCH_COL) * 64 + l;
+    float wc = pc[0];
+    if (wc != 0.0f) {
+      V3 vin = v3(pc[64], pc[128], pc[192]), nrm = v3(pc[256], pc[320], pc[384]);
+      if (wc > 1e-15f) { v = collide_node(v, (1.0f / wc) * vin, nrm, gp.col_friction); ncol = 1; }
+      pc[0] = 0.0f; pc[64] = 0.0f; pc[128] = 0.0f; pc[192] = 0.0f; pc[256] = 0.0f; pc[320] = 0.0f; pc[384] = 0.0f;
+    }
+  }
+  if (gp.has_mov && gp.mov_on) {
+    float *pv = g.mov + ((size_t)blk * GCH_MOV) * 64 + l;
+    float wv = pv[0];
+    if (wv != 0.0f) {
+      if (wv > 1e-15f) { v = (1.0f / wv) * v3(pv[64], pv[128], pv[192]); nmov = 1; }
+      pv[0] = 0.0f; pv[64] = 0.0f; pv[128] = 0.0f; pv[192] = 0.0f;
+    }
+  }
+  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
+  int gxn = 4 * bx + (l >> 4), gyn = 4 * by + ((l >> 2) & 3), gzn = 4 * bz + (l & 3);
+  if (bcl.n > 0 && in_grid(gxn, gyn, gzn, d.G)) {
+    size_t dense = ((size_t)gxn * d.G + gyn) * d.G + gzn;
+    for (int k = 0; k < bcl.n; ++k) apply_bc(bcl.bc[k], v, gxn, gyn, gzn, d.G, d.dx, gp.time, gp.dt, dense);
+  }
+  float *po = g.vout + ((size_t)blk * GCH_VOUT) * 64 + l;
+  po[0] = v.x; po[64] = v.y; po[128] = v.z; po[192] = m;
+  if (gp.count) {  // statistics for the algorithmic-bytes formula (N_coll, N_mov), one atomic per wavefront
+    unsigned long long bc = __ballot(ncol), bm = __ballot(nmov);
+    if (l == 0) {
+      if (bc) atomicAdd(g.counters + 2, __popcll(bc));
+      if (bm) atomicAdd(g.counters + 3, __popcll(bm));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// g2p (g2p_v / g2p_e, mpm_utils.py:716-857) with the v_out tile staged in LDS
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void g2p_gather(const float *tile, int ox, int oy, int oz, V3 x, const Dims &d,
+                                           const GridPtrs &g, V3 &nv, M3 &nC, M3 &nF) {
+  Stencil s = make_stencil(x, d.inv_dx);
+  int lx = s.bx - ox, ly = s.by - oy, lz = s.bz - oz;
+  bool in_tile = !((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u);
+  int base = (lx * TILE + ly) * TILE + lz;
+  nv = v3(0, 0, 0);
+  nC = m3_zero();
+  nF = m3_zero();
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float wx = sel3(i, s.w0.x, s.w1.x, s.w2.x), wy = sel3(j, s.w0.y, s.w1.y, s.w2.y), wz = sel3(k, s.w0.z, s.w1.z, s.w2.z);
+        float dwx = sel3(i, s.dw0.x, s.dw1.x, s.dw2.x), dwy = sel3(j, s.dw0.y, s.dw1.y, s.dw2.y), dwz = sel3(k, s.dw0.z, s.dw1.z, s.dw2.z);
+        float weight = wx * wy * wz;
+        V3 dweight = d.inv_dx * v3(dwx * wy * wz, wx * dwy * wz, wx * wy * dwz);
+        V3 dpos = v3((float)i - s.fx.x, (float)j - s.fx.y, (float)k - s.fx.z);
+        V3 gv;
+        if (in_tile) {
+          int t = base + (i * TILE + j) * TILE + k;
+          gv = v3(tile[t], tile[TILE3 + t], tile[2 * TILE3 + t]);
+        } else {  // drifted out of the tile margin: read the global grid (zero outside active blocks)
+          int x_ = s.bx + i, y_ = s.by + j, z_ = s.bz + k;
+          gv = v3(0, 0, 0);
+          if (in_grid(x_, y_, z_, d.G)) {
+            int blk = blk_of(x_, y_, z_, d.NB);
+            if (g.ab_flag[blk]) {
+              const float *p = g.vout + ((size_t)blk * GCH_VOUT) * 64 + loc_of(x_, y_, z_);
+              gv = v3(p[0], p[64], p[128]);
+            }
+          }
+        }
+        nv = nv + weight * gv;
+        nC = nC + (weight * d.inv_dx * 4.0f) * outer(gv, dpos);
+        nF = nF + outer(gv, dweight);
+      }
+}
+
+__global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const int *plist, const int *ranges, const int *chunks,
+                                             int n_chunks, int n_P, Dims d, float dt, GridPtrs g) {
+  __shared__ float tile[3 * TILE3];
+  int w = xcd_slice(blockIdx.x, n_chunks);
+  if (w < 0) return;
+  int slot = chunks[2 * w], chunk = chunks[2 * w + 1];
+  int blk = plist[slot];
+  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
+  int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
+  for (int t = threadIdx.x; t < TILE3; t += TPB) {
+    int x = ox + (t >> 6), y = oy + ((t >> 3) & 7), z = oz + (t & 7);
+    V3 v = v3(0, 0, 0);
+    if (in_grid(x, y, z, d.G)) {
+      const float *p = g.vout + ((size_t)blk_of(x, y, z, d.NB) * GCH_VOUT) * 64 + loc_of(x, y, z);
+      v = v3(p[0], p[64], p[128]);
+    }
+    tile[t] = v.x; tile[TILE3 + t] = v.y; tile[2 * TILE3 + t] = v.z;
+  }
+  __syncthreads();
+  float a_min = (1.0f / d.inv_dx) * 2.0f, a_max = d.grid_lim - (1.0f / d.inv_dx) * 2.0f;
+  // elements: C now; d3 <- (I + dt grad v) d3 now; x, v, d1, d2 in k_elem_finalize once all vertices are updated
+  {
+    int s0 = ranges[0 * n_P + slot] + chunk * CHUNK, s1 = min(ranges[1 * n_P + slot], s0 + CHUNK);
+    for (int s = s0 + threadIdx.x; s < s1; s += TPB) {
+      V3 nv; M3 nC, nF;
+      g2p_gather(tile, ox, oy, oz, ld3(b.all, A_X, s), d, g, nv, nC, nF);
+      st9(b.all, A_C, s, nC);
+      V3 d3 = v3(b.el.at(E_D + 2, s), b.el.at(E_D + 5, s), b.el.at(E_D + 8, s));
+      V3 d3n = (m3_identity() + dt * nF) * d3;
+      b.el.at(E_D + 2, s) = d3n.x; b.el.at(E_D + 5, s) = d3n.y; b.el.at(E_D + 8, s) = d3n.z;
+    }
+  }
+  // traditional
+  {
+    int s0 = ranges[2 * n_P + slot] + chunk * CHUNK, s1 = min(ranges[3 * n_P + slot], s0 + CHUNK);
+    for (int s = s0 + threadIdx.x; s < s1; s += TPB) {
+      V3 x = ld3(b.all, A_X, s), nv; M3 nC, nF;
+      g2p_gather(tile, ox, oy, oz, x, d, g, nv, nC, nF);
+      st3(b.all, A_V, s, nv);
+      V3 nx = x + dt * nv;
+      st3(b.all, A_X, s, v3(fminf(fmaxf(nx.x, a_min), a_max), fminf(fmaxf(nx.y, a_min), a_max), fminf(fmaxf(nx.z, a_min), a_max)));
+      st9(b.all, A_C, s, nC);
+      int t = s - d.n_e;
+      st9(b.tr, T_FT, t, (m3_identity() + dt * nF) * ld9(b.tr, T_F, t));
+    }
+  }
+  // vertices
+  {
+    int s0 = ranges[4 * n_P + slot] + chunk * CHUNK, s1 = min(ranges[5 * n_P + slot], s0 + CHUNK);
+    for (int s = s0 + threadIdx.x; s < s1; s += TPB) {
+      V3 x = ld3(b.all, A_X, s), nv; M3 nC, nF;
+      g2p_gather(tile, ox, oy, oz, x, d, g, nv, nC, nF);
+      st3(b.all, A_V, s, nv);
+      V3 nx = x + dt * nv;
+      st3(b.all, A_X, s, v3(fminf(fmaxf(nx.x, a_min), a_max), fminf(fmaxf(nx.y, a_min), a_max), fminf(fmaxf(nx.z, a_min), a_max)));
+      st9(b.all, A_C, s, nC);
+    }
+  }
+}
+
+// second half of g2p_e (mpm_utils.py:838-857): x, v = mean of the three updated vertices; d1, d2 = edges
+__global__ void k_elem_finalize(Bufs b, const int *face_slot, Dims d) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d.n_e) return;
+  if (b.sel[e] != 0) return;
+  int v1 = d.n_nv + face_slot[e], v2 = d.n_nv + face_slot[d.n_e + e], v3i = d.n_nv + face_slot[2 * d.n_e + e];
+  V3 x1 = ld3(b.all, A_X, v1), x2 = ld3(b.all, A_X, v2), x3 = ld3(b.all, A_X, v3i);
+  V3 u1 = ld3(b.all, A_V, v1), u2 = ld3(b.all, A_V, v2), u3 = ld3(b.all, A_V, v3i);
+  st3(b.all, A_V, e, v3((u1.x + u2.x + u3.x) / 3.0f, (u1.y + u2.y + u3.y) / 3.0f, (u1.z + u2.z + u3.z) / 3.0f));
+  st3(b.all, A_X, e, v3((x1.x + x2.x + x3.x) / 3.0f, (x1.y + x2.y + x3.y) / 3.0f, (x1.z + x2.z + x3.z) / 3.0f));
+  V3 d1 = x2 - x1, d2 = x3 - x1;
+  b.el.at(E_D + 0, e) = d1.x; b.el.at(E_D + 3, e) = d1.y; b.el.at(E_D + 6, e) = d1.z;
+  b.el.at(E_D + 1, e) = d2.x; b.el.at(E_D + 4, e) = d2.y; b.el.at(E_D + 7, e) = d2.z;
+}
+
+// pre-p2g particle operations on the sorted state (masks are in the caller's particle order)
+__global__ void k_pre_sorted(PreOp op, Bufs b, const int *perm, Dims d, float dt) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.n_p) return;
+  int mk = op.mask[perm[s]];
+  V3 pv = ld3(b.all, A_V, s);
+  if (op.type == PRE_IMPULSE) {
+    if (mk != 1) return;
+    float m = b.all.at(A_MASS, s);
+    pv = pv + dt * v3(op.force[0] / m, op.force[1] / m, op.force[2] / m);
+  } else if (op.type == PRE_IMPULSE_MASK) {
+    if (mk < 1) return;
+    pv = pv + dt * v3(op.force[0], op.force[1], op.force[2]);
+  } else if (op.type == PRE_VEL_SET) {
+    if (mk != 1) return;
+    pv = v3(op.velocity[0], op.velocity[1], op.velocity[2]);
+  } else {
+    if (mk != 1) return;
+    V3 nrm = v3(op.normal[0], op.normal[1], op.normal[2]);
+    V3 a1 = v3(op.axis1[0], op.axis1[1], op.axis1[2]), a2 = v3(op.axis2[0], op.axis2[1], op.axis2[2]);
+    V3 off = ld3(b.all, A_X, s) - v3(op.point[0], op.point[1], op.point[2]);
+    float hd = length(off - dot(off, nrm) * nrm);
+    float theta = acosf(dot(off, a1) / hd);
+    if (!(dot(off, a2) > 0.0f)) theta = -theta;
+    pv = (-hd * sinf(theta) * op.rotation_scale) * a1 + (hd * cosf(theta) * op.rotation_scale) * a2 + op.translation_scale * nrm;
+  }
+  st3(b.all, A_V, s, pv);
+}
+
+__global__ void k_export_grid(const int *alist, int n_A, Dims d, GridPtrs g, float *gm, float *gvo) {
+  int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (a >= n_A) return;
+  int blk = alist[a], l = threadIdx.x & 63;
+  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
+  int x = 4 * bx + (l >> 4), y = 4 * by + ((l >> 2) & 3), z = 4 * bz + (l & 3);
+  if (!in_grid(x, y, z, d.G)) return;
+  size_t dense = ((size_t)x * d.G + y) * d.G + z;
+  const float *po = g.vout + ((size_t)blk * GCH_VOUT) * 64 + l;
+  if (gm) gm[dense] = po[192];
+  if (gvo) { gvo[3 * dense] = po[0]; gvo[3 * dense + 1] = po[64]; gvo[3 * dense + 2] = po[128]; }
+}
+
+__global__ void k_count_active(const int *alist, int n_A, GridPtrs g, int *out) {
+  int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int c = 0;
+  if (a < n_A) c = g.vout[((size_t)alist[a] * GCH_VOUT) * 64 + 192 + (threadIdx.x & 63)] > 0.0f ? 1 : 0;
+  unsigned long long bal = __ballot(c);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(out, __popcll(bal));
+}
+
+__global__ void k_iota(int *p, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+}  // namespace
+
+// ================================================================================================
+// host side
+// ================================================================================================
+struct FastState {
+  Dims d{};
+  int blk_bits = 0, key_bits = 0;
+  size_t nblocks = 0;
+  Bufs buf[2]{};
+  int cur = 0;
+  int *perm[2] = {nullptr, nullptr}, *inv = nullptr, *face_slot = nullptr;
+  float *vforce = nullptr;
+  unsigned *keys[2] = {nullptr, nullptr};
+  int *order = nullptr, *iota = nullptr;
+  void *sort_tmp = nullptr, *scan_tmp = nullptr;
+  size_t sort_tmp_bytes = 0, scan_tmp_bytes = 0;
+  GridPtrs g{};
+  int *pb_flag = nullptr, *pb_index = nullptr, *ab_flag = nullptr, *ab_index = nullptr;
+  int *plist = nullptr, *alist = nullptr, *ranges = nullptr, *chunks = nullptr;
+  int cap_P = 0, cap_A = 0, cap_chunks = 0, cap_R = 0;
+  int64_t stat_steps = 0;
+  int n_P = 0, n_A = 0, n_chunks = 0;
+  int *h_pin = nullptr;  // pinned host scratch
+  std::vector<int> h_ranges, h_chunks;
+  int steps_since_rebin = 0;
+  bool have_order = false;
+  int64_t rebins = 0;
+  int rebin_interval = 32;
+  std::vector<void *> allocs;
+};
+
+namespace {
+
+template <class T>
+int dalloc(mpmhip_ctx *c, T **p, size_t count, bool zero = true) {
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  MPM_HIP_CHECK(c, hipMalloc((void **)p, bytes));
+  c->fast->allocs.push_back((void *)*p);
+  if (zero) MPM_HIP_CHECK(c, hipMemsetAsync(*p, 0, bytes, c->stream));
+  return MPMHIP_OK;
+}
+
+int alloc_bufs(mpmhip_ctx *c, Bufs &b) {
+  const Dims &d = c->fast->d;
+  int rc;
+  if ((rc = dalloc(c, &b.all.p, (size_t)A_NC * d.n_p))) return rc;
+  if ((rc = dalloc(c, &b.nv.p, (size_t)N_NC * d.n_nv))) return rc;
+  if ((rc = dalloc(c, &b.el.p, (size_t)E_NC * d.n_e))) return rc;
+  if ((rc = dalloc(c, &b.tr.p, (size_t)T_NC * d.n_t))) return rc;
+  if ((rc = dalloc(c, &b.face_orig, (size_t)3 * d.n_e))) return rc;
+  if ((rc = dalloc(c, &b.sel, (size_t)d.n_p))) return rc;
+  b.all.n = d.n_p; b.nv.n = d.n_nv; b.el.n = d.n_e; b.tr.n = d.n_t;
+  return MPMHIP_OK;
+}
+
+int ensure_cap(mpmhip_ctx *c, int **p, int *cap, int need, int per) {
+  if (need <= *cap) return MPMHIP_OK;
+  int ncap = std::max(need + need / 2, 1024);
+  int *np_ = nullptr;
+  MPM_HIP_CHECK(c, hipMalloc((void **)&np_, (size_t)ncap * per * sizeof(int)));
+  c->fast->allocs.push_back(np_);  // old buffer stays alive until destroy (in-flight kernels may use it)
+  *p = np_;
+  *cap = ncap;
+  return MPMHIP_OK;
+}
+
+int scan_flags(mpmhip_ctx *c, const int *flag, int *index, int n, int *total) {
+  FastState *f = c->fast;
+  size_t need = 0;
+  MPM_HIP_CHECK(c, rocprim::exclusive_scan(nullptr, need, flag, index, 0, (size_t)n, rocprim::plus<int>(), c->stream));
+  if (need > f->scan_tmp_bytes) {
+    MPM_HIP_CHECK(c, hipMalloc(&f->scan_tmp, need));
+    f->allocs.push_back(f->scan_tmp);
+    f->scan_tmp_bytes = need;
+  }
+  MPM_HIP_CHECK(c, rocprim::exclusive_scan(f->scan_tmp, need, flag, index, 0, (size_t)n, rocprim::plus<int>(), c->stream));
+  MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin, index + (n - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 1, flag + (n - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  *total = f->h_pin[0] + f->h_pin[1];
+  return MPMHIP_OK;
+}
+
+int do_import(mpmhip_ctx *c) {
+  FastState *f = c->fast;
+  const Dims &d = f->d;
+  if (!f->have_order) {
+    if (d.n_p) hipLaunchKernelGGL(k_iota, nblk(d.n_p), TPB, 0, c->stream, f->perm[f->cur], d.n_p);
+    f->have_order = true;
+  }
+  if (d.n_p)
+    hipLaunchKernelGGL(k_import, nblk(d.n_p), TPB, 0, c->stream, c->st, c->md, f->buf[f->cur], f->perm[f->cur], d);
+  c->caller_dirty = false;
+  c->internal_dirty = false;
+  f->steps_since_rebin = 1 << 30;  // force a rebin before the next transfer
+  return MPMHIP_OK;
+}
+
+int rebin(mpmhip_ctx *c) {
+  FastState *f = c->fast;
+  const Dims &d = f->d;
+  hipStream_t s = c->stream;
+  int cur = f->cur, alt = 1 - cur;
+  if (d.n_p == 0) { f->n_P = f->n_A = f->n_chunks = 0; f->steps_since_rebin = 0; return MPMHIP_OK; }
+  hipLaunchKernelGGL(k_keys, nblk(d.n_p), TPB, 0, s, f->buf[cur], d, f->blk_bits, f->keys[0], f->iota);
+  size_t need = 0;
+  MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(nullptr, need, f->keys[0], f->keys[1], f->iota, f->order, (size_t)d.n_p, 0u,
+                                             (unsigned)f->key_bits, s));
+  if (need > f->sort_tmp_bytes) {
+    MPM_HIP_CHECK(c, hipMalloc(&f->sort_tmp, need));
+    f->allocs.push_back(f->sort_tmp);
+    f->sort_tmp_bytes = need;
+  }
+  MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(f->sort_tmp, need, f->keys[0], f->keys[1], f->iota, f->order, (size_t)d.n_p,
+                                             0u, (unsigned)f->key_bits, s));
+  hipLaunchKernelGGL(k_permute, nblk(d.n_p), TPB, 0, s, f->buf[cur], f->buf[alt], f->order, f->perm[cur], f->perm[alt],
+                     f->inv, d);
+  f->cur = cur = alt;
+  if (d.n_e) hipLaunchKernelGGL(k_face_slots, nblk(d.n_e), TPB, 0, s, f->buf[cur], f->inv, f->face_slot, d);
+  const unsigned *skeys = f->keys[1];
+  int nb = (int)f->nblocks;
+  MPM_HIP_CHECK(c, hipMemsetAsync(f->pb_flag, 0, f->nblocks * sizeof(int), s));
+  MPM_HIP_CHECK(c, hipMemsetAsync(f->ab_flag, 0, f->nblocks * sizeof(int), s));
+  hipLaunchKernelGGL(k_mark_blocks, nblk(d.n_p), TPB, 0, s, skeys, d.n_p, f->blk_bits, f->pb_flag);
+  int rc = scan_flags(c, f->pb_flag, f->pb_index, nb, &f->n_P);
+  if (rc) return rc;
+  if ((rc = ensure_cap(c, &f->plist, &f->cap_P, f->n_P, 1))) return rc;
+  if ((rc = ensure_cap(c, &f->ranges, &f->cap_R, f->n_P, 6))) return rc;
+  MPM_HIP_CHECK(c, hipMemsetAsync(f->ranges, 0, (size_t)f->n_P * 6 * sizeof(int), s));
+  hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, f->pb_flag, f->pb_index, nb, f->plist);
+  hipLaunchKernelGGL(k_ranges, nblk(d.n_p), TPB, 0, s, skeys, d, f->blk_bits, f->pb_index, f->n_P, f->ranges);
+  hipLaunchKernelGGL(k_dilate, nblk((size_t)f->n_P * 27), TPB, 0, s, f->plist, f->n_P, d.NB, f->ab_flag);
+  if ((rc = scan_flags(c, f->ab_flag, f->ab_index, nb, &f->n_A))) return rc;
+  if ((rc = ensure_cap(c, &f->alist, &f->cap_A, f->n_A, 1))) return rc;
+  hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, f->ab_flag, f->ab_index, nb, f->alist);
+  // chunk list on the host from the compact ranges
+  f->h_ranges.resize((size_t)f->n_P * 6);
+  MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_ranges.data(), f->ranges, (size_t)f->n_P * 6 * sizeof(int), hipMemcpyDeviceToHost, s));
+  MPM_HIP_CHECK(c, hipStreamSynchronize(s));
+  f->h_chunks.clear();
+  for (int p = 0; p < f->n_P; ++p) {
+    int mx = 0;
+    for (int cl = 0; cl < 3; ++cl)
+      mx = std::max(mx, f->h_ranges[(size_t)(cl * 2 + 1) * f->n_P + p] - f->h_ranges[(size_t)(cl * 2) * f->n_P + p]);
+    int nch = (mx + CHUNK - 1) / CHUNK;
+    for (int k = 0; k < nch; ++k) { f->h_chunks.push_back(p); f->h_chunks.push_back(k); }
+  }
+  f->n_chunks = (int)(f->h_chunks.size() / 2);
+  if ((rc = ensure_cap(c, &f->chunks, &f->cap_chunks, f->n_chunks, 2))) return rc;
+  if (f->n_chunks)
+    MPM_HIP_CHECK(c, hipMemcpyAsync(f->chunks, f->h_chunks.data(), f->h_chunks.size() * sizeof(int), hipMemcpyHostToDevice, s));
+  MPM_HIP_CHECK(c, hipStreamSynchronize(s));  // h_chunks is pageable: the copy must finish before it is reused
+  f->g.ab_flag = f->ab_flag;
+  f->steps_since_rebin = 0;
+  f->rebins += 1;
+  return MPMHIP_OK;
+}
+
+}  // namespace
+
+int fast_init(mpmhip_ctx *c) {
+  const mpmhip_config &cfg = c->cfg;
+  if (cfg.n_grid > 512) return fail(c, MPMHIP_ERR_INVALID, "fast mode supports n_grid <= 512");
+  FastState *f = new FastState();
+  c->fast = f;
+  Dims &d = f->d;
+  d.n_p = cfg.n_particles; d.n_e = cfg.n_elements; d.n_v = cfg.n_vertices; d.n_nv = c->n_nv; d.n_t = c->n_trad;
+  d.G = cfg.n_grid; d.NB = (cfg.n_grid + 3) / 4;
+  d.dx = c->dx; d.inv_dx = c->inv_dx; d.grid_lim = cfg.grid_lim;
+  f->nblocks = (size_t)d.NB * d.NB * d.NB;
+  f->blk_bits = 1;
+  while ((1ull << f->blk_bits) < f->nblocks) ++f->blk_bits;
+  f->key_bits = f->blk_bits + 6 + 1 + 2;
+  if (f->key_bits > 32) return fail(c, MPMHIP_ERR_INVALID, "grid too large for 32-bit sort keys");
+  f->rebin_interval = cfg.rebin_interval > 0 ? cfg.rebin_interval : 32;
+  int rc;
+  for (int i = 0; i < 2; ++i) {
+    if ((rc = alloc_bufs(c, f->buf[i]))) return rc;
+    if ((rc = dalloc(c, &f->perm[i], (size_t)d.n_p))) return rc;
+    if ((rc = dalloc(c, &f->keys[i], (size_t)d.n_p))) return rc;
+  }
+  if ((rc = dalloc(c, &f->inv, (size_t)d.n_p))) return rc;
+  if ((rc = dalloc(c, &f->face_slot, (size_t)3 * d.n_e))) return rc;
+  if ((rc = dalloc(c, &f->vforce, (size_t)3 * d.n_v))) return rc;
+  if ((rc = dalloc(c, &f->order, (size_t)d.n_p))) return rc;
+  if ((rc = dalloc(c, &f->iota, (size_t)d.n_p))) return rc;
+  if ((rc = dalloc(c, &f->g.mv, f->nblocks * GCH_MV * 64))) return rc;
+  if ((rc = dalloc(c, &f->g.vout, f->nblocks * GCH_VOUT * 64))) return rc;
+  if ((rc = dalloc(c, &f->g.counters, 8))) return rc;
+  if ((rc = dalloc(c, &f->pb_flag, f->nblocks))) return rc;
+  if ((rc = dalloc(c, &f->pb_index, f->nblocks))) return rc;
+  if ((rc = dalloc(c, &f->ab_flag, f->nblocks))) return rc;
+  if ((rc = dalloc(c, &f->ab_index, f->nblocks))) return rc;
+  f->g.ab_flag = f->ab_flag;
+  MPM_HIP_CHECK(c, hipHostMalloc((void **)&f->h_pin, 64 * sizeof(int), hipHostMallocDefault));
+  return MPMHIP_OK;
+}
+
+void fast_destroy(mpmhip_ctx *c) {
+  FastState *f = c->fast;
+  if (!f) return;
+  for (void *p : f->allocs) (void)hipFree(p);
+  if (f->h_pin) (void)hipHostFree(f->h_pin);
+  delete f;
+  c->fast = nullptr;
+}
+
+int fast_add_collider_storage(mpmhip_ctx *c, MeshCollider &mc) {
+  FastState *f = c->fast;
+  if (!c->colliders.empty()) return fail(c, MPMHIP_ERR_LIMIT, "fast mode supports one mesh collider (the reference drivers register one)");
+  int rc = dalloc(c, &f->g.col, f->nblocks * GCH_COL * 64);
+  mc.weight = f->g.col;
+  return rc;
+}
+
+int fast_add_mover_storage(mpmhip_ctx *c, Mover &mv) {
+  FastState *f = c->fast;
+  if (!c->movers.empty()) return fail(c, MPMHIP_ERR_LIMIT, "fast mode supports one particle mover (the reference drivers register one)");
+  int rc = dalloc(c, &f->g.mov, f->nblocks * GCH_MOV * 64);
+  mv.weight = f->g.mov;
+  return rc;
+}
+
+int fast_pull(mpmhip_ctx *c) {
+  FastState *f = c->fast;
+  const Dims &d = f->d;
+  if (d.n_p && f->have_order) {
+    int m = c->sc.material;
+    hipLaunchKernelGGL(k_export, nblk(d.n_p), TPB, 0, c->stream, c->st, c->md, f->buf[f->cur], f->vforce,
+                       f->perm[f->cur], d, (m == 1 || m == 5) ? 1 : 0);
+  }
+  c->internal_dirty = false;
+  return MPMHIP_OK;
+}
+
+int fast_step(mpmhip_ctx *c, const StepArgs &a) {
+  FastState *f = c->fast;
+  const Dims &d = f->d;
+  hipStream_t s = c->stream;
+  int rc;
+  if (c->caller_dirty && (rc = do_import(c))) return rc;
+  const float dt = a.dt;
+  // pre-p2g particle operations, mpm_solver.py:260-279 (impulses first, then velocity modifiers)
+  if (!c->pre.empty() && d.n_p) {
+    float t = (float)c->time;
+    for (int pass = 0; pass < 2; ++pass)
+      for (auto &op : c->pre) {
+        bool imp = op.type == PRE_IMPULSE || op.type == PRE_IMPULSE_MASK;
+        if (imp != (pass == 0) || !(t >= op.start_time && t < op.end_time)) continue;
+        hipLaunchKernelGGL(k_pre_sorted, nblk(d.n_p), TPB, 0, s, op, f->buf[f->cur], f->perm[f->cur], d, dt);
+      }
+  }
+  if (f->steps_since_rebin >= f->rebin_interval) {
+    ScopedPhase ph(c, "rebin");
+    if ((rc = rebin(c))) return rc;
+  }
+  Bufs &b = f->buf[f->cur];
+  {
+    ScopedPhase ph(c, "compute_stress_from_F_trial");
+    if (d.n_v) MPM_HIP_CHECK(c, hipMemsetAsync(f->vforce, 0, (size_t)3 * d.n_v * sizeof(float), s));
+    if (d.n_e) hipLaunchKernelGGL(k_stress_elem, nblk(d.n_e), TPB, 0, s, b, f->face_slot, f->vforce, d, c->sc.friction_coeff);
+    if (d.n_t) hipLaunchKernelGGL(k_stress_trad, nblk(d.n_t), TPB, 0, s, b, d, c->sc, dt);
+  }
+  {
+    ScopedPhase ph(c, "p2g");
+    if (f->n_chunks)
+      hipLaunchKernelGGL(k_p2g, xcd_grid(f->n_chunks), TPB, 0, s, b, f->vforce, f->plist, f->ranges, f->chunks,
+                         f->n_chunks, f->n_P, d, c->sc.rpic_damping, dt, f->g);
+  }
+  bool mov_on = a.joint_v_v && a.joint_f_v && !c->movers.empty();
+  {
+    ScopedPhase ph(c, "apply_Mesh_Collision_on_grid");
+    if (!c->colliders.empty() && c->num_mesh_f)
+      hipLaunchKernelGGL(k_face_splat, nblk(c->num_mesh_f), TPB, 0, s, c->mesh_points, c->mesh_vel, c->mesh_idx,
+                         c->num_mesh_f, d, f->g);
+  }
+  if (mov_on) {
+    ScopedPhase ph(c, "apply_Particle_Moving_on_grid");
+    if (a.joint_t_v && a.n_joint_t > 0)
+      hipLaunchKernelGGL(k_mover_splat, nblk(a.n_joint_t), TPB, 0, s, b, f->inv, a.joint_t_v, a.n_joint_t,
+                         d.n_nv - a.n_joint_t, d, f->g);
+    if (c->cfg.num_joint_v > 0)
+      hipLaunchKernelGGL(k_mover_splat, nblk(c->cfg.num_joint_v), TPB, 0, s, b, f->inv, a.joint_v_v,
+                         c->cfg.num_joint_v, d.n_nv, d, f->g);
+    if (c->cfg.num_joint_f > 0)
+      hipLaunchKernelGGL(k_mover_splat, nblk(c->cfg.num_joint_f), TPB, 0, s, b, f->inv, a.joint_f_v,
+                         c->cfg.num_joint_f, 0, d, f->g);
+  }
+  {
+    ScopedPhase ph(c, "grid_update");
+    GridParams gp{dt, c->sc.g[0], c->sc.g[1], c->sc.g[2], c->sc.grid_v_damping_scale, (float)c->time,
+                  c->colliders.empty() ? 0 : 1, c->movers.empty() ? 0 : 1, mov_on ? 1 : 0,
+                  c->colliders.empty() ? 0.0f : c->colliders[0].friction, 1};
+    f->stat_steps += 1;
+    BCList bcl{};
+    bcl.n = (int)c->bcs.size();
+    for (int k = 0; k < bcl.n; ++k) bcl.bc[k] = c->bcs[k];
+    if (f->n_A)
+      hipLaunchKernelGGL(k_grid, xcd_grid((f->n_A + 3) / 4), TPB, 0, s, f->alist, f->n_A, d, f->g, gp, bcl);
+    for (auto &bc : c->bcs) bc_host_modify(bc, (float)c->time, dt);
+  }
+  {
+    ScopedPhase ph(c, "g2p_v");
+    if (f->n_chunks)
+      hipLaunchKernelGGL(k_g2p, xcd_grid(f->n_chunks), TPB, 0, s, b, f->plist, f->ranges, f->chunks, f->n_chunks,
+                         f->n_P, d, dt, f->g);
+  }
+  {
+    ScopedPhase ph(c, "g2p_e");
+    if (d.n_e) hipLaunchKernelGGL(k_elem_finalize, nblk(d.n_e), TPB, 0, s, b, f->face_slot, d);
+  }
+  f->steps_since_rebin += 1;
+  c->internal_dirty = true;
+  MPM_HIP_CHECK(c, hipGetLastError());
+  return MPMHIP_OK;
+}
+
+int fast_export_grid(mpmhip_ctx *c, float *m, float *v_in, float *v_out) {
+  FastState *f = c->fast;
+  const Dims &d = f->d;
+  size_t n = G3(c);
+  if (m) MPM_HIP_CHECK(c, hipMemsetAsync(m, 0, n * sizeof(float), c->stream));
+  if (v_in) MPM_HIP_CHECK(c, hipMemsetAsync(v_in, 0, 3 * n * sizeof(float), c->stream));  // consumed by the grid stage
+  if (v_out) MPM_HIP_CHECK(c, hipMemsetAsync(v_out, 0, 3 * n * sizeof(float), c->stream));
+  if (f->n_A) hipLaunchKernelGGL(k_export_grid, (unsigned)((f->n_A + 3) / 4), TPB, 0, c->stream, f->alist, f->n_A, d, f->g, m, v_out);
+  MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return MPMHIP_OK;
+}
+
+int fast_stats(mpmhip_ctx *c, mpmhip_stats *out) {
+  FastState *f = c->fast;
+  out->rebins = f->rebins;
+  out->n_active_blocks = f->n_A;
+  int *dcnt = f->g.counters + 4;
+  MPM_HIP_CHECK(c, hipMemsetAsync(dcnt, 0, sizeof(int), c->stream));
+  if (f->n_A) hipLaunchKernelGGL(k_count_active, (unsigned)((f->n_A + 3) / 4), TPB, 0, c->stream, f->alist, f->n_A, f->g, dcnt);
+  MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 8, f->g.counters, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  out->n_fallback_particles = f->h_pin[8];
+  out->reserved = f->h_pin[9];  // dropped contributions (must stay 0)
+  out->n_active_nodes = f->h_pin[12];
+  if (f->stat_steps > 0) {  // per-substep averages since the previous call
+    out->n_collider_nodes = (int)(f->h_pin[10] / f->stat_steps);
+    out->n_mover_nodes = (int)(f->h_pin[11] / f->stat_steps);
+  }
+  MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + 2, 0, 2 * sizeof(int), c->stream));
+  f->stat_steps = 0;
+  return MPMHIP_OK;
+}
+
+}  // namespace mpm
