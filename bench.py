@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""Headline benchmark: MPM substeps/s on the synthetic 'sheet-500k' scene (497,762 particles, 256^3 grid;
+BASELINE.json metric) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one substep (MPMWARP.p2g2p: stress -> p2g -> grid -> g2p) over the whole scene, inputs resident in
+HBM before the timed region.  N > 1 shards particles by spatial slab (strong scaling: total work fixed) with an
+RCCL halo exchange of the shared grid blocks after p2g (mpmavatar_amd/dist.py).
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  "roofline":     dominant kernel, algorithmic bytes per launch / HIP-event launch time vs 8 TB/s
+  "kernels":      the same for every phase of the substep
+  "cpu_baseline": the CPU oracle (restatement of the reference algorithm; the reference's Warp path cannot run
+                  here) timed on this box's host cores on a bounded number of substeps of the same scene.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+
+def phase_bytes(sc, n_active, n_coll, n_mov):
+    """Algorithmic bytes per substep of each phase (SURVEY.md 8(d) per-unit figures)."""
+    ne, nv, nt = sc.n_elements, sc.n_vertices, sc.n_traditional
+    return {
+        "compute_stress_from_F_trial": 188 * ne + 116 * nt + 12 * nv,
+        "p2g": 100 * ne + 76 * nv + 104 * nt + 16 * n_active,
+        "grid_update": 28 * n_active + 68 * n_coll + 32 * n_mov,
+        "g2p_v": (132 + 36) * ne + 72 * nv + 144 * nt + 12 * n_active,  # gather + C/d3 write of elements
+        "g2p_e": (228 - 132 - 36) * ne,                                  # x,v,d1,d2 from the three vertices
+    }
+
+
+def cpu_baseline(sc, budget_s=20.0):
+    """Time the CPU oracle (OpenMP build, all host cores) on a bounded number of substeps of the same scene."""
+    from oracle.scene_adapter import oracle_from_scene, run_scene
+    cores = os.cpu_count() or 1
+    o = oracle_from_scene(sc, omp=True, n_threads=cores)
+    run_scene(o, sc, 1)  # warm caches / page in the dense grids
+    n, t0 = 0, time.perf_counter()
+    while True:
+        k = n
+        kw = {}
+        if sc.mesh_vertices is not None:
+            import numpy as np
+            kw = dict(mesh_x=(sc.mesh_vertices + np.float32(sc.dt * (k + 1)) * sc.mesh_v).astype("float32"), mesh_v=sc.mesh_v)
+        if sc.joint_verts_v is not None:
+            kw.update(joint_verts_v=sc.joint_verts_v, joint_faces_v=sc.joint_faces_v)
+        o.p2g2p(sc.dt, **kw)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return {"value": n / el, "unit": "substeps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} substeps of {sc.name} (dense-grid OpenMP CPU restatement of the reference algorithm)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scene", default="sheet-500k")
+    ap.add_argument("--mode", default="fast", choices=["fast", "baseline"])
+    ap.add_argument("--rebin-interval", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the per-phase HIP-event pass")
+    args = ap.parse_args()
+
+    import torch
+    from mpmavatar_amd import harness, scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+
+    sc = scenes.REGISTRY[args.scene]()
+    if world > 1:
+        import torch.distributed as dist
+        from mpmavatar_amd import dist as mdist
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+        sim = mdist.build_sharded(sc, dev, rank, world, rebin_interval=args.rebin_interval)
+        run = lambda n: mdist.run(sim, n)
+        barrier = lambda: dist.barrier()
+    else:
+        sim = harness.build_solver(sc, dev, mode=args.mode, rebin_interval=args.rebin_interval)
+        run = lambda n: harness.run(sim, n, fused=True)
+        barrier = lambda: None
+
+    run(args.warmup)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    out = {
+        "metric": "MPM substeps/sec (500k particles, 256^3 grid)", "value": args.steps / elapsed, "unit": "substeps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": sc.name, "n_particles": sc.n_particles, "n_elements": sc.n_elements,
+                   "n_vertices": sc.n_vertices, "n_traditional": sc.n_traditional, "n_grid": sc.n_grid,
+                   "dt": sc.dt, "mode": args.mode, "parallelism": f"slab{world}" if world > 1 else "single"},
+    }
+
+    if world == 1:
+        sv = sim.solver
+        st = sv.stats()
+        n_act, n_col, n_mov = st["n_active_nodes"], st["n_collider_nodes"], st["n_mover_nodes"]
+        b_alg = harness.algorithmic_bytes(sc, n_act, n_col, n_mov)
+        out["config"].update({"n_active_nodes": n_act, "n_collider_nodes": n_col, "n_mover_nodes": n_mov,
+                              "n_active_blocks": st["n_active_blocks"], "rebins": st["rebins"],
+                              "fallback_particles": st["n_fallback_particles"], "alg_bytes_per_substep": b_alg["substep"]})
+        out["substep_GBps"] = b_alg["substep"] / (ms_per_step * 1e-3) / 1e9
+        out["substep_frac_of_hbm_peak"] = out["substep_GBps"] / HBM_PEAK_GBS
+        if not args.no_kernels:
+            # per-phase launch durations: HIP events recorded on the solver's stream around each phase
+            sv.enable_profiling(True)
+            sv.time_profile.clear()
+            harness.run(sim, args.steps, fused=False)
+            sv.enable_profiling(False)
+            pb = phase_bytes(sc, n_act, n_col, n_mov)
+            kernels = []
+            for name, samples in sv.time_profile.items():
+                ms = sum(samples) / max(len(samples), 1)
+                if name == "rebin":
+                    ms = sum(samples) / args.steps  # amortised
+                k = {"name": name, "ms": ms}
+                if name in pb and ms > 0:
+                    k["alg_bytes"] = pb[name]
+                    k["GBps"] = pb[name] / (ms * 1e-3) / 1e9
+                    k["frac"] = k["GBps"] / HBM_PEAK_GBS
+                kernels.append(k)
+            out["kernels"] = kernels
+            dom = max((k for k in kernels if "alg_bytes" in k), key=lambda k: k["ms"])
+            out["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": dom["frac"], "traffic": None,
+                               "alg_bytes_per_launch": dom["alg_bytes"], "ms_per_launch": dom["ms"]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sc)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string.h>
+#include <cstdlib>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -302,115 +303,157 @@ struct GridPtrs {
   float *mov;       // [block][4][64]: weight, velocity xyz
   const int *ab_flag;
   int *counters;    // [0] particles outside their tile margin, [1] dropped contributions (inactive block)
+  int dbg;          // MPMHIP_DBG bitmask (perf experiments only): 1 skip p2g flush, 2 skip p2g LDS atomics
 };
 
-// slow path for a particle that drifted out of its tile margin: straight to the global grid
-__device__ __noinline__ void p2g_scatter_global(const Stencil &s, float mass, V3 v, const M3 &C, const M3 &S,
-                                                V3 vforce, bool is_vert, float dt, const Dims &d, GridPtrs g) {
+// The LDS tile is stored with padded strides (i*99 + j*9 + k): the 27 nodes of one particle's 3x3x3 stencil
+// then fall into 27 different banks (99 = 3 mod 32, 9, 1), and neighbouring lanes -- which after the cell sort
+// mostly sit in the SAME cell -- start the stencil loop at different nodes (lane % 27), so that one ds_add_f32
+// wave instruction carries (almost) no same-address and no same-bank lanes.  Measured on MI355X: same-address
+// LDS float atomics serialise at ~4 clk per lane (395 us for this kernel before).
+constexpr int TS_I = 99, TS_J = 9;
+constexpr int TILE_PAD = 768;  // floats per channel: 7*99 + 7*9 + 7 = 763 < 768
+__device__ __forceinline__ int tile_idx(int i, int j, int k) { return i * TS_I + j * TS_J + k; }
+
+struct P2GParticle {
+  Stencil s;
+  float mass;
+  V3 a0;      // v - dx * C * fx
+  M3 Cdx;     // dx * C'
+  M3 Sdx;     // inv_dx * S   (elements: stress, traditional: vol*stress; unused for vertices)
+  V3 vforce;  // vertices only
+};
+
+template <int CLS>
+__device__ __forceinline__ P2GParticle p2g_load(const Bufs &b, const float *vforce, int s, const Dims &d, float rpic) {
+  P2GParticle q;
+  q.s = make_stencil(ld3(b.all, A_X, s), d.inv_dx);
+  q.mass = b.all.at(A_MASS, s);
+  M3 C = ld9(b.all, A_C, s);
+  C = (1.0f - rpic) * C + (rpic / 2.0f) * (C - transpose(C));  // mpm_utils.py:530-532
+  if (rpic < -0.001f) C = m3_zero();
+  q.a0 = ld3(b.all, A_V, s) - d.dx * (C * q.s.fx);
+  q.Cdx = d.dx * C;
+  q.Sdx = m3_zero();
+  q.vforce = v3(0, 0, 0);
+  if (CLS == 0) q.Sdx = d.inv_dx * ld9(b.nv, N_STRESS, s);
+  if (CLS == 1) q.Sdx = (d.inv_dx * b.nv.at(N_VOL, s)) * ld9(b.nv, N_STRESS, s);
+  if (CLS == 2) {
+    int vl = s - d.n_nv;
+    q.vforce = v3(vforce[vl], vforce[d.n_v + vl], vforce[2 * d.n_v + vl]);
+  }
+  return q;
+}
+
+// contribution of particle q to stencil node (i,j,k): mass and momentum (+ dt * force)
+template <int CLS>
+__device__ __forceinline__ void p2g_node(const P2GParticle &q, int i, int j, int k, float dt, float &wm, V3 &add) {
+  const Stencil &s = q.s;
+  float wx = sel3(i, s.w0.x, s.w1.x, s.w2.x), wy = sel3(j, s.w0.y, s.w1.y, s.w2.y), wz = sel3(k, s.w0.z, s.w1.z, s.w2.z);
+  float weight = wx * wy * wz;
+  V3 vel = q.a0 + (float)i * col0(q.Cdx) + (float)j * col1(q.Cdx) + (float)k * col2(q.Cdx);
+  V3 force;
+  if (CLS == 2) {
+    force = weight * q.vforce;
+  } else {
+    float dwx = sel3(i, s.dw0.x, s.dw1.x, s.dw2.x), dwy = sel3(j, s.dw0.y, s.dw1.y, s.dw2.y), dwz = sel3(k, s.dw0.z, s.dw1.z, s.dw2.z);
+    force = -1.0f * (q.Sdx * v3(dwx * wy * wz, wx * dwy * wz, wx * wy * dwz));
+  }
+  wm = weight * q.mass;
+  add = wm * vel + dt * force;
+}
+
+template <int CLS>
+__device__ __forceinline__ void p2g_range(double *tile, int *esc, int *esc_n, const Bufs &b, const float *vforce, int s0,
+                                          int s1, int ox, int oy, int oz, const Dims &d, float rpic, float dt, int dbg) {
+  for (int s = s0 + threadIdx.x; s < s1; s += TPB) {
+    P2GParticle q = p2g_load<CLS>(b, vforce, s, d, rpic);
+    int lx = q.s.bx - ox, ly = q.s.by - oy, lz = q.s.bz - oz;
+    if ((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u) {
+      esc[atomicAdd(esc_n, 1)] = s;  // drifted out of the tile margin: handled after the tile pass
+      continue;
+    }
+    if (dbg & 2) continue;
+    int base = tile_idx(lx, ly, lz);
+    int n = threadIdx.x % 27;
+    int i = n / 9, j = (n / 3) % 3, k = n % 3;
+#pragma unroll 3
+    for (int t = 0; t < 27; ++t) {
+      float wm;
+      V3 add;
+      p2g_node<CLS>(q, i, j, k, dt, wm, add);
+      double *p = tile + base + tile_idx(i, j, k);
+      atomicAdd(p, (double)wm);
+      atomicAdd(p + TILE_PAD, (double)add.x);
+      atomicAdd(p + 2 * TILE_PAD, (double)add.y);
+      atomicAdd(p + 3 * TILE_PAD, (double)add.z);
+      if (++k == 3) { k = 0; if (++j == 3) { j = 0; if (++i == 3) i = 0; } }
+    }
+  }
+}
+
+// slow path for the (rare) particles that left their tile margin since the last re-sort: global atomics
+template <int CLS>
+__device__ __noinline__ void p2g_escaped(const Bufs &b, const float *vforce, int s, const Dims &d, float rpic, float dt,
+                                         GridPtrs g) {
+  P2GParticle q = p2g_load<CLS>(b, vforce, s, d, rpic);
   atomicAdd(g.counters + 0, 1);
+#pragma unroll 1
   for (int n = 0; n < 27; ++n) {
     int i = n / 9, j = (n / 3) % 3, k = n % 3;
-    float wx = sel3(i, s.w0.x, s.w1.x, s.w2.x), wy = sel3(j, s.w0.y, s.w1.y, s.w2.y), wz = sel3(k, s.w0.z, s.w1.z, s.w2.z);
-    float dwx = sel3(i, s.dw0.x, s.dw1.x, s.dw2.x), dwy = sel3(j, s.dw0.y, s.dw1.y, s.dw2.y), dwz = sel3(k, s.dw0.z, s.dw1.z, s.dw2.z);
-    float weight = wx * wy * wz;
-    V3 dweight = d.inv_dx * v3(dwx * wy * wz, wx * dwy * wz, wx * wy * dwz);
-    V3 dpos = d.dx * v3((float)i - s.fx.x, (float)j - s.fx.y, (float)k - s.fx.z);
-    V3 force = is_vert ? weight * vforce : -1.0f * (S * dweight);
-    V3 add = (weight * mass) * (v + C * dpos) + dt * force;
-    int x = s.bx + i, y = s.by + j, z = s.bz + k;
+    float wm;
+    V3 add;
+    p2g_node<CLS>(q, i, j, k, dt, wm, add);
+    int x = q.s.bx + i, y = q.s.by + j, z = q.s.bz + k;
     if (!in_grid(x, y, z, d.G)) continue;
     int blk = blk_of(x, y, z, d.NB);
     if (!g.ab_flag[blk]) { atomicAdd(g.counters + 1, 1); continue; }
     float *p = g.mv + ((size_t)blk * GCH_MV) * 64 + loc_of(x, y, z);
-    atomicAdd(p, weight * mass);
+    atomicAdd(p, wm);
     atomicAdd(p + 64, add.x); atomicAdd(p + 128, add.y); atomicAdd(p + 192, add.z);
-  }
-}
-
-__device__ __forceinline__ void p2g_particle(float *tile, int ox, int oy, int oz, V3 x, float mass, V3 v, M3 C,
-                                             const M3 &S, V3 vforce, bool is_vert, float rpic, float dt, const Dims &d,
-                                             GridPtrs g) {
-  C = (1.0f - rpic) * C + (rpic / 2.0f) * (C - transpose(C));
-  if (rpic < -0.001f) C = m3_zero();
-  Stencil s = make_stencil(x, d.inv_dx);
-  int lx = s.bx - ox, ly = s.by - oy, lz = s.bz - oz;
-  if ((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u) {
-    p2g_scatter_global(s, mass, v, C, S, vforce, is_vert, dt, d, g);
-    return;
-  }
-  int base = (lx * TILE + ly) * TILE + lz;
-  // v + C*dpos = a0 + dx*(i*Ccol0 + j*Ccol1 + k*Ccol2)
-  V3 a0 = v - d.dx * (C * s.fx);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    float wx = sel3(i, s.w0.x, s.w1.x, s.w2.x), dwx = sel3(i, s.dw0.x, s.dw1.x, s.dw2.x);
-    V3 ai = a0 + (d.dx * (float)i) * col0(C);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float wy = sel3(j, s.w0.y, s.w1.y, s.w2.y), dwy = sel3(j, s.dw0.y, s.dw1.y, s.dw2.y);
-      V3 aij = ai + (d.dx * (float)j) * col1(C);
-      float wxy = wx * wy;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        float wz = sel3(k, s.w0.z, s.w1.z, s.w2.z), dwz = sel3(k, s.dw0.z, s.dw1.z, s.dw2.z);
-        float weight = wxy * wz;
-        V3 vel = aij + (d.dx * (float)k) * col2(C);
-        V3 force;
-        if (is_vert) force = weight * vforce;
-        else force = -1.0f * (S * (d.inv_dx * v3(dwx * wy * wz, wx * dwy * wz, wxy * dwz)));
-        float wm = weight * mass;
-        V3 add = wm * vel + dt * force;
-        int t = base + (i * TILE + j) * TILE + k;
-        atomicAdd(tile + t, wm);
-        atomicAdd(tile + TILE3 + t, add.x);
-        atomicAdd(tile + 2 * TILE3 + t, add.y);
-        atomicAdd(tile + 3 * TILE3 + t, add.z);
-      }
-    }
   }
 }
 
 __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, const float *vforce, const int *plist, const int *ranges,
                                              const int *chunks, int n_chunks, int n_P, Dims d, float rpic, float dt,
                                              GridPtrs g) {
-  __shared__ float tile[4 * TILE3];
+  // fp64 accumulators: ds_add_f64 runs at the full LDS atomic rate on gfx950 while ds_add_f32 is ~10x slower
+  // (tools/ubench_atomics.hip: 1929 vs 204 G lane-ops/s), and the extra bits only help parity
+  __shared__ double tile[4 * TILE_PAD];
+  __shared__ int esc[3 * CHUNK];
+  __shared__ int esc_n;
   int w = xcd_slice(blockIdx.x, n_chunks);
   if (w < 0) return;
   int slot = chunks[2 * w], chunk = chunks[2 * w + 1];
   int blk = plist[slot];
   int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
   int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
-  for (int t = threadIdx.x; t < 4 * TILE3; t += TPB) tile[t] = 0.0f;
+  for (int t = threadIdx.x; t < 4 * TILE_PAD; t += TPB) tile[t] = 0.0;
+  if (threadIdx.x == 0) esc_n = 0;
   __syncthreads();
-  // elements: S = stress (already times vol)
-  {
-    int s0 = ranges[0 * n_P + slot] + chunk * CHUNK, s1 = min(ranges[1 * n_P + slot], s0 + CHUNK);
-    for (int s = s0 + threadIdx.x; s < s1; s += TPB)
-      p2g_particle(tile, ox, oy, oz, ld3(b.all, A_X, s), b.all.at(A_MASS, s), ld3(b.all, A_V, s), ld9(b.all, A_C, s),
-                   ld9(b.nv, N_STRESS, s), v3(0, 0, 0), false, rpic, dt, d, g);
-  }
-  // traditional: S = vol * stress
-  {
-    int s0 = ranges[2 * n_P + slot] + chunk * CHUNK, s1 = min(ranges[3 * n_P + slot], s0 + CHUNK);
-    for (int s = s0 + threadIdx.x; s < s1; s += TPB)
-      p2g_particle(tile, ox, oy, oz, ld3(b.all, A_X, s), b.all.at(A_MASS, s), ld3(b.all, A_V, s), ld9(b.all, A_C, s),
-                   b.nv.at(N_VOL, s) * ld9(b.nv, N_STRESS, s), v3(0, 0, 0), false, rpic, dt, d, g);
-  }
-  // vertices: force = weight * vertex_force
-  {
-    int s0 = ranges[4 * n_P + slot] + chunk * CHUNK, s1 = min(ranges[5 * n_P + slot], s0 + CHUNK);
-    for (int s = s0 + threadIdx.x; s < s1; s += TPB) {
-      int vl = s - d.n_nv;
-      p2g_particle(tile, ox, oy, oz, ld3(b.all, A_X, s), b.all.at(A_MASS, s), ld3(b.all, A_V, s), ld9(b.all, A_C, s),
-                   m3_zero(), v3(vforce[vl], vforce[d.n_v + vl], vforce[2 * d.n_v + vl]), true, rpic, dt, d, g);
+  int e0 = ranges[0 * n_P + slot] + chunk * CHUNK, e1 = min(ranges[1 * n_P + slot], e0 + CHUNK);
+  int t0 = ranges[2 * n_P + slot] + chunk * CHUNK, t1 = min(ranges[3 * n_P + slot], t0 + CHUNK);
+  int v0 = ranges[4 * n_P + slot] + chunk * CHUNK, v1 = min(ranges[5 * n_P + slot], v0 + CHUNK);
+  p2g_range<0>(tile, esc, &esc_n, b, vforce, e0, e1, ox, oy, oz, d, rpic, dt, g.dbg);
+  p2g_range<1>(tile, esc, &esc_n, b, vforce, t0, t1, ox, oy, oz, d, rpic, dt, g.dbg);
+  p2g_range<2>(tile, esc, &esc_n, b, vforce, v0, v1, ox, oy, oz, d, rpic, dt, g.dbg);
+  __syncthreads();
+  if (esc_n > 0) {
+    for (int q = threadIdx.x; q < esc_n; q += TPB) {
+      int s = esc[q];
+      if (s < d.n_e) p2g_escaped<0>(b, vforce, s, d, rpic, dt, g);
+      else if (s < d.n_nv) p2g_escaped<1>(b, vforce, s, d, rpic, dt, g);
+      else p2g_escaped<2>(b, vforce, s, d, rpic, dt, g);
     }
   }
-  __syncthreads();
   // flush: skip untouched nodes; every touched node lies in an active block by construction
+  if (g.dbg & 1) return;
   for (int t = threadIdx.x; t < TILE3; t += TPB) {
-    float m = tile[t], px = tile[TILE3 + t], py = tile[2 * TILE3 + t], pz = tile[3 * TILE3 + t];
+    int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
+    const double *q = tile + tile_idx(ti, tj, tk);
+    float m = (float)q[0], px = (float)q[TILE_PAD], py = (float)q[2 * TILE_PAD], pz = (float)q[3 * TILE_PAD];
     if (m == 0.0f && px == 0.0f && py == 0.0f && pz == 0.0f) continue;
-    int x = ox + (t >> 6), y = oy + ((t >> 3) & 7), z = oz + (t & 7);
+    int x = ox + ti, y = oy + tj, z = oz + tk;
     if (!in_grid(x, y, z, d.G)) continue;
     float *p = g.mv + ((size_t)blk_of(x, y, z, d.NB) * GCH_MV) * 64 + loc_of(x, y, z);
     atomicAdd(p, m);
@@ -909,6 +952,7 @@ int fast_init(mpmhip_ctx *c) {
   if ((rc = dalloc(c, &f->ab_flag, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->ab_index, f->nblocks))) return rc;
   f->g.ab_flag = f->ab_flag;
+  if (const char *e = getenv("MPMHIP_DBG")) f->g.dbg = atoi(e);
   MPM_HIP_CHECK(c, hipHostMalloc((void **)&f->h_pin, 64 * sizeof(int), hipHostMallocDefault));
   return MPMHIP_OK;
 }

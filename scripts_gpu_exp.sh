@@ -1,0 +1,12 @@
+#!/bin/bash
+# perf experiments: MPMHIP_DBG variants of the p2g kernel
+R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
+for d in 0 1 2 3; do
+  echo "== MPMHIP_DBG=$d"
+  MPMHIP_DBG=$d python bench.py --steps 100 --warmup 40 --no-cpu-baseline 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        o=json.loads(l); print('ms/step',round(o['ms_per_step'],4), {k['name']:round(k['ms']*1000,1) for k in o['kernels']})
+"
+done
