@@ -12,9 +12,14 @@ using namespace mpm;
 namespace {
 std::string g_create_error;
 
-__global__ void k_advect(const float *x0, const float *v, float f, float *out, size_t n) {
+// set_vec3_to_vec3(mesh.points, mesh_x) / (mesh.velocities, mesh_v), mpm_solver.py:285-315, as ONE device-side
+// kernel that also applies the caller's advection mesh_x + (k*dt)*mesh_v (train_material_params.py:623; mul then
+// add, not fused, like the torch expression)
+__global__ void k_mesh_store(float *pts, float *vel, const float *x, const float *v, float f, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = x0[i] + f * v[i];
+  if (i >= n) return;
+  if (x) pts[i] = (v && f != 0.0f) ? __fadd_rn(x[i], __fmul_rn(f, v[i])) : x[i];
+  if (v) vel[i] = v[i];
 }
 
 bool fast_mode(const mpmhip_ctx *c) { return c->cfg.mode == MPMHIP_MODE_FAST; }
@@ -87,7 +92,7 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   (void)hipSetDevice(c->cfg.device);
   (void)hipStreamSynchronize(c->stream);
   if (c->fast) fast_destroy(c);
-  for (float *p : {c->grid_m, c->grid_v_in, c->grid_v_out, c->mesh_points, c->mesh_vel, c->mesh_scratch})
+  for (float *p : {c->grid_m, c->grid_v_in, c->grid_v_out, c->mesh_points, c->mesh_vel})
     if (p) (void)hipFree(p);
   if (c->mesh_idx) (void)hipFree(c->mesh_idx);
   if (!fast_mode(c)) {
@@ -180,7 +185,6 @@ int mpmhip_set_body_mesh(mpmhip_ctx *c, int32_t n_verts, int32_t n_faces, const 
   size_t nb = (size_t)n_verts * 3 * sizeof(float);
   MPM_HIP_CHECK(c, hipMalloc(&c->mesh_points, nb));
   MPM_HIP_CHECK(c, hipMalloc(&c->mesh_vel, nb));
-  MPM_HIP_CHECK(c, hipMalloc(&c->mesh_scratch, nb));
   MPM_HIP_CHECK(c, hipMalloc(&c->mesh_idx, (size_t)n_faces * 3 * sizeof(int32_t)));
   MPM_HIP_CHECK(c, hipMemcpy(c->mesh_points, verts, nb, hipMemcpyHostToDevice));
   MPM_HIP_CHECK(c, hipMemset(c->mesh_vel, 0, nb));
@@ -335,21 +339,19 @@ static int step_checked(mpmhip_ctx *c, const StepArgs &a) {
   if (!c->st_bound || !c->md_bound) return fail(c, MPMHIP_ERR_STATE, "step: state/model not bound");
   if (a.n_joint_t < 0 || a.n_joint_t > c->n_trad) return fail(c, MPMHIP_ERR_INVALID, "step: n_joint_t out of range");
   if ((a.mesh_x || a.mesh_v) && !c->mesh_points) return fail(c, MPMHIP_ERR_STATE, "step: mesh_x/mesh_v given but no body mesh");
-  size_t nb = (size_t)c->num_mesh_v * 3 * sizeof(float);
-  {
-    // set_vec3_to_vec3(mesh.points, mesh_x), (mesh.velocities, mesh_v): mpm_solver.py:285-315.
-    // Device-to-device; the reference's .cpu().numpy() round trip is not reproduced.
-    if (a.mesh_x) {
-      ScopedPhase ph(c, "update_mesh_positions");
-      MPM_HIP_CHECK(c, hipMemcpyAsync(c->mesh_points, a.mesh_x, nb, hipMemcpyDeviceToDevice, c->stream));
-    }
-    if (a.mesh_v) {
-      ScopedPhase ph(c, "update_mesh_velocities");
-      MPM_HIP_CHECK(c, hipMemcpyAsync(c->mesh_vel, a.mesh_v, nb, hipMemcpyDeviceToDevice, c->stream));
-    }
-  }
+  // the backends read the body mesh through cur_pts + cur_f * cur_vel (device-to-device; the reference's
+  // .cpu().numpy() round trip per substep, mpm_solver.py:282-302, is not reproduced)
+  c->cur_pts = a.mesh_x ? a.mesh_x : c->mesh_points;
+  c->cur_vel = a.mesh_v ? a.mesh_v : c->mesh_vel;
+  c->cur_f = (a.mesh_x && a.mesh_v) ? a.mesh_f : 0.0f;
   int rc = fast_mode(c) ? fast_step(c, a) : baseline_step(c, a);
   if (rc) return rc;
+  if (a.mesh_store && (a.mesh_x || a.mesh_v)) {
+    ScopedPhase ph(c, "update_mesh_positions");
+    size_t nm = (size_t)c->num_mesh_v * 3;
+    hipLaunchKernelGGL(k_mesh_store, (unsigned)((nm + 255) / 256), 256, 0, c->stream, c->mesh_points, c->mesh_vel,
+                       a.mesh_x, a.mesh_v, c->cur_f, nm);
+  }
   c->time = c->time + (double)a.dt;  // mpm_solver.py:536
   c->substeps += 1;
   return MPMHIP_OK;
@@ -358,7 +360,7 @@ static int step_checked(mpmhip_ctx *c, const StepArgs &a) {
 int mpmhip_step(mpmhip_ctx *c, float dt, const float *mesh_x, const float *mesh_v, const float *joint_traditional_v,
                 int32_t n_joint_t, const float *joint_verts_v, const float *joint_faces_v) {
   CHECK_CTX(c);
-  StepArgs a{dt, mesh_x, mesh_v, joint_traditional_v, joint_traditional_v ? n_joint_t : 0, joint_verts_v, joint_faces_v};
+  StepArgs a{dt, mesh_x, mesh_v, 0.0f, true, joint_traditional_v, joint_traditional_v ? n_joint_t : 0, joint_verts_v, joint_faces_v};
   return step_checked(c, a);
 }
 
@@ -367,16 +369,10 @@ int mpmhip_steps(mpmhip_ctx *c, float dt, int32_t n, const float *mesh_x, const 
                  const float *joint_faces_v) {
   CHECK_CTX(c);
   if (n < 0) return fail(c, MPMHIP_ERR_INVALID, "steps: n < 0");
-  size_t nm = (size_t)c->num_mesh_v * 3;
   for (int k = 0; k < n; ++k) {
-    const float *mx = mesh_x;
-    if (mesh_x && mesh_v && k > 0) {
-      // mesh_x + substep_size*substep_local*mesh_v, train_material_params.py:623
-      hipLaunchKernelGGL(k_advect, (unsigned)((nm + 255) / 256), 256, 0, c->stream, mesh_x, mesh_v,
-                         (float)((double)dt * (double)k), c->mesh_scratch, nm);
-      mx = c->mesh_scratch;
-    }
-    StepArgs a{dt, mx, mesh_v, joint_traditional_v, joint_traditional_v ? n_joint_t : 0, joint_verts_v, joint_faces_v};
+    // mesh_x + substep_size*substep_local*mesh_v, train_material_params.py:623, evaluated inside the kernels
+    StepArgs a{dt, mesh_x, mesh_v, (float)((double)dt * (double)k), k == n - 1, joint_traditional_v,
+               joint_traditional_v ? n_joint_t : 0, joint_verts_v, joint_faces_v};
     int rc = step_checked(c, a);
     if (rc) return rc;
   }

@@ -142,12 +142,12 @@ __device__ __forceinline__ bool splat_ok(int G, const Stencil &s) {
 }
 
 // compute_mesh, mpm_solver.py:829-880
-__global__ void k_face_splat(const float *pts, const float *vel, const int32_t *idx, int n_f, GridDesc gd,
+__global__ void k_face_splat(const float *pts, const float *vel, float adv, const int32_t *idx, int n_f, GridDesc gd,
                              float *weight, float *v_in, float *normal) {
   int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n_f) return;
   int i0 = idx[3 * f], i1 = idx[3 * f + 1], i2 = idx[3 * f + 2];
-  V3 p0 = load_v3(pts + 3 * i0), p1 = load_v3(pts + 3 * i1), p2 = load_v3(pts + 3 * i2);
+  V3 p0 = mesh_point(pts, vel, adv, i0), p1 = mesh_point(pts, vel, adv, i1), p2 = mesh_point(pts, vel, adv, i2);
   V3 fp = v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
   V3 u0 = load_v3(vel + 3 * i0), u1 = load_v3(vel + 3 * i1), u2 = load_v3(vel + 3 * i2);
   V3 fv = v3((u0.x + u1.x + u2.x) / 3.0f, (u0.y + u1.y + u2.y) / 3.0f, (u0.z + u1.z + u2.z) / 3.0f);
@@ -356,7 +356,7 @@ int baseline_step(mpmhip_ctx *c, const StepArgs &a) {
       MPM_HIP_CHECK(c, hipMemsetAsync(mc.v_in, 0, 3 * n * sizeof(float), s));
       MPM_HIP_CHECK(c, hipMemsetAsync(mc.normal, 0, 3 * n * sizeof(float), s));
       if (c->num_mesh_f)
-        hipLaunchKernelGGL(k_face_splat, nblk(c->num_mesh_f), TPB, 0, s, c->mesh_points, c->mesh_vel, c->mesh_idx,
+        hipLaunchKernelGGL(k_face_splat, nblk(c->num_mesh_f), TPB, 0, s, c->cur_pts, c->cur_vel, c->cur_f, c->mesh_idx,
                            c->num_mesh_f, gd, mc.weight, mc.v_in, mc.normal);
       hipLaunchKernelGGL(k_collide, nblk(n), TPB, 0, s, c->grid_v_out, mc.weight, mc.v_in, mc.normal, n, mc.friction);
     }

@@ -44,7 +44,9 @@ struct Mover {
 
 struct StepArgs {
   float dt;
-  const float *mesh_x, *mesh_v;
+  const float *mesh_x, *mesh_v;  // body mesh for this substep: position = mesh_x + mesh_f * mesh_v
+  float mesh_f;                  // fused advection factor k*dt of mpmhip_steps (0 for a plain step)
+  bool mesh_store;               // write the advected mesh back into the context's wp.Mesh copy
   const float *joint_t_v;
   int n_joint_t;
   const float *joint_v_v, *joint_f_v;
@@ -80,7 +82,9 @@ struct mpmhip_ctx {
   int num_mesh_v = 0, num_mesh_f = 0;
   float *mesh_points = nullptr, *mesh_vel = nullptr;
   int32_t *mesh_idx = nullptr;
-  float *mesh_scratch = nullptr;  // advected mesh_x for mpmhip_steps
+  // body mesh as seen by the current substep (set by the API layer): points = cur_pts + cur_f * cur_vel
+  const float *cur_pts = nullptr, *cur_vel = nullptr;
+  float cur_f = 0.f;
 
   std::vector<mpm::MeshCollider> colliders;
   std::vector<mpm::Mover> movers;

@@ -120,7 +120,42 @@ __global__ void k_import(mpmhip_state_ptrs st, mpmhip_model_ptrs md, Bufs b, con
   }
 }
 
-__global__ void k_export(mpmhip_state_ptrs st, mpmhip_model_ptrs md, Bufs b, const float *vforce, const int *perm,
+// Vertex forces without atomics: every element stores its corner forces f2, f3 (f1 = -(f2+f3), mpm_utils.py:
+// 168-170) and every vertex sums over its incident (element, corner) pairs through an ELL adjacency table that is
+// rebuilt in sorted index space at each re-sort.  Replaces the 9 scattered fp32 atomics per element of
+// kirchoff_stress_Anisotropy (mpm_utils.py:173-175): scattered global atomics run at ~21 G/s on MI355X.
+struct VAdj {
+  const int *adj;    // [K][n_v]: (element_slot << 2) | corner, -1 = empty
+  const float *ef;   // [6][n_e]: f2.xyz, f3.xyz per element (sorted slots)
+  int K, n_v, n_e;
+};
+__device__ __forceinline__ V3 vertex_force(const VAdj &a, int vl) {
+  V3 f = v3(0, 0, 0);
+  // batches of 4 incident elements with all loads issued up front (no data-dependent early exit: a serial
+  // adj -> ef -> adj -> ef chain costs two memory latencies per incident element)
+  for (int k0 = 0; k0 < a.K; k0 += 4) {
+    int ent[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ent[u] = (k0 + u < a.K) ? a.adj[(size_t)(k0 + u) * a.n_v + vl] : -1;
+    V3 f2[4], f3[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int e = ent[u] >> 2, c = ent[u] & 3;
+      f2[u] = v3(0, 0, 0);
+      f3[u] = v3(0, 0, 0);
+      if (ent[u] >= 0 && c != 2) f2[u] = v3(a.ef[e], a.ef[a.n_e + e], a.ef[2 * a.n_e + e]);
+      if (ent[u] >= 0 && c != 1) f3[u] = v3(a.ef[3 * a.n_e + e], a.ef[4 * a.n_e + e], a.ef[5 * a.n_e + e]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int c = ent[u] & 3;
+      if (ent[u] >= 0) f = f + (c == 0 ? -1.0f * (f2[u] + f3[u]) : (c == 1 ? f2[u] : f3[u]));
+    }
+  }
+  return f;
+}
+
+__global__ void k_export(mpmhip_state_ptrs st, mpmhip_model_ptrs md, Bufs b, VAdj va, const int *perm,
                          Dims d, int export_model) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= d.n_p) return;
@@ -144,7 +179,7 @@ __global__ void k_export(mpmhip_state_ptrs st, mpmhip_model_ptrs md, Bufs b, con
     }
   } else {
     int v = s - d.n_nv;
-    for (int c = 0; c < 3; ++c) st.vertex_force[3 * (size_t)(o - d.n_nv) + c] = vforce[(size_t)c * d.n_v + v];
+    store_v3(st.vertex_force + 3 * (size_t)(o - d.n_nv), vertex_force(va, v));
   }
 }
 
@@ -238,10 +273,13 @@ __global__ void k_dilate(const int *plist, int n_P, int NB, int *ab_flag) {
 // ------------------------------------------------------------------------------------------------
 // stress (compute_stress_from_F_trial, mpm_utils.py:1017-1105) on the sorted SoA state
 // ------------------------------------------------------------------------------------------------
-__global__ void k_stress_elem(Bufs b, const int *face_slot, float *vforce, Dims d, float friction_coeff) {
+__global__ void k_stress_elem(Bufs b, float *ef, Dims d, float friction_coeff) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.n_e) return;
-  if (b.sel[e] != 0) return;
+  if (b.sel[e] != 0) {
+    for (int c = 0; c < 6; ++c) ef[c * d.n_e + e] = 0.0f;
+    return;
+  }
   M3 dm = ld9(b.el, E_D, e);
   QR3 q = qr_cloth(dm);
   float gamma = b.el.at(E_GAMMA, e), kappa = b.el.at(E_KAPPA, e);
@@ -253,11 +291,9 @@ __global__ void k_stress_elem(Bufs b, const int *face_slot, float *vforce, Dims 
   kirchhoff_anisotropy(q, r02, r12, r22, d3, ld3(b.el, E_RINV, e), b.nv.at(N_VOL, e), b.nv.at(N_MU, e),
                        b.nv.at(N_LAM, e), gamma, kappa, stress, f1, f2, f3);
   st9(b.nv, N_STRESS, e, stress);
-  int v1 = face_slot[e], v2 = face_slot[d.n_e + e], v3i = face_slot[2 * d.n_e + e];
-  int nv = d.n_v;
-  atomicAdd(vforce + v1, f1.x); atomicAdd(vforce + nv + v1, f1.y); atomicAdd(vforce + 2 * nv + v1, f1.z);
-  atomicAdd(vforce + v2, f2.x); atomicAdd(vforce + nv + v2, f2.y); atomicAdd(vforce + 2 * nv + v2, f2.z);
-  atomicAdd(vforce + v3i, f3.x); atomicAdd(vforce + nv + v3i, f3.y); atomicAdd(vforce + 2 * nv + v3i, f3.z);
+  (void)f1;
+  ef[e] = f2.x; ef[d.n_e + e] = f2.y; ef[2 * d.n_e + e] = f2.z;
+  ef[3 * d.n_e + e] = f3.x; ef[4 * d.n_e + e] = f3.y; ef[5 * d.n_e + e] = f3.z;
 }
 
 __global__ void k_stress_trad(Bufs b, Dims d, mpmhip_model_scalars sc, float dt) {
@@ -306,26 +342,51 @@ struct GridPtrs {
   int dbg;          // MPMHIP_DBG bitmask (perf experiments only): 1 skip p2g flush, 2 skip p2g LDS atomics
 };
 
-// The LDS tile is stored with padded strides (i*99 + j*9 + k): the 27 nodes of one particle's 3x3x3 stencil
-// then fall into 27 different banks (99 = 3 mod 32, 9, 1), and neighbouring lanes -- which after the cell sort
-// mostly sit in the SAME cell -- start the stencil loop at different nodes (lane % 27), so that one ds_add_f32
-// wave instruction carries (almost) no same-address and no same-bank lanes.  Measured on MI355X: same-address
-// LDS float atomics serialise at ~4 clk per lane (395 us for this kernel before).
+// The LDS tile is stored with padded strides (i*99 + j*9 + k) so that the 27 nodes of a 3x3x3 stencil fall into
+// different banks (99 = 3 mod 32, 9, 1).
 constexpr int TS_I = 99, TS_J = 9;
-constexpr int TILE_PAD = 768;  // floats per channel: 7*99 + 7*9 + 7 = 763 < 768
+constexpr int TILE_PAD = 768;  // entries per channel: 7*99 + 7*9 + 7 = 763 < 768
 __device__ __forceinline__ int tile_idx(int i, int j, int k) { return i * TS_I + j * TS_J + k; }
+
+// One chunk = up to 256 particles of ONE particle block, all three classes packed back to back (elements, then
+// traditional, then vertices) so that lanes stay filled; lane t of chunk k takes combined index k*256 + t.
+struct ChunkMap {
+  int e0, ne, t0, nt, v0, nv;
+  __device__ __forceinline__ bool map(int ci, int &cls, int &s) const {
+    if (ci < ne) { cls = 0; s = e0 + ci; return true; }
+    ci -= ne;
+    if (ci < nt) { cls = 1; s = t0 + ci; return true; }
+    ci -= nt;
+    if (ci < nv) { cls = 2; s = v0 + ci; return true; }
+    return false;
+  }
+};
+__device__ __forceinline__ ChunkMap chunk_map(const int *ranges, int n_P, int slot) {
+  ChunkMap m;
+  m.e0 = ranges[0 * n_P + slot]; m.ne = ranges[1 * n_P + slot] - m.e0;
+  m.t0 = ranges[2 * n_P + slot]; m.nt = ranges[3 * n_P + slot] - m.t0;
+  m.v0 = ranges[4 * n_P + slot]; m.nv = ranges[5 * n_P + slot] - m.v0;
+  return m;
+}
 
 struct P2GParticle {
   Stencil s;
   float mass;
-  V3 a0;      // v - dx * C * fx
-  M3 Cdx;     // dx * C'
-  M3 Sdx;     // inv_dx * S   (elements: stress, traditional: vol*stress; unused for vertices)
-  V3 vforce;  // vertices only
+  V3 a0;    // v - dx * C' * fx
+  M3 Cdx;   // dx * C'
+  M3 Sdt;   // -dt * inv_dx * S   (elements: stress, traditional: vol*stress, vertices: 0)
+  V3 vfdt;  // dt * vertex_force  (vertices only)
 };
 
-template <int CLS>
-__device__ __forceinline__ P2GParticle p2g_load(const Bufs &b, const float *vforce, int s, const Dims &d, float rpic) {
+__device__ __forceinline__ P2GParticle p2g_zero(int ox, int oy, int oz, const Dims &d) {
+  P2GParticle q;
+  q.s = make_stencil(v3((float)(ox + 2) * d.dx, (float)(oy + 2) * d.dx, (float)(oz + 2) * d.dx), d.inv_dx);
+  q.mass = 0.0f; q.a0 = v3(0, 0, 0); q.Cdx = m3_zero(); q.Sdt = m3_zero(); q.vfdt = v3(0, 0, 0);
+  return q;
+}
+
+__device__ __forceinline__ P2GParticle p2g_load(const Bufs &b, const VAdj &va, int cls, int s, const Dims &d, float rpic,
+                                                float dt) {
   P2GParticle q;
   q.s = make_stencil(ld3(b.all, A_X, s), d.inv_dx);
   q.mass = b.all.at(A_MASS, s);
@@ -334,76 +395,75 @@ __device__ __forceinline__ P2GParticle p2g_load(const Bufs &b, const float *vfor
   if (rpic < -0.001f) C = m3_zero();
   q.a0 = ld3(b.all, A_V, s) - d.dx * (C * q.s.fx);
   q.Cdx = d.dx * C;
-  q.Sdx = m3_zero();
-  q.vforce = v3(0, 0, 0);
-  if (CLS == 0) q.Sdx = d.inv_dx * ld9(b.nv, N_STRESS, s);
-  if (CLS == 1) q.Sdx = (d.inv_dx * b.nv.at(N_VOL, s)) * ld9(b.nv, N_STRESS, s);
-  if (CLS == 2) {
-    int vl = s - d.n_nv;
-    q.vforce = v3(vforce[vl], vforce[d.n_v + vl], vforce[2 * d.n_v + vl]);
-  }
+  q.Sdt = m3_zero();
+  q.vfdt = v3(0, 0, 0);
+  if (cls == 0) q.Sdt = (-dt * d.inv_dx) * ld9(b.nv, N_STRESS, s);
+  else if (cls == 1) q.Sdt = (-dt * d.inv_dx * b.nv.at(N_VOL, s)) * ld9(b.nv, N_STRESS, s);
+  else q.vfdt = dt * vertex_force(va, s - d.n_nv);
   return q;
 }
 
-// contribution of particle q to stencil node (i,j,k): mass and momentum (+ dt * force)
-template <int CLS>
-__device__ __forceinline__ void p2g_node(const P2GParticle &q, int i, int j, int k, float dt, float &wm, V3 &add) {
-  const Stencil &s = q.s;
-  float wx = sel3(i, s.w0.x, s.w1.x, s.w2.x), wy = sel3(j, s.w0.y, s.w1.y, s.w2.y), wz = sel3(k, s.w0.z, s.w1.z, s.w2.z);
-  float weight = wx * wy * wz;
-  V3 vel = q.a0 + (float)i * col0(q.Cdx) + (float)j * col1(q.Cdx) + (float)k * col2(q.Cdx);
-  V3 force;
-  if (CLS == 2) {
-    force = weight * q.vforce;
-  } else {
-    float dwx = sel3(i, s.dw0.x, s.dw1.x, s.dw2.x), dwy = sel3(j, s.dw0.y, s.dw1.y, s.dw2.y), dwz = sel3(k, s.dw0.z, s.dw1.z, s.dw2.z);
-    force = -1.0f * (q.Sdx * v3(dwx * wy * wz, wx * dwy * wz, wx * wy * dwz));
+// ---- wave-level pre-reduction -------------------------------------------------------------------------
+// After the cell sort neighbouring lanes mostly hold particles of the SAME cell, i.e. they add into the same
+// 27 tile nodes.  Contributions are therefore summed across lanes first -- a segmented inclusive scan inside
+// each 16-lane DPP row (row_shr 1,2,4,8; a segment = run of lanes with equal cell key) -- and only the last
+// lane of every segment issues the LDS atomic.  Measured on MI355X the cost of a ds_add_f64 wave instruction
+// is proportional to its active lanes (tools/ubench_lds_lanes.hip), and ds_add_f32 is ~10x slower than
+// ds_add_f64 (tools/ubench_atomics.hip), hence fp64 accumulators in LDS.
+__device__ __forceinline__ int dpp_shr_i(int v, int old, int n) {  // lane l <- lane l-n of the same row, else old
+  switch (n) {
+    case 1: return __builtin_amdgcn_update_dpp(old, v, 0x111, 0xf, 0xf, false);
+    case 2: return __builtin_amdgcn_update_dpp(old, v, 0x112, 0xf, 0xf, false);
+    case 4: return __builtin_amdgcn_update_dpp(old, v, 0x114, 0xf, 0xf, false);
+    default: return __builtin_amdgcn_update_dpp(old, v, 0x118, 0xf, 0xf, false);
   }
-  wm = weight * q.mass;
-  add = wm * vel + dt * force;
+}
+__device__ __forceinline__ float dpp_shr_f(float v, int n) { return __int_as_float(dpp_shr_i(__float_as_int(v), 0, n)); }
+
+struct SegMask {
+  float m1, m2, m4, m8;  // 1.0 where lane-d belongs to the same segment
+  bool tail;             // last lane of its segment
+};
+__device__ __forceinline__ SegMask seg_masks(int key) {
+  SegMask sm;
+  sm.m1 = dpp_shr_i(key, ~key, 1) == key ? 1.0f : 0.0f;
+  sm.m2 = dpp_shr_i(key, ~key, 2) == key ? 1.0f : 0.0f;
+  sm.m4 = dpp_shr_i(key, ~key, 4) == key ? 1.0f : 0.0f;
+  sm.m8 = dpp_shr_i(key, ~key, 8) == key ? 1.0f : 0.0f;
+  int next = __builtin_amdgcn_update_dpp(~key, key, 0x101, 0xf, 0xf, false);  // row_shl:1 -> lane l+1
+  sm.tail = next != key;
+  return sm;
+}
+__device__ __forceinline__ float seg_scan(float v, const SegMask &sm) {
+  v = fmaf(dpp_shr_f(v, 1), sm.m1, v);
+  v = fmaf(dpp_shr_f(v, 2), sm.m2, v);
+  v = fmaf(dpp_shr_f(v, 4), sm.m4, v);
+  v = fmaf(dpp_shr_f(v, 8), sm.m8, v);
+  return v;
 }
 
-template <int CLS>
-__device__ __forceinline__ void p2g_range(double *tile, int *esc, int *esc_n, const Bufs &b, const float *vforce, int s0,
-                                          int s1, int ox, int oy, int oz, const Dims &d, float rpic, float dt, int dbg) {
-  for (int s = s0 + threadIdx.x; s < s1; s += TPB) {
-    P2GParticle q = p2g_load<CLS>(b, vforce, s, d, rpic);
-    int lx = q.s.bx - ox, ly = q.s.by - oy, lz = q.s.bz - oz;
-    if ((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u) {
-      esc[atomicAdd(esc_n, 1)] = s;  // drifted out of the tile margin: handled after the tile pass
-      continue;
-    }
-    if (dbg & 2) continue;
-    int base = tile_idx(lx, ly, lz);
-    int n = threadIdx.x % 27;
-    int i = n / 9, j = (n / 3) % 3, k = n % 3;
-#pragma unroll 3
-    for (int t = 0; t < 27; ++t) {
-      float wm;
-      V3 add;
-      p2g_node<CLS>(q, i, j, k, dt, wm, add);
-      double *p = tile + base + tile_idx(i, j, k);
-      atomicAdd(p, (double)wm);
-      atomicAdd(p + TILE_PAD, (double)add.x);
-      atomicAdd(p + 2 * TILE_PAD, (double)add.y);
-      atomicAdd(p + 3 * TILE_PAD, (double)add.z);
-      if (++k == 3) { k = 0; if (++j == 3) { j = 0; if (++i == 3) i = 0; } }
-    }
-  }
+// contribution of q to stencil node (i,j,k) in the reference's form (mpm_utils.py:519-556); slow path only
+__device__ __forceinline__ void p2g_node_ref(const P2GParticle &q, int i, int j, int k, float &wm, V3 &add) {
+  const Stencil &s = q.s;
+  float wx = sel3(i, s.w0.x, s.w1.x, s.w2.x), wy = sel3(j, s.w0.y, s.w1.y, s.w2.y), wz = sel3(k, s.w0.z, s.w1.z, s.w2.z);
+  float dwx = sel3(i, s.dw0.x, s.dw1.x, s.dw2.x), dwy = sel3(j, s.dw0.y, s.dw1.y, s.dw2.y), dwz = sel3(k, s.dw0.z, s.dw1.z, s.dw2.z);
+  float weight = wx * wy * wz;
+  V3 vel = q.a0 + (float)i * col0(q.Cdx) + (float)j * col1(q.Cdx) + (float)k * col2(q.Cdx);
+  wm = weight * q.mass;
+  add = wm * vel + q.Sdt * v3(dwx * wy * wz, wx * dwy * wz, wx * wy * dwz) + weight * q.vfdt;
 }
 
 // slow path for the (rare) particles that left their tile margin since the last re-sort: global atomics
-template <int CLS>
-__device__ __noinline__ void p2g_escaped(const Bufs &b, const float *vforce, int s, const Dims &d, float rpic, float dt,
-                                         GridPtrs g) {
-  P2GParticle q = p2g_load<CLS>(b, vforce, s, d, rpic);
+__device__ __forceinline__ void p2g_escaped(const Bufs &b, const VAdj &va, int cls, int s, const Dims &d, float rpic,
+                                         float dt, GridPtrs g) {
+  P2GParticle q = p2g_load(b, va, cls, s, d, rpic, dt);
   atomicAdd(g.counters + 0, 1);
 #pragma unroll 1
   for (int n = 0; n < 27; ++n) {
     int i = n / 9, j = (n / 3) % 3, k = n % 3;
     float wm;
     V3 add;
-    p2g_node<CLS>(q, i, j, k, dt, wm, add);
+    p2g_node_ref(q, i, j, k, wm, add);
     int x = q.s.bx + i, y = q.s.by + j, z = q.s.bz + k;
     if (!in_grid(x, y, z, d.G)) continue;
     int blk = blk_of(x, y, z, d.NB);
@@ -414,13 +474,11 @@ __device__ __noinline__ void p2g_escaped(const Bufs &b, const float *vforce, int
   }
 }
 
-__global__ __launch_bounds__(TPB) void k_p2g(Bufs b, const float *vforce, const int *plist, const int *ranges,
+__global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const int *plist, const int *ranges,
                                              const int *chunks, int n_chunks, int n_P, Dims d, float rpic, float dt,
                                              GridPtrs g) {
-  // fp64 accumulators: ds_add_f64 runs at the full LDS atomic rate on gfx950 while ds_add_f32 is ~10x slower
-  // (tools/ubench_atomics.hip: 1929 vs 204 G lane-ops/s), and the extra bits only help parity
   __shared__ double tile[4 * TILE_PAD];
-  __shared__ int esc[3 * CHUNK];
+  __shared__ int esc[CHUNK];
   __shared__ int esc_n;
   int w = xcd_slice(blockIdx.x, n_chunks);
   if (w < 0) return;
@@ -428,30 +486,77 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, const float *vforce, const 
   int blk = plist[slot];
   int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
   int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
+  ChunkMap cm = chunk_map(ranges, n_P, slot);
+  int cls = 0, s = 0;
+  bool valid = cm.map(chunk * CHUNK + (int)threadIdx.x, cls, s);
+  // issue the particle loads before the tile is cleared so that their latency overlaps
+  P2GParticle q = p2g_zero(ox, oy, oz, d);
+  if (valid) q = p2g_load(b, va, cls, s, d, rpic, dt);
   for (int t = threadIdx.x; t < 4 * TILE_PAD; t += TPB) tile[t] = 0.0;
   if (threadIdx.x == 0) esc_n = 0;
   __syncthreads();
-  int e0 = ranges[0 * n_P + slot] + chunk * CHUNK, e1 = min(ranges[1 * n_P + slot], e0 + CHUNK);
-  int t0 = ranges[2 * n_P + slot] + chunk * CHUNK, t1 = min(ranges[3 * n_P + slot], t0 + CHUNK);
-  int v0 = ranges[4 * n_P + slot] + chunk * CHUNK, v1 = min(ranges[5 * n_P + slot], v0 + CHUNK);
-  p2g_range<0>(tile, esc, &esc_n, b, vforce, e0, e1, ox, oy, oz, d, rpic, dt, g.dbg);
-  p2g_range<1>(tile, esc, &esc_n, b, vforce, t0, t1, ox, oy, oz, d, rpic, dt, g.dbg);
-  p2g_range<2>(tile, esc, &esc_n, b, vforce, v0, v1, ox, oy, oz, d, rpic, dt, g.dbg);
+  int key = -2 - (int)(threadIdx.x & 63), base = 0;
+  if (valid) {
+    int lx = q.s.bx - ox, ly = q.s.by - oy, lz = q.s.bz - oz;
+    if ((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u) {
+      esc[atomicAdd(&esc_n, 1)] = (int)threadIdx.x;  // drifted out of the tile margin: handled after the tile pass
+      valid = false;
+      q = p2g_zero(ox, oy, oz, d);
+    } else {
+      key = (lx * TILE + ly) * TILE + lz;
+      base = tile_idx(lx, ly, lz);
+    }
+  }
+  if (!(g.dbg & 2) && __any(valid)) {  // wave-uniform: DPP needs converged lanes
+    SegMask sm = seg_masks(key);
+    bool do_add = sm.tail && valid;
+    const Stencil &st = q.s;
+    // factored stencil: add_ijk = wm (B_ij + k Cz) + wz_k P_ij + dwz_k Q_ij, wm = wxy_ij (wz_k m)
+    float wzm0 = st.w0.z * q.mass, wzm1 = st.w1.z * q.mass, wzm2 = st.w2.z * q.mass;
+    V3 Cx = col0(q.Cdx), Cy = col1(q.Cdx), Cz = col2(q.Cdx);
+    V3 S0 = col0(q.Sdt), S1 = col1(q.Sdt), S2 = col2(q.Sdt);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float wx = sel3(i, st.w0.x, st.w1.x, st.w2.x), dwx = sel3(i, st.dw0.x, st.dw1.x, st.dw2.x);
+      V3 Bi = q.a0 + (float)i * Cx;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float wy = sel3(j, st.w0.y, st.w1.y, st.w2.y), dwy = sel3(j, st.dw0.y, st.dw1.y, st.dw2.y);
+        float wxy = wx * wy;
+        V3 Bij = Bi + (float)j * Cy;
+        V3 P = (dwx * wy) * S0 + (wx * dwy) * S1 + wxy * q.vfdt;
+        V3 Q = wxy * S2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float wzk = sel3(k, st.w0.z, st.w1.z, st.w2.z), dwzk = sel3(k, st.dw0.z, st.dw1.z, st.dw2.z);
+          float wm = wxy * sel3(k, wzm0, wzm1, wzm2);
+          V3 vel = Bij + (float)k * Cz;
+          V3 add = wm * vel + wzk * P + dwzk * Q;
+          float r0 = seg_scan(wm, sm), r1 = seg_scan(add.x, sm), r2 = seg_scan(add.y, sm), r3 = seg_scan(add.z, sm);
+          if (do_add) {
+            double *p = tile + base + tile_idx(i, j, k);
+            atomicAdd(p, (double)r0);
+            atomicAdd(p + TILE_PAD, (double)r1);
+            atomicAdd(p + 2 * TILE_PAD, (double)r2);
+            atomicAdd(p + 3 * TILE_PAD, (double)r3);
+          }
+        }
+      }
+    }
+  }
   __syncthreads();
   if (esc_n > 0) {
-    for (int q = threadIdx.x; q < esc_n; q += TPB) {
-      int s = esc[q];
-      if (s < d.n_e) p2g_escaped<0>(b, vforce, s, d, rpic, dt, g);
-      else if (s < d.n_nv) p2g_escaped<1>(b, vforce, s, d, rpic, dt, g);
-      else p2g_escaped<2>(b, vforce, s, d, rpic, dt, g);
+    for (int e = threadIdx.x; e < esc_n; e += TPB) {
+      int ec = 0, es = 0;
+      if (cm.map(chunk * CHUNK + esc[e], ec, es)) p2g_escaped(b, va, ec, es, d, rpic, dt, g);
     }
   }
   // flush: skip untouched nodes; every touched node lies in an active block by construction
   if (g.dbg & 1) return;
   for (int t = threadIdx.x; t < TILE3; t += TPB) {
     int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
-    const double *q = tile + tile_idx(ti, tj, tk);
-    float m = (float)q[0], px = (float)q[TILE_PAD], py = (float)q[2 * TILE_PAD], pz = (float)q[3 * TILE_PAD];
+    const double *qd = tile + tile_idx(ti, tj, tk);
+    float m = (float)qd[0], px = (float)qd[TILE_PAD], py = (float)qd[2 * TILE_PAD], pz = (float)qd[3 * TILE_PAD];
     if (m == 0.0f && px == 0.0f && py == 0.0f && pz == 0.0f) continue;
     int x = ox + ti, y = oy + tj, z = oz + tk;
     if (!in_grid(x, y, z, d.G)) continue;
@@ -468,11 +573,11 @@ __device__ __forceinline__ bool splat_ok(int G, const Stencil &s) {
   return s.bx >= 0 && s.bx < G - 3 && s.by >= 0 && s.by < G - 3 && s.bz >= 0 && s.bz < G - 3;
 }
 
-__global__ void k_face_splat(const float *pts, const float *vel, const int32_t *idx, int n_f, Dims d, GridPtrs g) {
+__global__ void k_face_splat(const float *pts, const float *vel, float adv, const int32_t *idx, int n_f, Dims d, GridPtrs g) {
   int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n_f) return;
   int i0 = idx[3 * f], i1 = idx[3 * f + 1], i2 = idx[3 * f + 2];
-  V3 p0 = load_v3(pts + 3 * i0), p1 = load_v3(pts + 3 * i1), p2 = load_v3(pts + 3 * i2);
+  V3 p0 = mesh_point(pts, vel, adv, i0), p1 = mesh_point(pts, vel, adv, i1), p2 = mesh_point(pts, vel, adv, i2);
   V3 fp = v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
   Stencil s = make_stencil(fp, d.inv_dx);
   if (!splat_ok(d.G, s)) return;
@@ -493,6 +598,9 @@ __global__ void k_face_splat(const float *pts, const float *vel, const int32_t *
     int x = s.bx + i, y = s.by + j, z = s.bz + k;
     int blk = blk_of(x, y, z, d.NB);
     if (!g.ab_flag[blk]) continue;
+    // only nodes that received mass are read with non-zero weight by g2p (weight > 0 <=> the same particle
+    // scattered mass there); p2g has completed on this stream, so massless nodes can be skipped
+    if (g.mv[((size_t)blk * GCH_MV) * 64 + loc_of(x, y, z)] == 0.0f) continue;
     float *p = g.col + ((size_t)blk * GCH_COL) * 64 + loc_of(x, y, z);
     atomicAdd(p, w);
     atomicAdd(p + 64, w * fv.x); atomicAdd(p + 128, w * fv.y); atomicAdd(p + 192, w * fv.z);
@@ -584,107 +692,119 @@ __global__ __launch_bounds__(TPB) void k_grid(const int *alist, int n_A, Dims d,
 }
 
 // ------------------------------------------------------------------------------------------------
-// g2p (g2p_v / g2p_e, mpm_utils.py:716-857) with the v_out tile staged in LDS
+// g2p (g2p_v / g2p_e, mpm_utils.py:716-857) with the v_out tile staged in LDS.
+// Factored gather: for every (i,j) column first reduce over k
+//   s0 = sum_k wz_k u_ijk,  s1 = sum_k dwz_k u_ijk,  s2 = sum_k k wz_k u_ijk          (u = grid_v_out)
+// then v = sum wxy s0,  M1 = sum u (x) (i,j,k) w = [sum i wxy s0 | sum j wxy s0 | sum wxy s2],
+// grad v = inv_dx [sum dwx wy s0 | sum wx dwy s0 | sum wxy s1],  C = 4 inv_dx (M1 - v (x) fx)
+// (the reference accumulates outer(grid_v, dpos) * weight * inv_dx * 4 with dpos = (i,j,k) - fx, :753-763).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void g2p_gather(const float *tile, int ox, int oy, int oz, V3 x, const Dims &d,
-                                           const GridPtrs &g, V3 &nv, M3 &nC, M3 &nF) {
+struct G2PResult {
+  V3 v;
+  M3 C, F;  // C (APIC matrix) and grad v
+};
+
+__device__ __forceinline__ G2PResult g2p_gather(const float *tile, int ox, int oy, int oz, V3 x, const Dims &d,
+                                                const GridPtrs &g) {
   Stencil s = make_stencil(x, d.inv_dx);
   int lx = s.bx - ox, ly = s.by - oy, lz = s.bz - oz;
   bool in_tile = !((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u);
-  int base = (lx * TILE + ly) * TILE + lz;
-  nv = v3(0, 0, 0);
-  nC = m3_zero();
-  nF = m3_zero();
+  int base = tile_idx(lx, ly, lz);
+  V3 nv = v3(0, 0, 0), Mx = v3(0, 0, 0), My = v3(0, 0, 0), Mz = v3(0, 0, 0);
+  V3 Fx = v3(0, 0, 0), Fy = v3(0, 0, 0), Fz = v3(0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 3; ++i) {
+    float wx = sel3(i, s.w0.x, s.w1.x, s.w2.x), dwx = sel3(i, s.dw0.x, s.dw1.x, s.dw2.x);
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < 3; ++j) {
+      float wy = sel3(j, s.w0.y, s.w1.y, s.w2.y), dwy = sel3(j, s.dw0.y, s.dw1.y, s.dw2.y);
+      V3 s0 = v3(0, 0, 0), s1 = v3(0, 0, 0), s2 = v3(0, 0, 0);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        float wx = sel3(i, s.w0.x, s.w1.x, s.w2.x), wy = sel3(j, s.w0.y, s.w1.y, s.w2.y), wz = sel3(k, s.w0.z, s.w1.z, s.w2.z);
-        float dwx = sel3(i, s.dw0.x, s.dw1.x, s.dw2.x), dwy = sel3(j, s.dw0.y, s.dw1.y, s.dw2.y), dwz = sel3(k, s.dw0.z, s.dw1.z, s.dw2.z);
-        float weight = wx * wy * wz;
-        V3 dweight = d.inv_dx * v3(dwx * wy * wz, wx * dwy * wz, wx * wy * dwz);
-        V3 dpos = v3((float)i - s.fx.x, (float)j - s.fx.y, (float)k - s.fx.z);
-        V3 gv;
+        float wzk = sel3(k, s.w0.z, s.w1.z, s.w2.z), dwzk = sel3(k, s.dw0.z, s.dw1.z, s.dw2.z);
+        V3 u;
         if (in_tile) {
-          int t = base + (i * TILE + j) * TILE + k;
-          gv = v3(tile[t], tile[TILE3 + t], tile[2 * TILE3 + t]);
+          const float *p = tile + base + tile_idx(i, j, k);
+          u = v3(p[0], p[TILE_PAD], p[2 * TILE_PAD]);
         } else {  // drifted out of the tile margin: read the global grid (zero outside active blocks)
           int x_ = s.bx + i, y_ = s.by + j, z_ = s.bz + k;
-          gv = v3(0, 0, 0);
+          u = v3(0, 0, 0);
           if (in_grid(x_, y_, z_, d.G)) {
             int blk = blk_of(x_, y_, z_, d.NB);
             if (g.ab_flag[blk]) {
               const float *p = g.vout + ((size_t)blk * GCH_VOUT) * 64 + loc_of(x_, y_, z_);
-              gv = v3(p[0], p[64], p[128]);
+              u = v3(p[0], p[64], p[128]);
             }
           }
         }
-        nv = nv + weight * gv;
-        nC = nC + (weight * d.inv_dx * 4.0f) * outer(gv, dpos);
-        nF = nF + outer(gv, dweight);
+        s0 = s0 + wzk * u;
+        s1 = s1 + dwzk * u;
+        if (k > 0) s2 = s2 + ((float)k * wzk) * u;
       }
+      float wxy = wx * wy;
+      nv = nv + wxy * s0;
+      if (i > 0) Mx = Mx + ((float)i * wxy) * s0;
+      if (j > 0) My = My + ((float)j * wxy) * s0;
+      Mz = Mz + wxy * s2;
+      Fx = Fx + (dwx * wy) * s0;
+      Fy = Fy + (wx * dwy) * s0;
+      Fz = Fz + wxy * s1;
+    }
+  }
+  G2PResult r;
+  r.v = nv;
+  float c4 = 4.0f * d.inv_dx;
+  r.C = m3_cols(c4 * (Mx - s.fx.x * nv), c4 * (My - s.fx.y * nv), c4 * (Mz - s.fx.z * nv));
+  r.F = m3_cols(d.inv_dx * Fx, d.inv_dx * Fy, d.inv_dx * Fz);
+  return r;
 }
 
 __global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const int *plist, const int *ranges, const int *chunks,
                                              int n_chunks, int n_P, Dims d, float dt, GridPtrs g) {
-  __shared__ float tile[3 * TILE3];
+  __shared__ float tile[3 * TILE_PAD];
   int w = xcd_slice(blockIdx.x, n_chunks);
   if (w < 0) return;
   int slot = chunks[2 * w], chunk = chunks[2 * w + 1];
   int blk = plist[slot];
   int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
   int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
+  ChunkMap cm = chunk_map(ranges, n_P, slot);
+  int cls = 0, s = 0;
+  bool valid = cm.map(chunk * CHUNK + (int)threadIdx.x, cls, s);
+  // particle loads first: their latency overlaps the tile staging below
+  V3 x = v3(0, 0, 0), d3 = v3(0, 0, 0);
+  M3 F = m3_identity();
+  if (valid) {
+    x = ld3(b.all, A_X, s);
+    if (cls == 0) d3 = v3(b.el.at(E_D + 2, s), b.el.at(E_D + 5, s), b.el.at(E_D + 8, s));
+    if (cls == 1) F = ld9(b.tr, T_F, s - d.n_e);
+  }
   for (int t = threadIdx.x; t < TILE3; t += TPB) {
-    int x = ox + (t >> 6), y = oy + ((t >> 3) & 7), z = oz + (t & 7);
+    int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
+    int gx = ox + ti, gy = oy + tj, gz = oz + tk;
     V3 v = v3(0, 0, 0);
-    if (in_grid(x, y, z, d.G)) {
-      const float *p = g.vout + ((size_t)blk_of(x, y, z, d.NB) * GCH_VOUT) * 64 + loc_of(x, y, z);
+    if (in_grid(gx, gy, gz, d.G)) {
+      const float *p = g.vout + ((size_t)blk_of(gx, gy, gz, d.NB) * GCH_VOUT) * 64 + loc_of(gx, gy, gz);
       v = v3(p[0], p[64], p[128]);
     }
-    tile[t] = v.x; tile[TILE3 + t] = v.y; tile[2 * TILE3 + t] = v.z;
+    float *q = tile + tile_idx(ti, tj, tk);
+    q[0] = v.x; q[TILE_PAD] = v.y; q[2 * TILE_PAD] = v.z;
   }
   __syncthreads();
+  if (!valid) return;
+  G2PResult r = g2p_gather(tile, ox, oy, oz, x, d, g);
+  st9(b.all, A_C, s, r.C);
+  if (cls == 0) {
+    // elements: C now, d3 <- (I + dt grad v) d3 now; x, v, d1, d2 in k_elem_finalize once all vertices are updated
+    V3 d3n = (m3_identity() + dt * r.F) * d3;
+    b.el.at(E_D + 2, s) = d3n.x; b.el.at(E_D + 5, s) = d3n.y; b.el.at(E_D + 8, s) = d3n.z;
+    return;
+  }
   float a_min = (1.0f / d.inv_dx) * 2.0f, a_max = d.grid_lim - (1.0f / d.inv_dx) * 2.0f;
-  // elements: C now; d3 <- (I + dt grad v) d3 now; x, v, d1, d2 in k_elem_finalize once all vertices are updated
-  {
-    int s0 = ranges[0 * n_P + slot] + chunk * CHUNK, s1 = min(ranges[1 * n_P + slot], s0 + CHUNK);
-    for (int s = s0 + threadIdx.x; s < s1; s += TPB) {
-      V3 nv; M3 nC, nF;
-      g2p_gather(tile, ox, oy, oz, ld3(b.all, A_X, s), d, g, nv, nC, nF);
-      st9(b.all, A_C, s, nC);
-      V3 d3 = v3(b.el.at(E_D + 2, s), b.el.at(E_D + 5, s), b.el.at(E_D + 8, s));
-      V3 d3n = (m3_identity() + dt * nF) * d3;
-      b.el.at(E_D + 2, s) = d3n.x; b.el.at(E_D + 5, s) = d3n.y; b.el.at(E_D + 8, s) = d3n.z;
-    }
-  }
-  // traditional
-  {
-    int s0 = ranges[2 * n_P + slot] + chunk * CHUNK, s1 = min(ranges[3 * n_P + slot], s0 + CHUNK);
-    for (int s = s0 + threadIdx.x; s < s1; s += TPB) {
-      V3 x = ld3(b.all, A_X, s), nv; M3 nC, nF;
-      g2p_gather(tile, ox, oy, oz, x, d, g, nv, nC, nF);
-      st3(b.all, A_V, s, nv);
-      V3 nx = x + dt * nv;
-      st3(b.all, A_X, s, v3(fminf(fmaxf(nx.x, a_min), a_max), fminf(fmaxf(nx.y, a_min), a_max), fminf(fmaxf(nx.z, a_min), a_max)));
-      st9(b.all, A_C, s, nC);
-      int t = s - d.n_e;
-      st9(b.tr, T_FT, t, (m3_identity() + dt * nF) * ld9(b.tr, T_F, t));
-    }
-  }
-  // vertices
-  {
-    int s0 = ranges[4 * n_P + slot] + chunk * CHUNK, s1 = min(ranges[5 * n_P + slot], s0 + CHUNK);
-    for (int s = s0 + threadIdx.x; s < s1; s += TPB) {
-      V3 x = ld3(b.all, A_X, s), nv; M3 nC, nF;
-      g2p_gather(tile, ox, oy, oz, x, d, g, nv, nC, nF);
-      st3(b.all, A_V, s, nv);
-      V3 nx = x + dt * nv;
-      st3(b.all, A_X, s, v3(fminf(fmaxf(nx.x, a_min), a_max), fminf(fmaxf(nx.y, a_min), a_max), fminf(fmaxf(nx.z, a_min), a_max)));
-      st9(b.all, A_C, s, nC);
-    }
-  }
+  st3(b.all, A_V, s, r.v);
+  V3 nx = x + dt * r.v;
+  st3(b.all, A_X, s, v3(fminf(fmaxf(nx.x, a_min), a_max), fminf(fmaxf(nx.y, a_min), a_max), fminf(fmaxf(nx.z, a_min), a_max)));
+  if (cls == 1) st9(b.tr, T_FT, s - d.n_e, (m3_identity() + dt * r.F) * F);
 }
 
 // second half of g2p_e (mpm_utils.py:838-857): x, v = mean of the three updated vertices; d1, d2 = edges
@@ -752,6 +872,32 @@ __global__ void k_count_active(const int *alist, int n_A, GridPtrs g, int *out) 
   if ((threadIdx.x & 63) == 0 && bal) atomicAdd(out, __popcll(bal));
 }
 
+// original-index ELL adjacency from the (float-encoded) faces: pass 0 counts valences, pass 1 fills
+__global__ void k_adj_build(const float *faces, int n_e, int n_v, int *cnt, int *adj, int K, int fill) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_e) return;
+  for (int c = 0; c < 3; ++c) {
+    int v = (int)faces[3 * (size_t)e + c];
+    if ((unsigned)v >= (unsigned)n_v) continue;
+    int slot = atomicAdd(cnt + v, 1);
+    if (fill && slot < K) adj[(size_t)slot * n_v + v] = (e << 2) | c;
+  }
+}
+__global__ void k_max_int(const int *a, int n, int *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicMax(out, a[i]);
+}
+// ELL adjacency in sorted slots: vertex slot vs <- original vertex perm[n_nv+vs]-n_nv, element ids through inv[]
+__global__ void k_adj_sorted(const int *adj_o, int *adj_s, const int *perm, const int *inv, int K, Dims d) {
+  int vs = blockIdx.x * blockDim.x + threadIdx.x;
+  if (vs >= d.n_v) return;
+  int o = perm[d.n_nv + vs] - d.n_nv;
+  for (int k = 0; k < K; ++k) {
+    int ent = adj_o[(size_t)k * d.n_v + o];
+    adj_s[(size_t)k * d.n_v + vs] = ent < 0 ? -1 : ((inv[ent >> 2] << 2) | (ent & 3));
+  }
+}
+
 __global__ void k_iota(int *p, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
@@ -769,7 +915,10 @@ struct FastState {
   Bufs buf[2]{};
   int cur = 0;
   int *perm[2] = {nullptr, nullptr}, *inv = nullptr, *face_slot = nullptr;
-  float *vforce = nullptr;
+  float *eforce = nullptr;   // [6][n_e]
+  int *adj_cnt = nullptr, *adj_o = nullptr, *adj_s = nullptr;
+  int adj_K = 0, adj_cap = 0;
+  VAdj va() const { return VAdj{adj_s, eforce, adj_K, d.n_v, d.n_e}; }
   unsigned *keys[2] = {nullptr, nullptr};
   int *order = nullptr, *iota = nullptr;
   void *sort_tmp = nullptr, *scan_tmp = nullptr;
@@ -850,6 +999,26 @@ int do_import(mpmhip_ctx *c) {
   }
   if (d.n_p)
     hipLaunchKernelGGL(k_import, nblk(d.n_p), TPB, 0, c->stream, c->st, c->md, f->buf[f->cur], f->perm[f->cur], d);
+  if (d.n_e && d.n_v) {  // cloth topology -> ELL adjacency (original indices); K = max valence
+    hipStream_t s = c->stream;
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->adj_cnt, 0, ((size_t)d.n_v + 1) * sizeof(int), s));
+    hipLaunchKernelGGL(k_adj_build, nblk(d.n_e), TPB, 0, s, c->st.faces, d.n_e, d.n_v, f->adj_cnt, (int *)nullptr, 0, 0);
+    hipLaunchKernelGGL(k_max_int, nblk(d.n_v), TPB, 0, s, f->adj_cnt, d.n_v, f->adj_cnt + d.n_v);
+    MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 16, f->adj_cnt + d.n_v, sizeof(int), hipMemcpyDeviceToHost, s));
+    MPM_HIP_CHECK(c, hipStreamSynchronize(s));
+    int K = std::max(f->h_pin[16], 1);
+    if (K > f->adj_cap) {
+      int rc2;
+      if ((rc2 = dalloc(c, &f->adj_o, (size_t)K * d.n_v, false))) return rc2;
+      if ((rc2 = dalloc(c, &f->adj_s, (size_t)K * d.n_v, false))) return rc2;
+      f->adj_cap = K;
+    }
+    f->adj_K = K;
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->adj_o, 0xff, (size_t)K * d.n_v * sizeof(int), s));
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->adj_cnt, 0, (size_t)d.n_v * sizeof(int), s));
+    hipLaunchKernelGGL(k_adj_build, nblk(d.n_e), TPB, 0, s, c->st.faces, d.n_e, d.n_v, f->adj_cnt, f->adj_o, K, 1);
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->eforce, 0, (size_t)6 * d.n_e * sizeof(float), s));
+  }
   c->caller_dirty = false;
   c->internal_dirty = false;
   f->steps_since_rebin = 1 << 30;  // force a rebin before the next transfer
@@ -877,6 +1046,8 @@ int rebin(mpmhip_ctx *c) {
                      f->inv, d);
   f->cur = cur = alt;
   if (d.n_e) hipLaunchKernelGGL(k_face_slots, nblk(d.n_e), TPB, 0, s, f->buf[cur], f->inv, f->face_slot, d);
+  if (d.n_e && d.n_v)
+    hipLaunchKernelGGL(k_adj_sorted, nblk(d.n_v), TPB, 0, s, f->adj_o, f->adj_s, f->perm[cur], f->inv, f->adj_K, d);
   const unsigned *skeys = f->keys[1];
   int nb = (int)f->nblocks;
   MPM_HIP_CHECK(c, hipMemsetAsync(f->pb_flag, 0, f->nblocks * sizeof(int), s));
@@ -899,10 +1070,10 @@ int rebin(mpmhip_ctx *c) {
   MPM_HIP_CHECK(c, hipStreamSynchronize(s));
   f->h_chunks.clear();
   for (int p = 0; p < f->n_P; ++p) {
-    int mx = 0;
+    int tot = 0;  // the three classes of a block are packed back to back (ChunkMap)
     for (int cl = 0; cl < 3; ++cl)
-      mx = std::max(mx, f->h_ranges[(size_t)(cl * 2 + 1) * f->n_P + p] - f->h_ranges[(size_t)(cl * 2) * f->n_P + p]);
-    int nch = (mx + CHUNK - 1) / CHUNK;
+      tot += f->h_ranges[(size_t)(cl * 2 + 1) * f->n_P + p] - f->h_ranges[(size_t)(cl * 2) * f->n_P + p];
+    int nch = (tot + CHUNK - 1) / CHUNK;
     for (int k = 0; k < nch; ++k) { f->h_chunks.push_back(p); f->h_chunks.push_back(k); }
   }
   f->n_chunks = (int)(f->h_chunks.size() / 2);
@@ -941,7 +1112,8 @@ int fast_init(mpmhip_ctx *c) {
   }
   if ((rc = dalloc(c, &f->inv, (size_t)d.n_p))) return rc;
   if ((rc = dalloc(c, &f->face_slot, (size_t)3 * d.n_e))) return rc;
-  if ((rc = dalloc(c, &f->vforce, (size_t)3 * d.n_v))) return rc;
+  if ((rc = dalloc(c, &f->eforce, (size_t)6 * d.n_e))) return rc;
+  if ((rc = dalloc(c, &f->adj_cnt, (size_t)d.n_v + 1))) return rc;
   if ((rc = dalloc(c, &f->order, (size_t)d.n_p))) return rc;
   if ((rc = dalloc(c, &f->iota, (size_t)d.n_p))) return rc;
   if ((rc = dalloc(c, &f->g.mv, f->nblocks * GCH_MV * 64))) return rc;
@@ -987,7 +1159,7 @@ int fast_pull(mpmhip_ctx *c) {
   const Dims &d = f->d;
   if (d.n_p && f->have_order) {
     int m = c->sc.material;
-    hipLaunchKernelGGL(k_export, nblk(d.n_p), TPB, 0, c->stream, c->st, c->md, f->buf[f->cur], f->vforce,
+    hipLaunchKernelGGL(k_export, nblk(d.n_p), TPB, 0, c->stream, c->st, c->md, f->buf[f->cur], f->va(),
                        f->perm[f->cur], d, (m == 1 || m == 5) ? 1 : 0);
   }
   c->internal_dirty = false;
@@ -1018,21 +1190,20 @@ int fast_step(mpmhip_ctx *c, const StepArgs &a) {
   Bufs &b = f->buf[f->cur];
   {
     ScopedPhase ph(c, "compute_stress_from_F_trial");
-    if (d.n_v) MPM_HIP_CHECK(c, hipMemsetAsync(f->vforce, 0, (size_t)3 * d.n_v * sizeof(float), s));
-    if (d.n_e) hipLaunchKernelGGL(k_stress_elem, nblk(d.n_e), TPB, 0, s, b, f->face_slot, f->vforce, d, c->sc.friction_coeff);
+    if (d.n_e) hipLaunchKernelGGL(k_stress_elem, nblk(d.n_e), TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff);
     if (d.n_t) hipLaunchKernelGGL(k_stress_trad, nblk(d.n_t), TPB, 0, s, b, d, c->sc, dt);
   }
   {
     ScopedPhase ph(c, "p2g");
     if (f->n_chunks)
-      hipLaunchKernelGGL(k_p2g, xcd_grid(f->n_chunks), TPB, 0, s, b, f->vforce, f->plist, f->ranges, f->chunks,
+      hipLaunchKernelGGL(k_p2g, xcd_grid(f->n_chunks), TPB, 0, s, b, f->va(), f->plist, f->ranges, f->chunks,
                          f->n_chunks, f->n_P, d, c->sc.rpic_damping, dt, f->g);
   }
   bool mov_on = a.joint_v_v && a.joint_f_v && !c->movers.empty();
   {
     ScopedPhase ph(c, "apply_Mesh_Collision_on_grid");
     if (!c->colliders.empty() && c->num_mesh_f)
-      hipLaunchKernelGGL(k_face_splat, nblk(c->num_mesh_f), TPB, 0, s, c->mesh_points, c->mesh_vel, c->mesh_idx,
+      hipLaunchKernelGGL(k_face_splat, nblk(c->num_mesh_f), TPB, 0, s, c->cur_pts, c->cur_vel, c->cur_f, c->mesh_idx,
                          c->num_mesh_f, d, f->g);
   }
   if (mov_on) {
