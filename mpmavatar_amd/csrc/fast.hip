@@ -79,14 +79,17 @@ __device__ __forceinline__ int loc_of(int x, int y, int z) { return ((x & 3) << 
 __device__ __forceinline__ bool in_grid(int x, int y, int z, int G) {
   return (unsigned)x < (unsigned)G && (unsigned)y < (unsigned)G && (unsigned)z < (unsigned)G;
 }
-// XCD-aware remap: consecutive workgroup ids land on different XCDs (observed: id % 8), so give each XCD a
-// contiguous slice of the (block-sorted) work list and keep neighbouring tiles in one L2.
+// XCD-aware remap: consecutive workgroup ids land on different XCDs (observed: id % 8).  Work items are sorted by
+// grid block, so runs of XCD_RUN consecutive items (neighbouring tiles) are given to the same XCD to share its L2,
+// while successive runs rotate over the 8 XCDs so that a spatially concentrated load (e.g. the blocks around the
+// body collider) is spread over the whole chip instead of landing on one or two XCDs.
+constexpr int XCD_RUN = 16;
 __device__ __forceinline__ int xcd_slice(int w, int n) {
-  int per = (n + 7) >> 3;
-  int i = (w & 7) * per + (w >> 3);
+  int xcd = w & 7, idx = w >> 3;
+  int i = ((idx / XCD_RUN) * 8 + xcd) * XCD_RUN + (idx % XCD_RUN);
   return i < n ? i : -1;
 }
-inline unsigned xcd_grid(int n) { return (unsigned)(((n + 7) / 8) * 8); }
+inline unsigned xcd_grid(int n) { return (unsigned)(((n + 8 * XCD_RUN - 1) / (8 * XCD_RUN)) * (8 * XCD_RUN)); }
 
 // ------------------------------------------------------------------------------------------------
 // import / export between the caller's AoS arrays (reference layout) and the sorted SoA state
@@ -573,38 +576,128 @@ __device__ __forceinline__ bool splat_ok(int G, const Stencil &s) {
   return s.bx >= 0 && s.bx < G - 3 && s.by >= 0 && s.by < G - 3 && s.bz >= 0 && s.bz < G - 3;
 }
 
-__global__ void k_face_splat(const float *pts, const float *vel, float adv, const int32_t *idx, int n_f, Dims d, GridPtrs g) {
+// Body-mesh collider (compute_mesh, mpm_solver.py:829-880) with the same LDS-tile structure as p2g.  Faces are
+// binned by grid block at each re-sort (rocPRIM sort of the centroid's block key).  Per substep one wavefront per
+// ACTIVE block takes the faces binned there (lane = face: centroid, mean vertex velocity, unit normal with the
+// caller's mesh advection applied), accumulates weight / weight*velocity / weight*normal into a 7-channel fp64
+// LDS tile with ds_add_f64 and flushes the touched nodes to the block-major collider channels with coalesced
+// atomics.  Faces in blocks outside the active list cannot reach a node that carries mass and are skipped; a
+// face that drifted out of its tile margin since the last re-sort falls back to global atomics.
+// (Tried and dropped: gathering the faces per node block inside the grid stage -- no atomics at all, but the few
+// wavefronts next to the body serialise ~50 faces x 60 dependent instructions each and set the kernel's tail.)
+constexpr int COL_CH = 7;
+
+__device__ __forceinline__ int face_block(V3 fp, const Dims &d) {
+  int bx = (int)(fp.x * d.inv_dx - 0.5f), by = (int)(fp.y * d.inv_dx - 0.5f), bz = (int)(fp.z * d.inv_dx - 0.5f);
+  bx = min(max(bx, 0), d.G - 1); by = min(max(by, 0), d.G - 1); bz = min(max(bz, 0), d.G - 1);
+  return blk_of(bx, by, bz, d.NB);
+}
+__device__ __forceinline__ V3 face_centroid(const float *pts, const float *vel, float adv, const int32_t *idx, int f,
+                                            V3 &p0, V3 &p1, V3 &p2) {
+  int i0 = idx[3 * f], i1 = idx[3 * f + 1], i2 = idx[3 * f + 2];
+  p0 = mesh_point(pts, vel, adv, i0); p1 = mesh_point(pts, vel, adv, i1); p2 = mesh_point(pts, vel, adv, i2);
+  return v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
+}
+
+__global__ void k_face_keys(const float *pts, const float *vel, float adv, const int32_t *idx, int n_f, Dims d,
+                            unsigned *keys, int *iota) {
   int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n_f) return;
-  int i0 = idx[3 * f], i1 = idx[3 * f + 1], i2 = idx[3 * f + 2];
-  V3 p0 = mesh_point(pts, vel, adv, i0), p1 = mesh_point(pts, vel, adv, i1), p2 = mesh_point(pts, vel, adv, i2);
-  V3 fp = v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
-  Stencil s = make_stencil(fp, d.inv_dx);
-  if (!splat_ok(d.G, s)) return;
-  // cull faces whose 3x3x3 nodes touch no active block: those nodes are never read by g2p
-  bool any = false;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    int x = s.bx + ((c & 1) ? 2 : 0), y = s.by + ((c & 2) ? 2 : 0), z = s.bz + ((c & 4) ? 2 : 0);
-    any = any || g.ab_flag[blk_of(x, y, z, d.NB)];
+  V3 p0, p1, p2;
+  keys[f] = (unsigned)face_block(face_centroid(pts, vel, adv, idx, f, p0, p1, p2), d);
+  iota[f] = f;
+}
+
+__global__ void k_face_bins(const unsigned *skeys, int n_f, int *fb_start, int *fb_cnt) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_f) return;
+  unsigned k = skeys[j];
+  if (j == 0 || skeys[j - 1] != k) fb_start[k] = j;
+  atomicAdd(fb_cnt + k, 1);
+}
+
+// non-empty face bins that lie on the active list (order irrelevant)
+__global__ void k_fbin_compact(const int *alist, int n_A, const int *fb_cnt, int *list, int *counter) {
+  int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n_A) return;
+  int blk = alist[a];
+  if (fb_cnt[blk] > 0) list[atomicAdd(counter, 1)] = blk;
+}
+
+__global__ __launch_bounds__(64) void k_col_splat(const float *pts, const float *vel, float adv, const int32_t *idx,
+                                                  const int *order, const int *fb_start, const int *fb_cnt,
+                                                  const int *fbins, int n_fbins, Dims d, GridPtrs g) {
+  __shared__ double tile[COL_CH * TILE_PAD];
+  if ((int)blockIdx.x >= n_fbins) return;
+  int blk = fbins[blockIdx.x];
+  int cnt = fb_cnt[blk];
+  int j0 = fb_start[blk], l = threadIdx.x;
+  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
+  int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
+  for (int t = l; t < COL_CH * TILE_PAD; t += 64) tile[t] = 0.0;
+  // active flags of the 27 blocks the tile overlaps, fetched once (lane n < 27 -> neighbour n)
+  bool nb_act = false;
+  if (l < 27) {
+    int x = bx + l / 9 - 1, y = by + (l / 3) % 3 - 1, z = bz + l % 3 - 1;
+    if ((unsigned)x < (unsigned)d.NB && (unsigned)y < (unsigned)d.NB && (unsigned)z < (unsigned)d.NB)
+      nb_act = g.ab_flag[(x * d.NB + y) * d.NB + z] != 0;
   }
-  if (!any) return;
-  V3 u0 = load_v3(vel + 3 * i0), u1 = load_v3(vel + 3 * i1), u2 = load_v3(vel + 3 * i2);
-  V3 fv = v3((u0.x + u1.x + u2.x) / 3.0f, (u0.y + u1.y + u2.y) / 3.0f, (u0.z + u1.z + u2.z) / 3.0f);
-  V3 fn = normalize(cross(p1 - p0, p2 - p0));
-  for (int n = 0; n < 27; ++n) {
-    int i = n / 9, j = (n / 3) % 3, k = n % 3;
-    float w = sel3(i, s.w0.x, s.w1.x, s.w2.x) * sel3(j, s.w0.y, s.w1.y, s.w2.y) * sel3(k, s.w0.z, s.w1.z, s.w2.z);
-    int x = s.bx + i, y = s.by + j, z = s.bz + k;
-    int blk = blk_of(x, y, z, d.NB);
-    if (!g.ab_flag[blk]) continue;
-    // only nodes that received mass are read with non-zero weight by g2p (weight > 0 <=> the same particle
-    // scattered mass there); p2g has completed on this stream, so massless nodes can be skipped
-    if (g.mv[((size_t)blk * GCH_MV) * 64 + loc_of(x, y, z)] == 0.0f) continue;
-    float *p = g.col + ((size_t)blk * GCH_COL) * 64 + loc_of(x, y, z);
+  unsigned long long act_mask = __ballot(nb_act);
+  __syncthreads();
+  for (int jj = j0; jj < j0 + cnt; jj += 64) {
+    if (jj + l >= j0 + cnt) continue;
+    int f = order[jj + l];
+    V3 p0, p1, p2;
+    V3 fp = face_centroid(pts, vel, adv, idx, f, p0, p1, p2);
+    Stencil s = make_stencil(fp, d.inv_dx);
+    if (!splat_ok(d.G, s)) continue;  // mpm_solver.py:858
+    int i0 = idx[3 * f], i1 = idx[3 * f + 1], i2 = idx[3 * f + 2];
+    V3 u0 = load_v3(vel + 3 * i0), u1 = load_v3(vel + 3 * i1), u2 = load_v3(vel + 3 * i2);
+    V3 fv = v3((u0.x + u1.x + u2.x) / 3.0f, (u0.y + u1.y + u2.y) / 3.0f, (u0.z + u1.z + u2.z) / 3.0f);
+    V3 fn = normalize(cross(p1 - p0, p2 - p0));  // wp.mesh_eval_face_normal
+    int lx = s.bx - ox, ly = s.by - oy, lz = s.bz - oz;
+    bool in_tile = !((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u);
+    int base = tile_idx(lx, ly, lz);
+    int n = l % 27, i = n / 9, j = (n / 3) % 3, k = n % 3;  // staggered start: neighbouring faces share nodes
+#pragma unroll 3
+    for (int t = 0; t < 27; ++t) {
+      float w = sel3(i, s.w0.x, s.w1.x, s.w2.x) * sel3(j, s.w0.y, s.w1.y, s.w2.y) * sel3(k, s.w0.z, s.w1.z, s.w2.z);
+      if (in_tile) {
+        double *p = tile + base + tile_idx(i, j, k);
+        atomicAdd(p, (double)w);
+        atomicAdd(p + TILE_PAD, (double)(w * fv.x)); atomicAdd(p + 2 * TILE_PAD, (double)(w * fv.y));
+        atomicAdd(p + 3 * TILE_PAD, (double)(w * fv.z));
+        atomicAdd(p + 4 * TILE_PAD, (double)(w * fn.x)); atomicAdd(p + 5 * TILE_PAD, (double)(w * fn.y));
+        atomicAdd(p + 6 * TILE_PAD, (double)(w * fn.z));
+      } else {  // drifted out of the tile margin since the faces were binned
+        g.counters[6] = 1;
+        int x = s.bx + i, y = s.by + j, z = s.bz + k;
+        int nb = blk_of(x, y, z, d.NB);
+        if (g.ab_flag[nb]) {
+          float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
+          atomicAdd(p, w);
+          atomicAdd(p + 64, w * fv.x); atomicAdd(p + 128, w * fv.y); atomicAdd(p + 192, w * fv.z);
+          atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
+        }
+      }
+      if (++k == 3) { k = 0; if (++j == 3) { j = 0; if (++i == 3) i = 0; } }
+    }
+  }
+  __syncthreads();
+  for (int t = l; t < TILE3; t += 64) {
+    int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
+    const double *q = tile + tile_idx(ti, tj, tk);
+    float w = (float)q[0];
+    if (w == 0.0f) continue;
+    int x = ox + ti, y = oy + tj, z = oz + tk;
+    if (!in_grid(x, y, z, d.G)) continue;
+    int nb = blk_of(x, y, z, d.NB);
+    int nidx = (((x >> 2) - bx + 1) * 3 + ((y >> 2) - by + 1)) * 3 + ((z >> 2) - bz + 1);
+    if (!((act_mask >> nidx) & 1ull)) continue;  // inactive block: never read by g2p, never re-zeroed
+    float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
     atomicAdd(p, w);
-    atomicAdd(p + 64, w * fv.x); atomicAdd(p + 128, w * fv.y); atomicAdd(p + 192, w * fv.z);
-    atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
+    atomicAdd(p + 64, (float)q[TILE_PAD]); atomicAdd(p + 128, (float)q[2 * TILE_PAD]); atomicAdd(p + 192, (float)q[3 * TILE_PAD]);
+    atomicAdd(p + 256, (float)q[4 * TILE_PAD]); atomicAdd(p + 320, (float)q[5 * TILE_PAD]); atomicAdd(p + 384, (float)q[6 * TILE_PAD]);
   }
 }
 
@@ -657,7 +750,9 @@ __global__ __launch_bounds__(TPB) void k_grid(const int *alist, int n_A, Dims d,
   }
   if (gp.damping < 1.0f) v = v - (1.0f - gp.damping) * v;
   if (m != 0.0f || px != 0.0f || py != 0.0f || pz != 0.0f) { pm[0] = 0.0f; pm[64] = 0.0f; pm[128] = 0.0f; pm[192] = 0.0f; }
-  if (gp.has_col) {
+  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
+  int gxn = 4 * bx + (l >> 4), gyn = 4 * by + ((l >> 2) & 3), gzn = 4 * bz + (l & 3);
+  if (gp.has_col) {  // normalize_grid + collide, mpm_solver.py:882-917
     float *pc = g.col + ((size_t)blk * GCH_COL) * 64 + l;
     float wc = pc[0];
     if (wc != 0.0f) {
@@ -674,8 +769,6 @@ __global__ __launch_bounds__(TPB) void k_grid(const int *alist, int n_A, Dims d,
       pv[0] = 0.0f; pv[64] = 0.0f; pv[128] = 0.0f; pv[192] = 0.0f;
     }
   }
-  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
-  int gxn = 4 * bx + (l >> 4), gyn = 4 * by + ((l >> 2) & 3), gzn = 4 * bz + (l & 3);
   if (bcl.n > 0 && in_grid(gxn, gyn, gzn, d.G)) {
     size_t dense = ((size_t)gxn * d.G + gyn) * d.G + gzn;
     for (int k = 0; k < bcl.n; ++k) apply_bc(bcl.bc[k], v, gxn, gyn, gzn, d.G, d.dx, gp.time, gp.dt, dense);
@@ -803,12 +896,17 @@ __global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const int *plist, const int
   float a_min = (1.0f / d.inv_dx) * 2.0f, a_max = d.grid_lim - (1.0f / d.inv_dx) * 2.0f;
   st3(b.all, A_V, s, r.v);
   V3 nx = x + dt * r.v;
-  st3(b.all, A_X, s, v3(fminf(fmaxf(nx.x, a_min), a_max), fminf(fmaxf(nx.y, a_min), a_max), fminf(fmaxf(nx.z, a_min), a_max)));
+  nx = v3(fminf(fmaxf(nx.x, a_min), a_max), fminf(fmaxf(nx.y, a_min), a_max), fminf(fmaxf(nx.z, a_min), a_max));
+  st3(b.all, A_X, s, nx);
+  {  // will this particle still fit its block's tile at the next p2g?  If not, ask the host for a re-sort.
+    int nbx = (int)(nx.x * d.inv_dx - 0.5f) - ox, nby = (int)(nx.y * d.inv_dx - 0.5f) - oy, nbz = (int)(nx.z * d.inv_dx - 0.5f) - oz;
+    if ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u) g.counters[6] = 1;
+  }
   if (cls == 1) st9(b.tr, T_FT, s - d.n_e, (m3_identity() + dt * r.F) * F);
 }
 
 // second half of g2p_e (mpm_utils.py:838-857): x, v = mean of the three updated vertices; d1, d2 = edges
-__global__ void k_elem_finalize(Bufs b, const int *face_slot, Dims d) {
+__global__ void k_elem_finalize(Bufs b, const int *face_slot, const unsigned *skeys, int blk_bits, int *counters, Dims d) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.n_e) return;
   if (b.sel[e] != 0) return;
@@ -816,7 +914,14 @@ __global__ void k_elem_finalize(Bufs b, const int *face_slot, Dims d) {
   V3 x1 = ld3(b.all, A_X, v1), x2 = ld3(b.all, A_X, v2), x3 = ld3(b.all, A_X, v3i);
   V3 u1 = ld3(b.all, A_V, v1), u2 = ld3(b.all, A_V, v2), u3 = ld3(b.all, A_V, v3i);
   st3(b.all, A_V, e, v3((u1.x + u2.x + u3.x) / 3.0f, (u1.y + u2.y + u3.y) / 3.0f, (u1.z + u2.z + u3.z) / 3.0f));
-  st3(b.all, A_X, e, v3((x1.x + x2.x + x3.x) / 3.0f, (x1.y + x2.y + x3.y) / 3.0f, (x1.z + x2.z + x3.z) / 3.0f));
+  V3 xe = v3((x1.x + x2.x + x3.x) / 3.0f, (x1.y + x2.y + x3.y) / 3.0f, (x1.z + x2.z + x3.z) / 3.0f);
+  st3(b.all, A_X, e, xe);
+  {  // drift check against the block this element was sorted into
+    int blk = key_block(skeys[e], blk_bits);
+    int oz = 4 * (blk % d.NB) - 1, oy = 4 * ((blk / d.NB) % d.NB) - 1, ox = 4 * (blk / (d.NB * d.NB)) - 1;
+    int nbx = (int)(xe.x * d.inv_dx - 0.5f) - ox, nby = (int)(xe.y * d.inv_dx - 0.5f) - oy, nbz = (int)(xe.z * d.inv_dx - 0.5f) - oz;
+    if ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u) counters[6] = 1;
+  }
   V3 d1 = x2 - x1, d2 = x3 - x1;
   b.el.at(E_D + 0, e) = d1.x; b.el.at(E_D + 3, e) = d1.y; b.el.at(E_D + 6, e) = d1.z;
   b.el.at(E_D + 1, e) = d2.x; b.el.at(E_D + 4, e) = d2.y; b.el.at(E_D + 7, e) = d2.z;
@@ -915,6 +1020,14 @@ struct FastState {
   Bufs buf[2]{};
   int cur = 0;
   int *perm[2] = {nullptr, nullptr}, *inv = nullptr, *face_slot = nullptr;
+  // body-face bins (collider gather)
+  unsigned *fkeys[2] = {nullptr, nullptr};
+  int *forder = nullptr, *fiota = nullptr, *fb_start = nullptr, *fb_cnt = nullptr;
+  bool faces_binned = false;
+  hipStream_t side = nullptr;            // collider / mover splats overlap stress + p2g
+  hipEvent_t ev_ready = nullptr, ev_side = nullptr;
+  int *fbins = nullptr;
+  int cap_fbins = 0, n_fbins = 0;
   float *eforce = nullptr;   // [6][n_e]
   int *adj_cnt = nullptr, *adj_o = nullptr, *adj_s = nullptr;
   int adj_K = 0, adj_cap = 0;
@@ -932,6 +1045,8 @@ struct FastState {
   int *h_pin = nullptr;  // pinned host scratch
   std::vector<int> h_ranges, h_chunks;
   int steps_since_rebin = 0;
+  hipEvent_t ev_flag = nullptr;
+  bool flag_pending = false;
   bool have_order = false;
   int64_t rebins = 0;
   int rebin_interval = 32;
@@ -1081,6 +1196,33 @@ int rebin(mpmhip_ctx *c) {
   if (f->n_chunks)
     MPM_HIP_CHECK(c, hipMemcpyAsync(f->chunks, f->h_chunks.data(), f->h_chunks.size() * sizeof(int), hipMemcpyHostToDevice, s));
   MPM_HIP_CHECK(c, hipStreamSynchronize(s));  // h_chunks is pageable: the copy must finish before it is reused
+  if (!c->colliders.empty() && c->num_mesh_f) {
+    int nf = c->num_mesh_f;
+    hipLaunchKernelGGL(k_face_keys, nblk(nf), TPB, 0, s, c->cur_pts, c->cur_vel, c->cur_f, c->mesh_idx, nf, d, f->fkeys[0], f->fiota);
+    size_t need2 = 0;
+    MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(nullptr, need2, f->fkeys[0], f->fkeys[1], f->fiota, f->forder, (size_t)nf, 0u,
+                                               (unsigned)f->blk_bits, s));
+    if (need2 > f->sort_tmp_bytes) {
+      MPM_HIP_CHECK(c, hipMalloc(&f->sort_tmp, need2));
+      f->allocs.push_back(f->sort_tmp);
+      f->sort_tmp_bytes = need2;
+    }
+    MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(f->sort_tmp, need2, f->fkeys[0], f->fkeys[1], f->fiota, f->forder, (size_t)nf,
+                                               0u, (unsigned)f->blk_bits, s));
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->fb_cnt, 0, f->nblocks * sizeof(int), s));
+    hipLaunchKernelGGL(k_face_bins, nblk(nf), TPB, 0, s, f->fkeys[1], nf, f->fb_start, f->fb_cnt);
+    if ((rc = ensure_cap(c, &f->fbins, &f->cap_fbins, std::min(nf, f->n_A), 1))) return rc;
+    int *cnt = f->g.counters + 5;
+    MPM_HIP_CHECK(c, hipMemsetAsync(cnt, 0, sizeof(int), s));
+    if (f->n_A) hipLaunchKernelGGL(k_fbin_compact, nblk(f->n_A), TPB, 0, s, f->alist, f->n_A, f->fb_cnt, f->fbins, cnt);
+    MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 20, cnt, sizeof(int), hipMemcpyDeviceToHost, s));
+    MPM_HIP_CHECK(c, hipStreamSynchronize(s));
+    f->n_fbins = f->h_pin[20];
+    f->faces_binned = true;
+  }
+  MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + 6, 0, sizeof(int), s));
+  f->h_pin[24] = 0;
+  f->flag_pending = false;
   f->g.ab_flag = f->ab_flag;
   f->steps_since_rebin = 0;
   f->rebins += 1;
@@ -1103,7 +1245,8 @@ int fast_init(mpmhip_ctx *c) {
   while ((1ull << f->blk_bits) < f->nblocks) ++f->blk_bits;
   f->key_bits = f->blk_bits + 6 + 1 + 2;
   if (f->key_bits > 32) return fail(c, MPMHIP_ERR_INVALID, "grid too large for 32-bit sort keys");
-  f->rebin_interval = cfg.rebin_interval > 0 ? cfg.rebin_interval : 32;
+  // upper bound between re-sorts; the drift flag normally triggers one earlier (or never, for slow scenes)
+  f->rebin_interval = cfg.rebin_interval > 0 ? cfg.rebin_interval : 256;
   int rc;
   for (int i = 0; i < 2; ++i) {
     if ((rc = alloc_bufs(c, f->buf[i]))) return rc;
@@ -1126,6 +1269,10 @@ int fast_init(mpmhip_ctx *c) {
   f->g.ab_flag = f->ab_flag;
   if (const char *e = getenv("MPMHIP_DBG")) f->g.dbg = atoi(e);
   MPM_HIP_CHECK(c, hipHostMalloc((void **)&f->h_pin, 64 * sizeof(int), hipHostMallocDefault));
+  MPM_HIP_CHECK(c, hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+  MPM_HIP_CHECK(c, hipEventCreateWithFlags(&f->ev_ready, hipEventDisableTiming));
+  MPM_HIP_CHECK(c, hipEventCreateWithFlags(&f->ev_side, hipEventDisableTiming));
+  MPM_HIP_CHECK(c, hipEventCreateWithFlags(&f->ev_flag, hipEventDisableTiming));
   return MPMHIP_OK;
 }
 
@@ -1134,6 +1281,10 @@ void fast_destroy(mpmhip_ctx *c) {
   if (!f) return;
   for (void *p : f->allocs) (void)hipFree(p);
   if (f->h_pin) (void)hipHostFree(f->h_pin);
+  if (f->side) { (void)hipStreamSynchronize(f->side); (void)hipStreamDestroy(f->side); }
+  if (f->ev_ready) (void)hipEventDestroy(f->ev_ready);
+  if (f->ev_side) (void)hipEventDestroy(f->ev_side);
+  if (f->ev_flag) (void)hipEventDestroy(f->ev_flag);
   delete f;
   c->fast = nullptr;
 }
@@ -1141,9 +1292,16 @@ void fast_destroy(mpmhip_ctx *c) {
 int fast_add_collider_storage(mpmhip_ctx *c, MeshCollider &mc) {
   FastState *f = c->fast;
   if (!c->colliders.empty()) return fail(c, MPMHIP_ERR_LIMIT, "fast mode supports one mesh collider (the reference drivers register one)");
-  int rc = dalloc(c, &f->g.col, f->nblocks * GCH_COL * 64);
+  int rc, nf = c->num_mesh_f;
+  for (int i = 0; i < 2; ++i)
+    if ((rc = dalloc(c, &f->fkeys[i], (size_t)nf))) return rc;
+  if ((rc = dalloc(c, &f->forder, (size_t)nf))) return rc;
+  if ((rc = dalloc(c, &f->fiota, (size_t)nf))) return rc;
+  if ((rc = dalloc(c, &f->fb_start, f->nblocks))) return rc;
+  if ((rc = dalloc(c, &f->fb_cnt, f->nblocks))) return rc;
+  if ((rc = dalloc(c, &f->g.col, f->nblocks * GCH_COL * 64))) return rc;
   mc.weight = f->g.col;
-  return rc;
+  return MPMHIP_OK;
 }
 
 int fast_add_mover_storage(mpmhip_ctx *c, Mover &mv) {
@@ -1183,11 +1341,52 @@ int fast_step(mpmhip_ctx *c, const StepArgs &a) {
         hipLaunchKernelGGL(k_pre_sorted, nblk(d.n_p), TPB, 0, s, op, f->buf[f->cur], f->perm[f->cur], d, dt);
       }
   }
+  // Drift flag raised by g2p / element finalise / collider splat.  It is copied back every 8 substeps; before
+  // the next copy is issued the host waits for the previous one, which also bounds how far the host may run
+  // ahead of the GPU (<= 16 substeps) -- otherwise a fused mpmhip_steps(n) would have enqueued all n substeps
+  // long before the first flag arrives.
+  if (f->flag_pending && (f->steps_since_rebin & 7) == 0) {
+    MPM_HIP_CHECK(c, hipEventSynchronize(f->ev_flag));
+    f->flag_pending = false;
+    if (f->h_pin[24]) f->steps_since_rebin = 1 << 30;
+  }
   if (f->steps_since_rebin >= f->rebin_interval) {
     ScopedPhase ph(c, "rebin");
     if ((rc = rebin(c))) return rc;
   }
   Bufs &b = f->buf[f->cur];
+  // The body-face and joint splats only need the particle positions and the (re-zeroed) collider / mover
+  // channels, so they run on a side stream concurrently with stress + p2g and are joined before the grid stage.
+  // With profiling on (one sync per phase, like the reference's ScopedTimer) everything stays on one stream.
+  bool has_col = !c->colliders.empty() && c->num_mesh_f && f->n_fbins;
+  bool mov_on = a.joint_v_v && a.joint_f_v && !c->movers.empty();
+  bool side = !c->profiling && (has_col || mov_on);
+  hipStream_t ss = side ? f->side : s;
+  auto launch_splats = [&]() {
+    if (has_col) {
+      ScopedPhase ph(c, "apply_Mesh_Collision_on_grid");
+      hipLaunchKernelGGL(k_col_splat, (unsigned)f->n_fbins, 64, 0, ss, c->cur_pts, c->cur_vel, c->cur_f, c->mesh_idx,
+                         f->forder, f->fb_start, f->fb_cnt, f->fbins, f->n_fbins, d, f->g);
+    }
+    if (mov_on) {
+      ScopedPhase ph(c, "apply_Particle_Moving_on_grid");
+      if (a.joint_t_v && a.n_joint_t > 0)
+        hipLaunchKernelGGL(k_mover_splat, nblk(a.n_joint_t), TPB, 0, ss, b, f->inv, a.joint_t_v, a.n_joint_t,
+                           d.n_nv - a.n_joint_t, d, f->g);
+      if (c->cfg.num_joint_v > 0)
+        hipLaunchKernelGGL(k_mover_splat, nblk(c->cfg.num_joint_v), TPB, 0, ss, b, f->inv, a.joint_v_v,
+                           c->cfg.num_joint_v, d.n_nv, d, f->g);
+      if (c->cfg.num_joint_f > 0)
+        hipLaunchKernelGGL(k_mover_splat, nblk(c->cfg.num_joint_f), TPB, 0, ss, b, f->inv, a.joint_f_v,
+                           c->cfg.num_joint_f, 0, d, f->g);
+    }
+  };
+  if (side) {
+    MPM_HIP_CHECK(c, hipEventRecord(f->ev_ready, s));
+    MPM_HIP_CHECK(c, hipStreamWaitEvent(f->side, f->ev_ready, 0));
+    launch_splats();
+    MPM_HIP_CHECK(c, hipEventRecord(f->ev_side, f->side));
+  }
   {
     ScopedPhase ph(c, "compute_stress_from_F_trial");
     if (d.n_e) hipLaunchKernelGGL(k_stress_elem, nblk(d.n_e), TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff);
@@ -1199,29 +1398,12 @@ int fast_step(mpmhip_ctx *c, const StepArgs &a) {
       hipLaunchKernelGGL(k_p2g, xcd_grid(f->n_chunks), TPB, 0, s, b, f->va(), f->plist, f->ranges, f->chunks,
                          f->n_chunks, f->n_P, d, c->sc.rpic_damping, dt, f->g);
   }
-  bool mov_on = a.joint_v_v && a.joint_f_v && !c->movers.empty();
-  {
-    ScopedPhase ph(c, "apply_Mesh_Collision_on_grid");
-    if (!c->colliders.empty() && c->num_mesh_f)
-      hipLaunchKernelGGL(k_face_splat, nblk(c->num_mesh_f), TPB, 0, s, c->cur_pts, c->cur_vel, c->cur_f, c->mesh_idx,
-                         c->num_mesh_f, d, f->g);
-  }
-  if (mov_on) {
-    ScopedPhase ph(c, "apply_Particle_Moving_on_grid");
-    if (a.joint_t_v && a.n_joint_t > 0)
-      hipLaunchKernelGGL(k_mover_splat, nblk(a.n_joint_t), TPB, 0, s, b, f->inv, a.joint_t_v, a.n_joint_t,
-                         d.n_nv - a.n_joint_t, d, f->g);
-    if (c->cfg.num_joint_v > 0)
-      hipLaunchKernelGGL(k_mover_splat, nblk(c->cfg.num_joint_v), TPB, 0, s, b, f->inv, a.joint_v_v,
-                         c->cfg.num_joint_v, d.n_nv, d, f->g);
-    if (c->cfg.num_joint_f > 0)
-      hipLaunchKernelGGL(k_mover_splat, nblk(c->cfg.num_joint_f), TPB, 0, s, b, f->inv, a.joint_f_v,
-                         c->cfg.num_joint_f, 0, d, f->g);
-  }
+  if (side) MPM_HIP_CHECK(c, hipStreamWaitEvent(s, f->ev_side, 0));
+  else launch_splats();
   {
     ScopedPhase ph(c, "grid_update");
     GridParams gp{dt, c->sc.g[0], c->sc.g[1], c->sc.g[2], c->sc.grid_v_damping_scale, (float)c->time,
-                  c->colliders.empty() ? 0 : 1, c->movers.empty() ? 0 : 1, mov_on ? 1 : 0,
+                  (c->colliders.empty() || !c->num_mesh_f) ? 0 : 1, c->movers.empty() ? 0 : 1, mov_on ? 1 : 0,
                   c->colliders.empty() ? 0.0f : c->colliders[0].friction, 1};
     f->stat_steps += 1;
     BCList bcl{};
@@ -1239,9 +1421,14 @@ int fast_step(mpmhip_ctx *c, const StepArgs &a) {
   }
   {
     ScopedPhase ph(c, "g2p_e");
-    if (d.n_e) hipLaunchKernelGGL(k_elem_finalize, nblk(d.n_e), TPB, 0, s, b, f->face_slot, d);
+    if (d.n_e) hipLaunchKernelGGL(k_elem_finalize, nblk(d.n_e), TPB, 0, s, b, f->face_slot, f->keys[1], f->blk_bits, f->g.counters, d);
   }
   f->steps_since_rebin += 1;
+  if (!f->flag_pending && (f->steps_since_rebin & 7) == 0) {
+    MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 24, f->g.counters + 6, sizeof(int), hipMemcpyDeviceToHost, s));
+    MPM_HIP_CHECK(c, hipEventRecord(f->ev_flag, s));
+    f->flag_pending = true;
+  }
   c->internal_dirty = true;
   MPM_HIP_CHECK(c, hipGetLastError());
   return MPMHIP_OK;

@@ -1,9 +1,9 @@
 #!/bin/bash
-# perf experiments: MPMHIP_DBG variants of the p2g kernel
+# perf experiments: MPMHIP_DBG variants (bit0 skip p2g flush, bit1 skip p2g scatter, bit2 skip collider gather)
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
-for d in 0 1 2 3; do
+for d in ${DBGS:-0 1 2 3}; do
   echo "== MPMHIP_DBG=$d"
-  MPMHIP_DBG=$d python bench.py --steps 100 --warmup 40 --no-cpu-baseline 2>/dev/null | python -c "
+  MPMHIP_DBG=$d python bench.py --steps 100 --warmup 40 --no-cpu-baseline ${BENCH_ARGS} 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
