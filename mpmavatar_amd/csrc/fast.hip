@@ -444,6 +444,34 @@ __device__ __forceinline__ float seg_scan(float v, const SegMask &sm) {
   v = fmaf(dpp_shr_f(v, 8), sm.m8, v);
   return v;
 }
+// The same scan for four values at once with the DPP source operand folded into the FMA
+// (v_fmac_f32_dpp: dst += dpp(src0) * src1; lanes whose source falls outside the 16-lane row are left
+// unchanged).  hipcc emits v_mov_b32_dpp + v_fmac_f32 for the C++ form above, i.e. twice the VALU issue slots,
+// and this kernel is VALU-bound.  The four chains are interleaved so that a register written by one DPP op is
+// read through DPP only three instructions later (gfx9 needs 2 wait states between a VALU write and a DPP
+// read of the same VGPR); the leading s_nop covers values produced right before the block.
+__device__ __forceinline__ void seg_scan4(float &a, float &b, float &c, float &d, const SegMask &sm) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_fmac_f32_dpp %0, %0, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %1, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %2, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %3, %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %0, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %1, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %2, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %3, %3, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %0, %6 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %1, %6 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %2, %6 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %3, %3, %6 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %0, %7 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %1, %1, %7 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %2, %2, %7 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %3, %3, %7 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d)
+      : "v"(sm.m1), "v"(sm.m2), "v"(sm.m4), "v"(sm.m8));
+}
 
 // contribution of q to stencil node (i,j,k) in the reference's form (mpm_utils.py:519-556); slow path only
 __device__ __forceinline__ void p2g_node_ref(const P2GParticle &q, int i, int j, int k, float &wm, V3 &add) {
@@ -535,7 +563,8 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const int *plist, 
           float wm = wxy * sel3(k, wzm0, wzm1, wzm2);
           V3 vel = Bij + (float)k * Cz;
           V3 add = wm * vel + wzk * P + dwzk * Q;
-          float r0 = seg_scan(wm, sm), r1 = seg_scan(add.x, sm), r2 = seg_scan(add.y, sm), r3 = seg_scan(add.z, sm);
+          float r0 = wm, r1 = add.x, r2 = add.y, r3 = add.z;
+          seg_scan4(r0, r1, r2, r3, sm);
           if (do_add) {
             double *p = tile + base + tile_idx(i, j, k);
             atomicAdd(p, (double)r0);
