@@ -341,6 +341,7 @@ struct GridPtrs {
   float *col;       // [block][8][64]: weight, v_in xyz, normal xyz, pad
   float *mov;       // [block][4][64]: weight, velocity xyz
   const int *ab_flag;
+  int *esc_list;    // [n_p] sorted indices of particles queued for k_g2p_escaped
   int *counters;    // [0] particles outside their tile margin, [1] dropped contributions (inactive block)
   int dbg;          // MPMHIP_DBG bitmask (perf experiments only): 1 skip p2g flush, 2 skip p2g LDS atomics
 };
@@ -826,12 +827,19 @@ struct G2PResult {
   M3 C, F;  // C (APIC matrix) and grad v
 };
 
-__device__ __forceinline__ G2PResult g2p_gather(const float *tile, int ox, int oy, int oz, V3 x, const Dims &d,
-                                                const GridPtrs &g) {
+__device__ __forceinline__ G2PResult g2p_finish(const Stencil &s, const Dims &d, V3 nv, V3 Mx, V3 My, V3 Mz, V3 Fx, V3 Fy,
+                                                V3 Fz) {
+  G2PResult r;
+  r.v = nv;
+  float c4 = 4.0f * d.inv_dx;
+  r.C = m3_cols(c4 * (Mx - s.fx.x * nv), c4 * (My - s.fx.y * nv), c4 * (Mz - s.fx.z * nv));
+  r.F = m3_cols(d.inv_dx * Fx, d.inv_dx * Fy, d.inv_dx * Fz);
+  return r;
+}
+
+__device__ __forceinline__ G2PResult g2p_gather(const float *tile, int ox, int oy, int oz, V3 x, const Dims &d) {
   Stencil s = make_stencil(x, d.inv_dx);
-  int lx = s.bx - ox, ly = s.by - oy, lz = s.bz - oz;
-  bool in_tile = !((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u);
-  int base = tile_idx(lx, ly, lz);
+  int base = tile_idx(s.bx - ox, s.by - oy, s.bz - oz);
   V3 nv = v3(0, 0, 0), Mx = v3(0, 0, 0), My = v3(0, 0, 0), Mz = v3(0, 0, 0);
   V3 Fx = v3(0, 0, 0), Fy = v3(0, 0, 0), Fz = v3(0, 0, 0);
 #pragma unroll
@@ -844,21 +852,8 @@ __device__ __forceinline__ G2PResult g2p_gather(const float *tile, int ox, int o
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         float wzk = sel3(k, s.w0.z, s.w1.z, s.w2.z), dwzk = sel3(k, s.dw0.z, s.dw1.z, s.dw2.z);
-        V3 u;
-        if (in_tile) {
-          const float *p = tile + base + tile_idx(i, j, k);
-          u = v3(p[0], p[TILE_PAD], p[2 * TILE_PAD]);
-        } else {  // drifted out of the tile margin: read the global grid (zero outside active blocks)
-          int x_ = s.bx + i, y_ = s.by + j, z_ = s.bz + k;
-          u = v3(0, 0, 0);
-          if (in_grid(x_, y_, z_, d.G)) {
-            int blk = blk_of(x_, y_, z_, d.NB);
-            if (g.ab_flag[blk]) {
-              const float *p = g.vout + ((size_t)blk * GCH_VOUT) * 64 + loc_of(x_, y_, z_);
-              u = v3(p[0], p[64], p[128]);
-            }
-          }
-        }
+        const float *p = tile + base + tile_idx(i, j, k);
+        V3 u = v3(p[0], p[TILE_PAD], p[2 * TILE_PAD]);
         s0 = s0 + wzk * u;
         s1 = s1 + dwzk * u;
         if (k > 0) s2 = s2 + ((float)k * wzk) * u;
@@ -873,48 +868,40 @@ __device__ __forceinline__ G2PResult g2p_gather(const float *tile, int ox, int o
       Fz = Fz + wxy * s1;
     }
   }
-  G2PResult r;
-  r.v = nv;
-  float c4 = 4.0f * d.inv_dx;
-  r.C = m3_cols(c4 * (Mx - s.fx.x * nv), c4 * (My - s.fx.y * nv), c4 * (Mz - s.fx.z * nv));
-  r.F = m3_cols(d.inv_dx * Fx, d.inv_dx * Fy, d.inv_dx * Fz);
-  return r;
+  return g2p_finish(s, d, nv, Mx, My, Mz, Fx, Fy, Fz);
 }
 
-__global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const int *plist, const int *ranges, const int *chunks,
-                                             int n_chunks, int n_P, Dims d, float dt, GridPtrs g) {
-  __shared__ float tile[3 * TILE_PAD];
-  int w = xcd_slice(blockIdx.x, n_chunks);
-  if (w < 0) return;
-  int slot = chunks[2 * w], chunk = chunks[2 * w + 1];
-  int blk = plist[slot];
-  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
-  int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
-  ChunkMap cm = chunk_map(ranges, n_P, slot);
-  int cls = 0, s = 0;
-  bool valid = cm.map(chunk * CHUNK + (int)threadIdx.x, cls, s);
-  // particle loads first: their latency overlaps the tile staging below
-  V3 x = v3(0, 0, 0), d3 = v3(0, 0, 0);
-  M3 F = m3_identity();
-  if (valid) {
-    x = ld3(b.all, A_X, s);
-    if (cls == 0) d3 = v3(b.el.at(E_D + 2, s), b.el.at(E_D + 5, s), b.el.at(E_D + 8, s));
-    if (cls == 1) F = ld9(b.tr, T_F, s - d.n_e);
-  }
-  for (int t = threadIdx.x; t < TILE3; t += TPB) {
-    int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
-    int gx = ox + ti, gy = oy + tj, gz = oz + tk;
-    V3 v = v3(0, 0, 0);
-    if (in_grid(gx, gy, gz, d.G)) {
-      const float *p = g.vout + ((size_t)blk_of(gx, gy, gz, d.NB) * GCH_VOUT) * 64 + loc_of(gx, gy, gz);
-      v = v3(p[0], p[64], p[128]);
+// same sums for a particle that drifted out of its tile margin: rolled loop over the global grid (zero outside
+// active blocks); kept small so that it does not set the kernel's register budget
+__device__ __forceinline__ G2PResult g2p_gather_global(V3 x, const Dims &d, const GridPtrs &g) {
+  Stencil s = make_stencil(x, d.inv_dx);
+  V3 nv = v3(0, 0, 0), Mx = v3(0, 0, 0), My = v3(0, 0, 0), Mz = v3(0, 0, 0);
+  V3 Fx = v3(0, 0, 0), Fy = v3(0, 0, 0), Fz = v3(0, 0, 0);
+#pragma unroll 1
+  for (int n = 0; n < 27; ++n) {
+    int i = n / 9, j = (n / 3) % 3, k = n % 3;
+    float wx = sel3(i, s.w0.x, s.w1.x, s.w2.x), wy = sel3(j, s.w0.y, s.w1.y, s.w2.y), wz = sel3(k, s.w0.z, s.w1.z, s.w2.z);
+    float dwx = sel3(i, s.dw0.x, s.dw1.x, s.dw2.x), dwy = sel3(j, s.dw0.y, s.dw1.y, s.dw2.y), dwz = sel3(k, s.dw0.z, s.dw1.z, s.dw2.z);
+    int x_ = s.bx + i, y_ = s.by + j, z_ = s.bz + k;
+    V3 u = v3(0, 0, 0);
+    if (in_grid(x_, y_, z_, d.G)) {
+      int blk = blk_of(x_, y_, z_, d.NB);
+      if (g.ab_flag[blk]) {
+        const float *p = g.vout + ((size_t)blk * GCH_VOUT) * 64 + loc_of(x_, y_, z_);
+        u = v3(p[0], p[64], p[128]);
+      }
     }
-    float *q = tile + tile_idx(ti, tj, tk);
-    q[0] = v.x; q[TILE_PAD] = v.y; q[2 * TILE_PAD] = v.z;
+    float w = wx * wy * wz;
+    nv = nv + w * u;
+    Mx = Mx + ((float)i * w) * u; My = My + ((float)j * w) * u; Mz = Mz + ((float)k * w) * u;
+    Fx = Fx + (dwx * wy * wz) * u; Fy = Fy + (wx * dwy * wz) * u; Fz = Fz + (wx * wy * dwz) * u;
   }
-  __syncthreads();
-  if (!valid) return;
-  G2PResult r = g2p_gather(tile, ox, oy, oz, x, d, g);
+  return g2p_finish(s, d, nv, Mx, My, Mz, Fx, Fy, Fz);
+}
+
+// particle update from the gathered values (g2p_v :765-786, first half of g2p_e :843-857)
+__device__ __forceinline__ void g2p_write(const Bufs &b, int cls, int s, V3 x, V3 d3, const G2PResult &r, int ox, int oy,
+                                          int oz, const Dims &d, float dt, const GridPtrs &g) {
   st9(b.all, A_C, s, r.C);
   if (cls == 0) {
     // elements: C now, d3 <- (I + dt grad v) d3 now; x, v, d1, d2 in k_elem_finalize once all vertices are updated
@@ -931,7 +918,68 @@ __global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const int *plist, const int
     int nbx = (int)(nx.x * d.inv_dx - 0.5f) - ox, nby = (int)(nx.y * d.inv_dx - 0.5f) - oy, nbz = (int)(nx.z * d.inv_dx - 0.5f) - oz;
     if ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u) g.counters[6] = 1;
   }
-  if (cls == 1) st9(b.tr, T_FT, s - d.n_e, (m3_identity() + dt * r.F) * F);
+  if (cls == 1) st9(b.tr, T_FT, s - d.n_e, (m3_identity() + dt * r.F) * ld9(b.tr, T_F, s - d.n_e));
+}
+
+__global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const int *plist, const int *ranges, const int *chunks,
+                                             int n_chunks, int n_P, Dims d, float dt, GridPtrs g) {
+  __shared__ float tile[3 * TILE_PAD];
+  int w = xcd_slice(blockIdx.x, n_chunks);
+  if (w < 0) return;
+  int slot = chunks[2 * w], chunk = chunks[2 * w + 1];
+  int blk = plist[slot];
+  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
+  int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
+  ChunkMap cm = chunk_map(ranges, n_P, slot);
+  int cls = 0, s = 0;
+  bool valid = cm.map(chunk * CHUNK + (int)threadIdx.x, cls, s);
+  // particle loads first: their latency overlaps the tile staging below
+  V3 x = v3(0, 0, 0), d3 = v3(0, 0, 0);
+  if (valid) {
+    x = ld3(b.all, A_X, s);
+    if (cls == 0) d3 = v3(b.el.at(E_D + 2, s), b.el.at(E_D + 5, s), b.el.at(E_D + 8, s));
+    int lx = (int)(x.x * d.inv_dx - 0.5f) - ox, ly = (int)(x.y * d.inv_dx - 0.5f) - oy, lz = (int)(x.z * d.inv_dx - 0.5f) - oz;
+    if ((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u) {
+      // drifted out of the tile margin: queued for k_g2p_escaped.  (Doing this here, before the gather, matters:
+      // an early exit after the gather made hipcc allocate 180 instead of 104 VGPRs for this kernel.)
+      g.esc_list[atomicAdd(g.counters + 7, 1)] = s;
+      valid = false;
+    }
+  }
+  for (int t = threadIdx.x; t < TILE3; t += TPB) {
+    int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
+    int gx = ox + ti, gy = oy + tj, gz = oz + tk;
+    V3 v = v3(0, 0, 0);
+    if (in_grid(gx, gy, gz, d.G)) {
+      const float *p = g.vout + ((size_t)blk_of(gx, gy, gz, d.NB) * GCH_VOUT) * 64 + loc_of(gx, gy, gz);
+      v = v3(p[0], p[64], p[128]);
+    }
+    float *q = tile + tile_idx(ti, tj, tk);
+    q[0] = v.x; q[TILE_PAD] = v.y; q[2 * TILE_PAD] = v.z;
+  }
+  __syncthreads();
+  if (!valid) return;
+  G2PResult r = g2p_gather(tile, ox, oy, oz, x, d);
+  g2p_write(b, cls, s, x, d3, r, ox, oy, oz, d, dt, g);
+}
+
+// the (rare) particles that left their tile margin since the last re-sort: one workgroup walks the queue
+__global__ __launch_bounds__(TPB) void k_g2p_escaped(Bufs b, const unsigned *skeys, int blk_bits, Dims d, float dt,
+                                                     GridPtrs g) {
+  int n = g.counters[7];
+  for (int q = threadIdx.x; q < n; q += TPB) {
+    int s = g.esc_list[q];
+    int cls = s < d.n_e ? 0 : (s < d.n_nv ? 1 : 2);
+    int blk = key_block(skeys[s], blk_bits);
+    int oz = 4 * (blk % d.NB) - 1, oy = 4 * ((blk / d.NB) % d.NB) - 1, ox = 4 * (blk / (d.NB * d.NB)) - 1;
+    V3 x = ld3(b.all, A_X, s), d3 = v3(0, 0, 0);
+    if (cls == 0) d3 = v3(b.el.at(E_D + 2, s), b.el.at(E_D + 5, s), b.el.at(E_D + 8, s));
+    G2PResult r = g2p_gather_global(x, d, g);
+    g2p_write(b, cls, s, x, d3, r, ox, oy, oz, d, dt, g);
+    atomicAdd(g.counters + 0, 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) g.counters[7] = 0;
 }
 
 // second half of g2p_e (mpm_utils.py:838-857): x, v = mean of the three updated vertices; d1, d2 = edges
@@ -1291,6 +1339,7 @@ int fast_init(mpmhip_ctx *c) {
   if ((rc = dalloc(c, &f->g.mv, f->nblocks * GCH_MV * 64))) return rc;
   if ((rc = dalloc(c, &f->g.vout, f->nblocks * GCH_VOUT * 64))) return rc;
   if ((rc = dalloc(c, &f->g.counters, 8))) return rc;
+  if ((rc = dalloc(c, &f->g.esc_list, (size_t)d.n_p))) return rc;
   if ((rc = dalloc(c, &f->pb_flag, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->pb_index, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->ab_flag, f->nblocks))) return rc;
@@ -1444,9 +1493,11 @@ int fast_step(mpmhip_ctx *c, const StepArgs &a) {
   }
   {
     ScopedPhase ph(c, "g2p_v");
-    if (f->n_chunks)
+    if (f->n_chunks) {
       hipLaunchKernelGGL(k_g2p, xcd_grid(f->n_chunks), TPB, 0, s, b, f->plist, f->ranges, f->chunks, f->n_chunks,
                          f->n_P, d, dt, f->g);
+      hipLaunchKernelGGL(k_g2p_escaped, 1, TPB, 0, s, b, f->keys[1], f->blk_bits, d, dt, f->g);
+    }
   }
   {
     ScopedPhase ph(c, "g2p_e");
