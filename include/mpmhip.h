@@ -182,6 +182,35 @@ int mpmhip_synchronize(mpmhip_ctx *ctx);
 double mpmhip_get_time(const mpmhip_ctx *ctx);
 int mpmhip_set_time(mpmhip_ctx *ctx, double t);
 
+/* ---- multi-GPU (one process and one context per GPU; not in the reference) --------------------
+ * Particles are sharded across ranks by the caller (mpmavatar_amd/dist.py: static spatial slabs); every rank runs
+ * its own context on its particles plus ghost copies (particle_selection == 2: stress yes, transfers no).  The
+ * substep is split in three so that the caller can run its two neighbour exchanges (RCCL send/recv through
+ * torch.distributed) between the phases:
+ *   begin: [stress, p2g] + pack halo_send      -> exchange halo   (sum of the grid blocks both ranks touch)
+ *   mid  : add halo_recv, [grid, g2p] + pack ghost_send -> exchange ghosts (x, v of vertices; d3 of elements)
+ *   end  : unpack ghost_recv, [element finalise]
+ * All ranks must re-sort at the same substep: mpmhip_dist_rebin() replaces the context's own re-sort policy. */
+typedef struct {
+  int32_t n_blocks;          /* grid blocks on both ranks' active lists */
+  const int32_t *blocks;     /* [dev] their ids in ascending order (identical on both ranks) */
+  float *halo_send, *halo_recv; /* [dev] n_blocks * CH * 64 floats; CH = 8 when a particle mover exists, else 4 */
+  int32_t n_send_p, n_recv_p, n_send_e, n_recv_e;
+  const int32_t *send_p, *recv_p; /* [dev] caller-order indices of vertices/traditional particles sent / received */
+  const int32_t *send_e, *recv_e; /* [dev] caller-order indices of elements whose d3 is sent / received */
+  float *ghost_send, *ghost_recv; /* [dev] 6*n_p + 3*n_e floats */
+} mpmhip_dist_peer;
+int mpmhip_dist_enable(mpmhip_ctx *ctx);
+int mpmhip_dist_num_blocks(const mpmhip_ctx *ctx); /* size of the active-block byte map */
+/* import the bound state if needed, re-sort, and write this rank's active-block map (1 byte per block) [dev] */
+int mpmhip_dist_rebin(mpmhip_ctx *ctx, uint8_t *active_map);
+int mpmhip_dist_set_peers(mpmhip_ctx *ctx, int32_t n_peers, const mpmhip_dist_peer *peers);
+int mpmhip_dist_step_begin(mpmhip_ctx *ctx, float dt, const float *mesh_x, const float *mesh_v, float mesh_advect,
+                           const float *joint_traditional_v, int32_t n_joint_t, const float *joint_verts_v,
+                           const float *joint_faces_v);
+int mpmhip_dist_step_mid(mpmhip_ctx *ctx);
+int mpmhip_dist_step_end(mpmhip_ctx *ctx);
+
 /* ---- introspection ---------------------------------------------------------------------- */
 /* dense reference-layout copies of grid_m [G^3], grid_v_in [G^3*3], grid_v_out [G^3*3] as they
  * stand after the last substep's grid stage ([dev] outputs, any may be NULL).  Synchronous. */

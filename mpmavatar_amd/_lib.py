@@ -56,6 +56,12 @@ class Stats(C.Structure):
                 ("n_fallback_particles", C.c_int32), ("reserved", C.c_int32)]
 
 
+class DistPeer(C.Structure):
+    _fields_ = [("n_blocks", C.c_int32), ("blocks", vp), ("halo_send", vp), ("halo_recv", vp),
+                ("n_send_p", C.c_int32), ("n_recv_p", C.c_int32), ("n_send_e", C.c_int32), ("n_recv_e", C.c_int32),
+                ("send_p", vp), ("recv_p", vp), ("send_e", vp), ("recv_e", vp), ("ghost_send", vp), ("ghost_recv", vp)]
+
+
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
 SIGNATURES = {
     "mpmhip_version": (C.c_int, []),
@@ -82,6 +88,13 @@ SIGNATURES = {
     "mpmhip_add_velocity_rotation": (C.c_int, [vp, f3, f3, f3, f3, C.c_float, C.c_float, vp, C.c_float, C.c_float]),
     "mpmhip_step": (C.c_int, [vp, C.c_float, vp, vp, vp, C.c_int32, vp, vp]),
     "mpmhip_steps": (C.c_int, [vp, C.c_float, C.c_int32, vp, vp, vp, C.c_int32, vp, vp]),
+    "mpmhip_dist_enable": (C.c_int, [vp]),
+    "mpmhip_dist_num_blocks": (C.c_int, [vp]),
+    "mpmhip_dist_rebin": (C.c_int, [vp, vp]),
+    "mpmhip_dist_set_peers": (C.c_int, [vp, C.c_int32, C.POINTER(DistPeer)]),
+    "mpmhip_dist_step_begin": (C.c_int, [vp, C.c_float, vp, vp, C.c_float, vp, C.c_int32, vp, vp]),
+    "mpmhip_dist_step_mid": (C.c_int, [vp]),
+    "mpmhip_dist_step_end": (C.c_int, [vp]),
     "mpmhip_synchronize": (C.c_int, [vp]),
     "mpmhip_get_time": (C.c_double, [vp]),
     "mpmhip_set_time": (C.c_int, [vp, C.c_double]),

@@ -379,6 +379,51 @@ int mpmhip_steps(mpmhip_ctx *c, float dt, int32_t n, const float *mesh_x, const 
   return MPMHIP_OK;
 }
 
+int mpmhip_dist_enable(mpmhip_ctx *c) {
+  CHECK_CTX(c);
+  if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
+  return fast_dist_enable(c);
+}
+int mpmhip_dist_num_blocks(const mpmhip_ctx *c) { return (c && c->fast) ? fast_dist_num_blocks(c) : 0; }
+int mpmhip_dist_rebin(mpmhip_ctx *c, uint8_t *active_map) {
+  CHECK_CTX(c);
+  if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
+  return fast_dist_rebin(c, active_map);
+}
+int mpmhip_dist_set_peers(mpmhip_ctx *c, int32_t n_peers, const mpmhip_dist_peer *peers) {
+  CHECK_CTX(c);
+  if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
+  return fast_dist_set_peers(c, n_peers, peers);
+}
+int mpmhip_dist_step_begin(mpmhip_ctx *c, float dt, const float *mesh_x, const float *mesh_v, float mesh_advect,
+                           const float *joint_traditional_v, int32_t n_joint_t, const float *joint_verts_v,
+                           const float *joint_faces_v) {
+  CHECK_CTX(c);
+  if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
+  if (!c->st_bound || !c->md_bound) return fail(c, MPMHIP_ERR_STATE, "step: state/model not bound");
+  if ((mesh_x || mesh_v) && !c->mesh_points) return fail(c, MPMHIP_ERR_STATE, "step: mesh_x/mesh_v given but no body mesh");
+  StepArgs a{dt, mesh_x, mesh_v, mesh_advect, true, joint_traditional_v, joint_traditional_v ? n_joint_t : 0, joint_verts_v, joint_faces_v};
+  c->cur_pts = a.mesh_x ? a.mesh_x : c->mesh_points;
+  c->cur_vel = a.mesh_v ? a.mesh_v : c->mesh_vel;
+  c->cur_f = (a.mesh_x && a.mesh_v) ? a.mesh_f : 0.0f;
+  c->fast_dt = dt;
+  return fast_dist_phase(c, 0, a);
+}
+int mpmhip_dist_step_mid(mpmhip_ctx *c) {
+  CHECK_CTX(c);
+  StepArgs a{};
+  return fast_dist_phase(c, 1, a);
+}
+int mpmhip_dist_step_end(mpmhip_ctx *c) {
+  CHECK_CTX(c);
+  StepArgs a{};
+  int rc = fast_dist_phase(c, 2, a);
+  if (rc) return rc;
+  c->time = c->time + (double)c->fast_dt;
+  c->substeps += 1;
+  return MPMHIP_OK;
+}
+
 int mpmhip_synchronize(mpmhip_ctx *c) {
   CHECK_CTX(c);
   MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));

@@ -92,6 +92,7 @@ struct mpmhip_ctx {
   std::vector<mpm::PreOp> pre;
 
   double time = 0.0;
+  float fast_dt = 0.f;  // dt of the substep in flight (dist phases)
   int64_t substeps = 0;
   std::string err;
 
@@ -158,6 +159,12 @@ int fast_export_grid(mpmhip_ctx *ctx, float *m, float *v_in, float *v_out);
 int fast_stats(mpmhip_ctx *ctx, mpmhip_stats *out);
 int fast_add_collider_storage(mpmhip_ctx *ctx, MeshCollider &mc);
 int fast_add_mover_storage(mpmhip_ctx *ctx, Mover &mv);
+
+int fast_dist_enable(mpmhip_ctx *ctx);
+int fast_dist_num_blocks(const mpmhip_ctx *ctx);
+int fast_dist_rebin(mpmhip_ctx *ctx, unsigned char *active_map);
+int fast_dist_set_peers(mpmhip_ctx *ctx, int n, const mpmhip_dist_peer *peers);
+int fast_dist_phase(mpmhip_ctx *ctx, int phase, const StepArgs &a);
 
 // shared small kernels (common.hip)
 int launch_pre_ops(mpmhip_ctx *ctx, float dt, float *v, const float *x, const float *mass, int n);

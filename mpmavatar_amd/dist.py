@@ -1,0 +1,262 @@
+"""Multi-GPU substeps: one process and one libmpmhip context per GPU (not in the reference,
+which is single-GPU).
+
+Decomposition
+  * static ownership: vertices and traditional particles are assigned to ranks by the quantile slab of their
+    initial x coordinate, an element to the owner of its first vertex.  Ownership never migrates, so the ghost
+    lists below are built once (cloth keeps its neighbourhood; spatial overlap of ranks only widens the halo).
+  * ghosts: a rank also holds (a) every element that touches one of its vertices (so vertex forces are complete
+    without an exchange) and (b) every vertex of its local elements.  Ghost copies carry particle_selection == 2:
+    stress / element finalise run on them, p2g / g2p do not.
+  * per substep two neighbour exchanges, RCCL send/recv through torch.distributed on the solver's stream:
+      1. after p2g : the (m, momentum[, mover]) channels of the grid blocks that both ranks have on their active
+         lists are summed (both then run the identical grid update there, so g2p needs no second exchange);
+      2. after g2p : owners send x, v of their boundary vertices and d3 of their boundary elements to the ghosts.
+    The body-face splat is replicated (each rank splats the faces that touch its active blocks).
+  * all ranks re-sort at the same substep (every ``rebin_interval`` substeps); the shared-block lists are rebuilt
+    there from an all_gather of the per-rank active-block maps.
+Backend "nccl" (= RCCL) exchanges device buffers; "gloo" stages through host memory and exists so that the whole
+path can be exercised with two processes on one GPU (tests/test_gpu_dist.py) and on CPU-only CI (partition logic).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field, replace
+from typing import Dict, List
+
+import numpy as np
+
+from .scenes import Scene
+
+
+@dataclass
+class Shard:
+    rank: int
+    world: int
+    scene: Scene                      # local scene: owned + ghost particles, joint entries first
+    own_e: np.ndarray                 # global element ids owned (ascending)
+    ghost_e: np.ndarray               # global element ids held as ghosts
+    own_t: np.ndarray
+    own_v: np.ndarray
+    ghost_v: np.ndarray
+    send_p: Dict[int, np.ndarray] = field(default_factory=dict)   # peer -> local particle indices (vertices) to send
+    recv_p: Dict[int, np.ndarray] = field(default_factory=dict)
+    send_e: Dict[int, np.ndarray] = field(default_factory=dict)   # peer -> local element indices whose d3 is sent
+    recv_e: Dict[int, np.ndarray] = field(default_factory=dict)
+    send_p_gid: Dict[int, np.ndarray] = field(default_factory=dict)  # the same lists as global ids (tests)
+    recv_p_gid: Dict[int, np.ndarray] = field(default_factory=dict)
+
+
+def _owners(sc: Scene, world: int):
+    n_e, n_t = sc.n_elements, sc.n_traditional
+    xt, xv = sc.x[n_e:n_e + n_t, 0], sc.x[n_e + n_t:, 0]
+    px = np.concatenate([xv, xt]).astype(np.float64)
+    cuts = np.quantile(px, np.arange(1, world) / world) if world > 1 and px.size else np.zeros(0)
+    owner_v = np.searchsorted(cuts, xv, side="right").astype(np.int32)
+    owner_t = np.searchsorted(cuts, xt, side="right").astype(np.int32)
+    owner_e = owner_v[sc.faces[:, 0]] if n_e else np.zeros(0, np.int32)
+    return owner_e, owner_t, owner_v
+
+
+def partition(sc: Scene, world: int) -> List[Shard]:
+    """Deterministic: every rank computes the full partition from the same Scene, no communication."""
+    n_e, n_t, n_v = sc.n_elements, sc.n_traditional, sc.n_vertices
+    owner_e, owner_t, owner_v = _owners(sc, world)
+    faces = sc.faces.astype(np.int64)
+    shards = []
+    for r in range(world):
+        own_e = np.nonzero(owner_e == r)[0]
+        touches = (owner_v[faces] == r).any(1) if n_e else np.zeros(0, bool)
+        ghost_e = np.nonzero(touches & (owner_e != r))[0]
+        el = np.concatenate([own_e, ghost_e])
+        own_v = np.nonzero(owner_v == r)[0]
+        need_v = np.unique(faces[el].reshape(-1)) if el.size else np.zeros(0, np.int64)
+        ghost_v = need_v[owner_v[need_v] != r]
+        vl = np.concatenate([own_v, ghost_v])
+        own_t = np.nonzero(owner_t == r)[0]
+        g2l = np.full(n_v, -1, np.int64)
+        g2l[vl] = np.arange(vl.size)
+        f_loc = g2l[faces[el]].astype(np.int32) if el.size else np.zeros((0, 3), np.int32)
+        assert (f_loc >= 0).all()
+        x = np.concatenate([sc.x[el], sc.x[n_e + own_t], sc.x[n_e + n_t + vl]], 0)
+        v = np.concatenate([sc.v[el], sc.v[n_e + own_t], sc.v[n_e + n_t + vl]], 0)
+        vol = np.concatenate([sc.vol[el], sc.vol[n_e + own_t], sc.vol[n_e + n_t + vl]], 0)
+        sel = np.zeros(x.shape[0], np.int32)
+        sel[own_e.size:el.size] = 2
+        sel[el.size + own_t.size + own_v.size:] = 2
+        njv = int((own_v < sc.num_joint_v).sum())
+        njf = int((own_e < sc.num_joint_f).sum())
+        jv = None if sc.joint_verts_v is None else sc.joint_verts_v[own_v[:njv]]
+        jf = None if sc.joint_faces_v is None else sc.joint_faces_v[own_e[:njf]]
+        local = replace(sc, name=f"{sc.name}[{r}/{world}]", n_elements=int(el.size), n_traditional=int(own_t.size),
+                        n_vertices=int(vl.size), x=np.ascontiguousarray(x, np.float32), v=np.ascontiguousarray(v, np.float32),
+                        vol=np.ascontiguousarray(vol, np.float32), faces=f_loc, d=sc.d[el], R_inv=sc.R_inv[el],
+                        num_joint_v=njv, num_joint_f=njf, joint_verts_v=jv, joint_faces_v=jf, selection=sel)
+        shards.append(Shard(r, world, local, own_e, ghost_e, own_t, own_v, ghost_v))
+    # ghost exchange lists, ordered by global id on both sides
+    for r, sh in enumerate(shards):
+        off_v = sh.scene.n_elements + sh.scene.n_traditional
+        lv = {g: i for i, g in enumerate(np.concatenate([sh.own_v, sh.ghost_v]))}
+        le = {g: i for i, g in enumerate(np.concatenate([sh.own_e, sh.ghost_e]))}
+        for q, other in enumerate(shards):
+            if q == r:
+                continue
+            sv = np.intersect1d(other.ghost_v, sh.own_v)           # I own, q holds as ghost
+            rv = np.intersect1d(sh.ghost_v, other.own_v)           # q owns, I hold as ghost
+            se = np.intersect1d(other.ghost_e, sh.own_e)
+            re_ = np.intersect1d(sh.ghost_e, other.own_e)
+            if sv.size + rv.size + se.size + re_.size == 0:
+                continue
+            sh.send_p[q] = np.array([off_v + lv[g] for g in sv], np.int32)
+            sh.recv_p[q] = np.array([off_v + lv[g] for g in rv], np.int32)
+            sh.send_e[q] = np.array([le[g] for g in se], np.int32)
+            sh.recv_e[q] = np.array([le[g] for g in re_], np.int32)
+            sh.send_p_gid[q], sh.recv_p_gid[q] = sv, rv
+    return shards
+
+
+# --------------------------------------------------------------------------------------------- runtime
+@dataclass
+class ShardedSim:
+    shard: Shard
+    sim: object                        # harness.Sim of the local scene
+    backend: str
+    rebin_interval: int
+    steps_done: int = 0
+    peers: list = field(default_factory=list)
+    keep: list = field(default_factory=list)
+    static: dict = field(default_factory=dict)
+
+
+def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int = 0) -> ShardedSim:
+    import torch
+    import torch.distributed as dist
+    from . import harness
+    from . import _lib as L
+    shard = partition(sc, world)[rank]
+    sim = harness.build_solver(shard.scene, device, mode="fast")
+    sv = sim.solver
+    sv._bind(sim.model, sim.state)
+    sv._call("mpmhip_dist_enable")
+    ss = ShardedSim(shard, sim, dist.get_backend(), rebin_interval or 32)
+    dev = torch.device(device)
+    i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.int32), device=dev)
+    for q in sorted(set(shard.send_p) | set(shard.recv_p)):
+        ss.static[q] = dict(send_p=i32(shard.send_p[q]), recv_p=i32(shard.recv_p[q]), send_e=i32(shard.send_e[q]),
+                            recv_e=i32(shard.recv_e[q]))
+        n_s = 6 * len(shard.send_p[q]) + 3 * len(shard.send_e[q])
+        n_r = 6 * len(shard.recv_p[q]) + 3 * len(shard.recv_e[q])
+        ss.static[q]["gs"] = torch.zeros(max(n_s, 1), dtype=torch.float32, device=dev)
+        ss.static[q]["gr"] = torch.zeros(max(n_r, 1), dtype=torch.float32, device=dev)
+    nb = sv._lib.mpmhip_dist_num_blocks(sv._ctx)
+    ss.static["map"] = torch.zeros(nb, dtype=torch.uint8, device=dev)
+    return ss
+
+
+def _all_gather_maps(ss: ShardedSim):
+    import torch
+    import torch.distributed as dist
+    m = ss.static["map"]
+    world = ss.shard.world
+    if ss.backend == "gloo":
+        mc = m.cpu()
+        outs = [torch.zeros_like(mc) for _ in range(world)]
+        dist.all_gather(outs, mc)
+        return [o.to(m.device) for o in outs]
+    outs = [torch.zeros_like(m) for _ in range(world)]
+    dist.all_gather(outs, m)
+    return outs
+
+
+def rebin_all(ss: ShardedSim):
+    """Collective: every rank re-sorts and rebuilds the shared-block lists with each peer."""
+    import torch
+    from . import _lib as L
+    sv = ss.sim.solver
+    sv._call("mpmhip_dist_rebin", ss.static["map"].data_ptr())
+    maps = _all_gather_maps(ss)
+    mine = maps[ss.shard.rank]
+    ch = 8 if sv.particle_movers else 4
+    peers, keep = [], []
+    arr = []
+    for q in range(ss.shard.world):
+        if q == ss.shard.rank:
+            continue
+        blocks = torch.nonzero(mine & maps[q]).reshape(-1).to(torch.int32)
+        st = ss.static.get(q)
+        if blocks.numel() == 0 and st is None:
+            continue
+        nb = int(blocks.numel())
+        hs = torch.zeros(max(nb * ch * 64, 1), dtype=torch.float32, device=mine.device)
+        hr = torch.zeros_like(hs)
+        keep += [blocks, hs, hr]
+        p = L.DistPeer()
+        p.n_blocks, p.blocks, p.halo_send, p.halo_recv = nb, blocks.data_ptr() if nb else None, hs.data_ptr(), hr.data_ptr()
+        if st is not None:
+            p.n_send_p, p.n_recv_p = st["send_p"].numel(), st["recv_p"].numel()
+            p.n_send_e, p.n_recv_e = st["send_e"].numel(), st["recv_e"].numel()
+            p.send_p, p.recv_p = st["send_p"].data_ptr(), st["recv_p"].data_ptr()
+            p.send_e, p.recv_e = st["send_e"].data_ptr(), st["recv_e"].data_ptr()
+            p.ghost_send, p.ghost_recv = st["gs"].data_ptr(), st["gr"].data_ptr()
+        arr.append(p)
+        peers.append(dict(rank=q, hs=hs, hr=hr, n_halo=nb * ch * 64,
+                          gs=None if st is None else st["gs"], gr=None if st is None else st["gr"],
+                          n_gs=0 if st is None else 6 * st["send_p"].numel() + 3 * st["send_e"].numel(),
+                          n_gr=0 if st is None else 6 * st["recv_p"].numel() + 3 * st["recv_e"].numel()))
+    carr = (L.DistPeer * max(len(arr), 1))(*arr)
+    sv._call("mpmhip_dist_set_peers", len(arr), carr)
+    ss.peers, ss.keep = peers, keep
+
+
+def _exchange(ss: ShardedSim, kind: str):
+    import torch
+    import torch.distributed as dist
+    ops, post = [], []
+    for p in ss.peers:
+        sbuf, rbuf, ns, nr = (p["hs"], p["hr"], p["n_halo"], p["n_halo"]) if kind == "halo" else (p["gs"], p["gr"], p["n_gs"], p["n_gr"])
+        if ss.backend == "gloo":
+            if ns:
+                ops.append(dist.P2POp(dist.isend, sbuf[:ns].cpu(), p["rank"]))
+            if nr:
+                tmp = torch.empty(nr, dtype=torch.float32)
+                ops.append(dist.P2POp(dist.irecv, tmp, p["rank"]))
+                post.append((rbuf, tmp, nr))
+        else:
+            if ns:
+                ops.append(dist.P2POp(dist.isend, sbuf[:ns], p["rank"]))
+            if nr:
+                ops.append(dist.P2POp(dist.irecv, rbuf[:nr], p["rank"]))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for rbuf, tmp, nr in post:
+        rbuf[:nr].copy_(tmp)
+
+
+def run(ss: ShardedSim, n_steps: int):
+    """Advance n substeps on every rank (collective)."""
+    sim, sv, sc = ss.sim, ss.sim.solver, ss.sim.scene
+    dp = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
+    jv, jf = sim.joint_verts_v, sim.joint_faces_v
+    dummy = sv._dummy_ptr()
+    for _ in range(n_steps):
+        if ss.steps_done % ss.rebin_interval == 0:
+            rebin_all(ss)
+        adv = float(np.float32(sc.dt * ss.steps_done))
+        jvp = None if jv is None else (dp(jv) or dummy)
+        jfp = None if jf is None else (dp(jf) or dummy)
+        sv._call("mpmhip_dist_step_begin", float(sc.dt), dp(sim.mesh_x0), dp(sim.mesh_v), adv, None, 0, jvp, jfp)
+        _exchange(ss, "halo")
+        sv._call("mpmhip_dist_step_mid")
+        _exchange(ss, "ghost")
+        sv._call("mpmhip_dist_step_end")
+        ss.steps_done += 1
+
+
+def gather_positions(ss: ShardedSim):
+    """Owned particle positions with their global ids (for tests): (elements, traditional, vertices)."""
+    st, sh, sc = ss.sim.state, ss.shard, ss.sim.scene
+    x = st.particle_x.detach().cpu().numpy()
+    ne, nt = sc.n_elements, sc.n_traditional
+    return dict(e_id=sh.own_e, e_x=x[:sh.own_e.size], t_id=sh.own_t, t_x=x[ne:ne + sh.own_t.size],
+                v_id=sh.own_v, v_x=x[ne + nt:ne + nt + sh.own_v.size])

@@ -40,6 +40,8 @@ def build_solver(sc: Scene, device="cuda:0", mode=None, rebin_interval=0) -> Sim
     state.from_torch(t(sc.x), t(sc.vol), t(D_inv), t(sc.R_inv), t(sc.faces.astype(np.float32)), flags[0], flags[1],
                      flags[2], torch.zeros((n_p - n_v, 6)), device=dev, requires_grad=True, n_grid=sc.n_grid,
                      grid_lim=sc.grid_lim)
+    if sc.selection is not None:
+        state.particle_selection = t(sc.selection, torch.int32)
     model = MPMModelStruct()
     model.init(n_p, device=dev, requires_grad=True)
     model.init_other_params(n_grid=sc.n_grid, grid_lim=sc.grid_lim, device=dev)
