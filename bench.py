@@ -87,6 +87,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    if os.environ.get("MPMHIP_DIST_BACKEND") == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()  # ranks may share a GPU in the gloo test mode
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
 
@@ -94,7 +96,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         from mpmavatar_amd import dist as mdist
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        backend = os.environ.get("MPMHIP_DIST_BACKEND", "nccl")  # "gloo": host-staged exchange (2 ranks on 1 GPU tests)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
         sim = mdist.build_sharded(sc, dev, rank, world, rebin_interval=args.rebin_interval)
         run = lambda n: mdist.run(sim, n)
         barrier = lambda: dist.barrier()

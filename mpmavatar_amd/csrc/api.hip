@@ -407,7 +407,14 @@ int mpmhip_dist_step_begin(mpmhip_ctx *c, float dt, const float *mesh_x, const f
   c->cur_vel = a.mesh_v ? a.mesh_v : c->mesh_vel;
   c->cur_f = (a.mesh_x && a.mesh_v) ? a.mesh_f : 0.0f;
   c->fast_dt = dt;
-  return fast_dist_phase(c, 0, a);
+  int rc = fast_dist_phase(c, 0, a);
+  if (rc) return rc;
+  if (a.mesh_x || a.mesh_v) {  // keep the context's wp.Mesh copy current (used by the next collective re-sort)
+    size_t nm = (size_t)c->num_mesh_v * 3;
+    hipLaunchKernelGGL(k_mesh_store, (unsigned)((nm + 255) / 256), 256, 0, c->stream, c->mesh_points, c->mesh_vel,
+                       a.mesh_x, a.mesh_v, c->cur_f, nm);
+  }
+  return MPMHIP_OK;
 }
 int mpmhip_dist_step_mid(mpmhip_ctx *c) {
   CHECK_CTX(c);

@@ -1635,6 +1635,10 @@ int fast_dist_rebin(mpmhip_ctx *c, unsigned char *active_map) {
   int rc;
   if (!c->st_bound || !c->md_bound) return fail(c, MPMHIP_ERR_STATE, "dist_rebin: state/model not bound");
   if (c->caller_dirty && (rc = do_import(c))) return rc;
+  // between substeps the caller's mesh tensors may be gone: bin the body faces from the context's own copy
+  c->cur_pts = c->mesh_points;
+  c->cur_vel = c->mesh_vel;
+  c->cur_f = 0.0f;
   if ((rc = rebin(c))) return rc;
   if (active_map)
     hipLaunchKernelGGL(k_flags_to_bytes, nblk(f->nblocks), TPB, 0, c->stream, f->ab_flag, (int)f->nblocks, active_map);

@@ -91,7 +91,8 @@ def partition(sc: Scene, world: int) -> List[Shard]:
         local = replace(sc, name=f"{sc.name}[{r}/{world}]", n_elements=int(el.size), n_traditional=int(own_t.size),
                         n_vertices=int(vl.size), x=np.ascontiguousarray(x, np.float32), v=np.ascontiguousarray(v, np.float32),
                         vol=np.ascontiguousarray(vol, np.float32), faces=f_loc, d=sc.d[el], R_inv=sc.R_inv[el],
-                        num_joint_v=njv, num_joint_f=njf, joint_verts_v=jv, joint_faces_v=jf, selection=sel)
+                        num_joint_v=njv, num_joint_f=njf, joint_verts_v=jv, joint_faces_v=jf, selection=sel,
+                        has_mover=(sc.num_joint_v > 0 or sc.num_joint_f > 0) if sc.has_mover is None else sc.has_mover)
         shards.append(Shard(r, world, local, own_e, ghost_e, own_t, own_v, ghost_v))
     # ghost exchange lists, ordered by global id on both sides
     for r, sh in enumerate(shards):

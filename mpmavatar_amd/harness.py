@@ -57,7 +57,7 @@ def build_solver(sc: Scene, device="cuda:0", mode=None, rebin_interval=0) -> Sim
     solver.prepare_mu_lam(model, state, dev)
     if sc.mesh_vertices is not None:
         solver.add_mesh_collider(solver.mesh.id, n_grid=model.n_grid, friction=sc.mesh_friction)
-    if sc.num_joint_v > 0 or sc.num_joint_f > 0:
+    if (sc.num_joint_v > 0 or sc.num_joint_f > 0) if sc.has_mover is None else sc.has_mover:
         solver.add_particle_mover(n_grid=model.n_grid)
     for kind, kw in sc.bcs:
         {"bounding_box": solver.add_bounding_box, "surface_collider": solver.add_surface_collider,

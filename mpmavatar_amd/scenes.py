@@ -47,6 +47,7 @@ class Scene:
     bcs: list = field(default_factory=list)      # [("bounding_box", {}), ("surface_collider", {...})]
     dt: float = 1e-4
     n_steps: int = 100
+    has_mover: Optional[bool] = None             # None: a particle mover is registered iff the scene has joints
     selection: Optional[np.ndarray] = None       # particle_selection (0 simulate, 1 frozen, 2 ghost copy); None = all 0
 
     @property
