@@ -1,0 +1,183 @@
+"""GPU tests of the warp_mpm-compatible API surface (MPMWARP / MPMStateStruct / MPMModelStruct) through the C ABI:
+state rebinding and read-back semantics, pre-p2g particle operations, grid boundary conditions, profiling keys, and
+size-independent properties at the BASELINE.json headline size (fast vs baseline kernels, free fall, conservation)."""
+import numpy as np
+import pytest
+import torch
+
+from mpmavatar_amd import harness, scenes
+
+pytestmark = pytest.mark.gpu
+MODES = ["fast", "baseline"]
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-3))
+
+
+def _oracle(sc):
+    from oracle.scene_adapter import oracle_from_scene
+    return oracle_from_scene(sc)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_read_modify_continue(mode, oracle_lib):
+    """Reading a state field syncs it back; in-place edits by the caller are picked up by the next substep."""
+    from oracle.scene_adapter import run_scene
+    sc = scenes.small_garment()
+    o = _oracle(sc)
+    sim = harness.build_solver(sc, "cuda:0", mode=mode)
+    harness.run(sim, 10, fused=True)
+    run_scene(o, sc, 10)
+    x = sim.state.particle_x                      # triggers the pull
+    assert rel(x.cpu().numpy(), o.x) < 1e-5
+    sim.state.particle_v.mul_(0.5)                # caller edits the tensor in place
+    o.v *= 0.5
+    for k in range(10, 20):
+        kw = dict(mesh_x=(sc.mesh_vertices + np.float32(sc.dt * k) * sc.mesh_v).astype(np.float32), mesh_v=sc.mesh_v,
+                  joint_verts_v=sc.joint_verts_v, joint_faces_v=sc.joint_faces_v)
+        o.p2g2p(sc.dt, **kw)
+    harness.run(sim, 10, fused=False)
+    assert rel(sim.state.particle_x.cpu().numpy(), o.x) < 1e-5
+    assert rel(sim.state.particle_v.cpu().numpy(), o.v) < 2e-2
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_reset_state_gives_a_fresh_run(mode):
+    sc = scenes.small_sheet()
+    a = harness.build_solver(sc, "cuda:0", mode=mode)
+    harness.run(a, 30, fused=True)
+    dev = a.state.device
+    t = lambda arr: torch.as_tensor(arr, dtype=torch.float32, device=dev)
+    t_before = a.solver.time
+    a.state.reset_state(sc.n_vertices, t(sc.x).clone(), t(sc.d).clone(), None, t(sc.v).clone(), tensor_R_inv=t(sc.R_inv).clone(), device=dev)
+    a.steps_done = 0
+    harness.run(a, 30, fused=True)
+    assert a.solver.time == pytest.approx(t_before * 2, rel=1e-6)      # quirk Q3: time is never reset
+    b = harness.build_solver(sc, "cuda:0", mode=mode)
+    harness.run(b, 30, fused=True)
+    assert rel(a.state.particle_x.cpu().numpy(), b.state.particle_x.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_continue_from_torch(mode):
+    sc = scenes.small_cube()
+    a = harness.build_solver(sc, "cuda:0", mode=mode)
+    harness.run(a, 20, fused=True)
+    x, v, C = (getattr(a.state, n).clone() for n in ("particle_x", "particle_v", "particle_C"))
+    harness.run(a, 20, fused=True)
+    xa = a.state.particle_x.cpu().numpy()
+    b = harness.build_solver(sc, "cuda:0", mode=mode)
+    harness.run(b, 20, fused=True)
+    b.state.continue_from_torch(x, tensor_velocity=v, tensor_C=C, device=b.state.device)   # same x, v, C; F kept by b
+    harness.run(b, 20, fused=True)
+    assert rel(b.state.particle_x.cpu().numpy(), xa) < 1e-6
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_pre_p2g_operations_and_grid_bcs(mode, oracle_lib):
+    sc = scenes.small_cube(n=6)
+    sc.bcs = []
+    o = _oracle(sc)
+    sim = harness.build_solver(sc, "cuda:0", mode=mode)
+    sv, st = sim.solver, sim.state
+    c = sc.x.mean(0).tolist()
+    mask = (np.arange(sc.n_particles) % 3 == 0).astype(np.int32)
+    # impulse in a box, velocity clamp in a box, cylinder rotation, velocity by mask; moving cuboid BC + bounding box
+    sv.add_impulse_on_particles(st, [0.0, 2e-6, 0.0], sc.dt, point=c, size=[0.05, 0.05, 0.05], num_dt=5)
+    o.add_impulse_on_particles([0.0, 2e-6, 0.0], sc.dt, point=c, size=[0.05, 0.05, 0.05], num_dt=5)
+    sv.enforce_particle_velocity_translation(st, [c[0] + 0.08, c[1], c[2]], [0.03, 1.0, 1.0], [0.0, 0.1, 0.0], 0.0, 4 * sc.dt)
+    o.enforce_particle_velocity_translation([c[0] + 0.08, c[1], c[2]], [0.03, 1.0, 1.0], [0.0, 0.1, 0.0], 0.0, 4 * sc.dt)
+    sv.enforce_particle_velocity_by_mask(st, torch.as_tensor(mask), [0.05, 0.0, 0.0], 6 * sc.dt, 9 * sc.dt)
+    o.enforce_particle_velocity_by_mask(mask, [0.05, 0.0, 0.0], 6 * sc.dt, 9 * sc.dt)
+    sv.set_velocity_on_cuboid([c[0], c[1] - 0.12, c[2]], [0.5, 0.04, 0.5], [0.0, 0.2, 0.0], start_time=0.0, end_time=999.0)
+    o.set_velocity_on_cuboid([c[0], c[1] - 0.12, c[2]], [0.5, 0.04, 0.5], [0.0, 0.2, 0.0], start_time=0.0, end_time=999.0)
+    sv.add_bounding_box()
+    o.add_bounding_box()
+    for _ in range(15):
+        sv.p2g2p(sim.model, st, sc.dt)
+        o.p2g2p(sc.dt)
+    assert rel(st.particle_x.cpu().numpy(), o.x) < 1e-5
+    assert rel(st.particle_v.cpu().numpy(), o.v) < 1e-4
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_rotation_modifier_and_surface_collider(mode, oracle_lib):
+    from oracle import oracle as O
+    sc = scenes.small_cube(n=5)
+    sc.bcs = []
+    o = _oracle(sc)
+    sim = harness.build_solver(sc, "cuda:0", mode=mode)
+    sv, st = sim.solver, sim.state
+    c = sc.x.mean(0)
+    sv.enforce_particle_velocity_rotation(st, c.tolist(), [0.0, 1.0, 0.0], [0.05, 0.2], 1.5, 0.1, 0.0, 5 * sc.dt)
+    # oracle side: same mask / axes as the shim computes (mpm_solver.py:1168-1211)
+    nrm = np.array([0.0, 1.0, 0.0]); h1 = np.array([1.0, 1.0, 1.0]); h1 = h1 - (h1 @ nrm) * nrm; h1 /= np.linalg.norm(h1); h2 = np.cross(h1, nrm)
+    off = o.x - c
+    mask = ((np.abs(off @ nrm) < 0.05) & (np.linalg.norm(off - np.outer(off @ nrm, nrm), axis=1) < 0.2)).astype(np.int32)
+    op = o._new_pre(O.PRE_VEL_ROTATE, mask, 0.0, 5 * sc.dt)
+    op.point, op.normal, op.axis1, op.axis2 = O.f3(*c), O.f3(*nrm), O.f3(*h1), O.f3(*h2)
+    op.rotation_scale, op.translation_scale = 1.5, 0.1
+    sv.add_surface_collider([0.0, float(c[1]) - 0.05, 0.0], [0.0, 1.0, 0.0])
+    o.add_surface_collider([0.0, float(c[1]) - 0.05, 0.0], [0.0, 1.0, 0.0])
+    for _ in range(12):
+        sv.p2g2p(sim.model, st, sc.dt)
+        o.p2g2p(sc.dt)
+    assert rel(st.particle_x.cpu().numpy(), o.x) < 1e-5
+    assert rel(st.particle_v.cpu().numpy(), o.v) < 1e-4
+    with pytest.raises(ValueError):
+        sv.add_surface_collider([0, 0, 0], [0, 1, 0], surface="sticky", friction=0.2)
+    with pytest.raises(TypeError):
+        sv.set_parameters_dict(sim.model, st, {"material": "unobtainium"})
+
+
+def test_profile_keys_match_reference():
+    sc = scenes.small_garment()
+    sim = harness.build_solver(sc, "cuda:0", mode="baseline")
+    sim.solver.enable_profiling(True)
+    harness.run(sim, 3)
+    keys = set(sim.solver.time_profile)
+    # ScopedTimer names of mpm_solver.py:288-534
+    assert {"compute_stress_from_F_trial", "p2g", "grid_update", "apply_Mesh_Collision_on_grid",
+            "apply_Particle_Moving_on_grid", "g2p_v", "g2p_e"} <= keys
+
+
+# ---------------------------------------------------------------- headline size (sheet-500k, 256^3)
+@pytest.fixture(scope="module")
+def big_pair():
+    sc = scenes.sheet()
+    a = harness.build_solver(sc, "cuda:0", mode="fast")
+    b = harness.build_solver(sc, "cuda:0", mode="baseline")
+    harness.run(a, 100, fused=True)
+    harness.run(b, 100, fused=True)
+    return sc, a, b
+
+
+def test_headline_size_fast_equals_baseline(big_pair):
+    sc, a, b = big_pair
+    xa, xb = a.state.particle_x.cpu().numpy(), b.state.particle_x.cpu().numpy()
+    assert np.isfinite(xa).all() and rel(xa, xb) < 1e-5
+    assert rel(a.state.particle_v.cpu().numpy(), b.state.particle_v.cpu().numpy()) < 2e-2
+    st = a.solver.stats()
+    assert st["rebins"] >= 1
+
+
+def test_headline_size_free_fall_away_from_the_collider(big_pair):
+    sc, a, _ = big_pair
+    ne = sc.n_elements
+    x0 = sc.x[ne:]
+    far = np.hypot(x0[:, 0] - 1.0, x0[:, 2] - 1.0) > 0.5          # vertices well outside the sphere's footprint
+    v = a.state.particle_v.cpu().numpy()[ne:][far]
+    x = a.state.particle_x.cpu().numpy()[ne:][far]
+    n, dt, g = 100, np.float32(sc.dt), 9.8
+    assert np.allclose(v[:, 1], -g * dt * n, rtol=5e-3)
+    assert np.allclose(x[:, 1] - x0[far][:, 1], -g * dt * dt * n * (n + 1) / 2, atol=2e-6)
+    assert np.abs(v[:, [0, 2]]).max() < 5e-3
+
+
+def test_headline_size_grid_mass_is_conserved(big_pair):
+    sc, a, _ = big_pair
+    m, _, _ = a.solver.export_grid()
+    total = float(a.state.particle_mass.double().sum())
+    assert float(m.double().sum()) == pytest.approx(total, rel=1e-5)
