@@ -276,14 +276,41 @@ __global__ void k_dilate(const int *plist, int n_P, int NB, int *ab_flag) {
 // ------------------------------------------------------------------------------------------------
 // stress (compute_stress_from_F_trial, mpm_utils.py:1017-1105) on the sorted SoA state
 // ------------------------------------------------------------------------------------------------
-__global__ void k_stress_elem(Bufs b, float *ef, Dims d, float friction_coeff) {
+// FINALIZE = true fuses the tail of the previous substep's g2p_e (x, v = mean of the three updated vertices,
+// d1, d2 = edges; mpm_utils.py:838-857) into this substep's stress kernel: one launch and one round trip of the
+// director matrix less per substep.  The host runs the stand-alone k_elem_finalize instead whenever something needs
+// finished elements earlier (re-sort, read-back, pre-p2g operations, joint-face splats, multi-GPU ghosts).
+template <bool FINALIZE>
+__global__ void k_stress_elem(Bufs b, float *ef, Dims d, float friction_coeff, const int *face_slot,
+                              const unsigned *skeys, int blk_bits, int *counters) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.n_e) return;
   if (b.sel[e] == 1) {  // not simulated (selection == 2 marks a ghost copy: stress yes, transfers no)
     for (int c = 0; c < 6; ++c) ef[c * d.n_e + e] = 0.0f;
     return;
   }
-  M3 dm = ld9(b.el, E_D, e);
+  M3 dm;
+  if (FINALIZE) {
+    int v1 = d.n_nv + face_slot[e], v2 = d.n_nv + face_slot[d.n_e + e], v3i = d.n_nv + face_slot[2 * d.n_e + e];
+    V3 x1 = ld3(b.all, A_X, v1), x2 = ld3(b.all, A_X, v2), x3 = ld3(b.all, A_X, v3i);
+    V3 u1 = ld3(b.all, A_V, v1), u2 = ld3(b.all, A_V, v2), u3 = ld3(b.all, A_V, v3i);
+    st3(b.all, A_V, e, v3((u1.x + u2.x + u3.x) / 3.0f, (u1.y + u2.y + u3.y) / 3.0f, (u1.z + u2.z + u3.z) / 3.0f));
+    V3 xe = v3((x1.x + x2.x + x3.x) / 3.0f, (x1.y + x2.y + x3.y) / 3.0f, (x1.z + x2.z + x3.z) / 3.0f);
+    st3(b.all, A_X, e, xe);
+    {  // drift check against the block this element was sorted into
+      int blk = key_block(skeys[e], blk_bits);
+      int oz = 4 * (blk % d.NB) - 1, oy = 4 * ((blk / d.NB) % d.NB) - 1, ox = 4 * (blk / (d.NB * d.NB)) - 1;
+      int nbx = (int)(xe.x * d.inv_dx - 0.5f) - ox, nby = (int)(xe.y * d.inv_dx - 0.5f) - oy, nbz = (int)(xe.z * d.inv_dx - 0.5f) - oz;
+      if (b.sel[e] == 0 && ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u)) counters[6] = 1;
+    }
+    V3 d3o = v3(b.el.at(E_D + 2, e), b.el.at(E_D + 5, e), b.el.at(E_D + 8, e));
+    V3 d1 = x2 - x1, d2 = x3 - x1;
+    dm = m3_cols(d1, d2, d3o);
+    b.el.at(E_D + 0, e) = d1.x; b.el.at(E_D + 3, e) = d1.y; b.el.at(E_D + 6, e) = d1.z;
+    b.el.at(E_D + 1, e) = d2.x; b.el.at(E_D + 4, e) = d2.y; b.el.at(E_D + 7, e) = d2.z;
+  } else {
+    dm = ld9(b.el, E_D, e);
+  }
   QR3 q = qr_cloth(dm);
   float gamma = b.el.at(E_GAMMA, e), kappa = b.el.at(E_KAPPA, e);
   float r02, r12, r22;
@@ -1190,6 +1217,7 @@ struct FastState {
   int n_P = 0, n_A = 0, n_chunks = 0;
   int *h_pin = nullptr;  // pinned host scratch
   std::vector<int> h_ranges, h_chunks;
+  bool elem_pending = false;  // element finalise of the last substep still to be done (fused into the next stress)
   int steps_since_rebin = 0;
   hipEvent_t ev_flag = nullptr;
   bool flag_pending = false;
@@ -1251,6 +1279,16 @@ int scan_flags(mpmhip_ctx *c, const int *flag, int *index, int n, int *total) {
   return MPMHIP_OK;
 }
 
+// run the stand-alone element finalise if the last substep deferred it
+int flush_elements(mpmhip_ctx *c) {
+  FastState *f = c->fast;
+  if (f->elem_pending && f->d.n_e)
+    hipLaunchKernelGGL(k_elem_finalize, nblk(f->d.n_e), TPB, 0, c->stream, f->buf[f->cur], f->face_slot, f->keys[1],
+                       f->blk_bits, f->g.counters, f->d);
+  f->elem_pending = false;
+  return MPMHIP_OK;
+}
+
 int do_import(mpmhip_ctx *c) {
   FastState *f = c->fast;
   const Dims &d = f->d;
@@ -1280,6 +1318,7 @@ int do_import(mpmhip_ctx *c) {
     hipLaunchKernelGGL(k_adj_build, nblk(d.n_e), TPB, 0, s, c->st.faces, d.n_e, d.n_v, f->adj_cnt, f->adj_o, K, 1);
     MPM_HIP_CHECK(c, hipMemsetAsync(f->eforce, 0, (size_t)6 * d.n_e * sizeof(float), s));
   }
+  f->elem_pending = false;
   c->caller_dirty = false;
   c->internal_dirty = false;
   f->steps_since_rebin = 1 << 30;  // force a rebin before the next transfer
@@ -1292,6 +1331,7 @@ int rebin(mpmhip_ctx *c) {
   hipStream_t s = c->stream;
   int cur = f->cur, alt = 1 - cur;
   if (d.n_p == 0) { f->n_P = f->n_A = f->n_chunks = 0; f->steps_since_rebin = 0; return MPMHIP_OK; }
+  flush_elements(c);
   hipLaunchKernelGGL(k_keys, nblk(d.n_p), TPB, 0, s, f->buf[cur], d, f->blk_bits, f->keys[0], f->iota);
   size_t need = 0;
   MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(nullptr, need, f->keys[0], f->keys[1], f->iota, f->order, (size_t)d.n_p, 0u,
@@ -1462,6 +1502,7 @@ int fast_add_mover_storage(mpmhip_ctx *c, Mover &mv) {
 int fast_pull(mpmhip_ctx *c) {
   FastState *f = c->fast;
   const Dims &d = f->d;
+  flush_elements(c);
   if (d.n_p && f->have_order) {
     int m = c->sc.material;
     hipLaunchKernelGGL(k_export, nblk(d.n_p), TPB, 0, c->stream, c->st, c->md, f->buf[f->cur], f->va(),
@@ -1488,6 +1529,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   const float dt = a.dt;
   // pre-p2g particle operations, mpm_solver.py:260-279 (impulses first, then velocity modifiers)
   if (!c->pre.empty() && d.n_p) {
+    flush_elements(c);
     float t = (float)c->time;
     for (int pass = 0; pass < 2; ++pass)
       for (auto &op : c->pre) {
@@ -1517,6 +1559,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   // With profiling on (one sync per phase, like the reference's ScopedTimer) everything stays on one stream.
   bool has_col = !c->colliders.empty() && c->num_mesh_f && f->n_fbins;
   bool mov_on = a.joint_v_v && a.joint_f_v && !c->movers.empty();
+  if (mov_on && c->cfg.num_joint_f > 0) flush_elements(c);  // joint-face splats read element positions
   bool side = !c->profiling && (has_col || mov_on);
   hipStream_t ss = side ? f->side : s;
   auto launch_splats = [&]() {
@@ -1546,7 +1589,15 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   }
   {
     ScopedPhase ph(c, "compute_stress_from_F_trial");
-    if (d.n_e) hipLaunchKernelGGL(k_stress_elem, nblk(d.n_e), TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff);
+    if (d.n_e) {
+      if (f->elem_pending)
+        hipLaunchKernelGGL(k_stress_elem<true>, nblk(d.n_e), TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff, f->face_slot,
+                           f->keys[1], f->blk_bits, f->g.counters);
+      else
+        hipLaunchKernelGGL(k_stress_elem<false>, nblk(d.n_e), TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff, f->face_slot,
+                           f->keys[1], f->blk_bits, f->g.counters);
+      f->elem_pending = false;
+    }
     if (d.n_t) hipLaunchKernelGGL(k_stress_trad, nblk(d.n_t), TPB, 0, s, b, d, c->sc, dt);
   }
   {
@@ -1602,7 +1653,9 @@ static int step_phase_c(mpmhip_ctx *c, const StepArgs &a) {
   Bufs &b = f->buf[f->cur];
   {
     ScopedPhase ph(c, "g2p_e");
-    if (d.n_e) hipLaunchKernelGGL(k_elem_finalize, nblk(d.n_e), TPB, 0, s, b, f->face_slot, f->keys[1], f->blk_bits, f->g.counters, d);
+    // single-GPU, unprofiled: defer into the next substep's stress kernel (k_stress_elem<true>)
+    f->elem_pending = d.n_e > 0;
+    if (f->dist || c->profiling) flush_elements(c);
   }
   f->steps_since_rebin += 1;
   if (!f->dist && !f->flag_pending && (f->steps_since_rebin & 7) == 0) {
