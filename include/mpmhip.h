@@ -211,6 +211,22 @@ int mpmhip_dist_step_begin(mpmhip_ctx *ctx, float dt, const float *mesh_x, const
 int mpmhip_dist_step_mid(mpmhip_ctx *ctx);
 int mpmhip_dist_step_end(mpmhip_ctx *ctx);
 
+/* RCCL transport inside the library (no Python in the substep loop): the communicator is created from a
+ * ncclUniqueId that rank 0 obtains with mpmhip_rccl_unique_id() and the caller broadcasts (torch.distributed).
+ * librccl.so.1 is dlopen'ed on first use (the copy torch has already loaded, if any). */
+int mpmhip_rccl_unique_id(char id[128]);
+int mpmhip_rccl_init(mpmhip_ctx *ctx, int32_t rank, int32_t world, const char id[128]);
+/* static ghost lists per peer rank ([host] int arrays of caller-order particle indices, see mpmhip_dist_peer) */
+int mpmhip_rccl_set_ghosts(mpmhip_ctx *ctx, int32_t n_peers, const int32_t *peer_ranks, const int32_t *n_send_p,
+                           const int32_t *const *send_p, const int32_t *n_recv_p, const int32_t *const *recv_p,
+                           const int32_t *n_send_e, const int32_t *const *send_e, const int32_t *n_recv_e,
+                           const int32_t *const *recv_e);
+/* n substeps (collective): re-sort + shared-block lists every rebin_interval substeps (counted from step_index),
+ * halo and ghost exchanges with ncclSend/ncclRecv groups on the context's stream; mesh advection factor of substep
+ * k is (step_index + k) * dt */
+int mpmhip_rccl_steps(mpmhip_ctx *ctx, float dt, int32_t n, int64_t step_index, int32_t rebin_interval,
+                      const float *mesh_x, const float *mesh_v, const float *joint_verts_v, const float *joint_faces_v);
+
 /* ---- introspection ---------------------------------------------------------------------- */
 /* dense reference-layout copies of grid_m [G^3], grid_v_in [G^3*3], grid_v_out [G^3*3] as they
  * stand after the last substep's grid stage ([dev] outputs, any may be NULL).  Synchronous. */

@@ -431,6 +431,40 @@ int mpmhip_dist_step_end(mpmhip_ctx *c) {
   return MPMHIP_OK;
 }
 
+int mpmhip_rccl_unique_id(char id[128]) {
+  if (!id) return MPMHIP_ERR_INVALID;
+  return fast_rccl_unique_id(id, g_create_error);
+}
+int mpmhip_rccl_init(mpmhip_ctx *c, int32_t rank, int32_t world, const char id[128]) {
+  CHECK_CTX(c);
+  if (!fast_mode(c) || !id) return fail(c, MPMHIP_ERR_INVALID, "rccl_init: fast mode context and an id are required");
+  return fast_rccl_init(c, rank, world, id);
+}
+int mpmhip_rccl_set_ghosts(mpmhip_ctx *c, int32_t n_peers, const int32_t *peer_ranks, const int32_t *n_send_p,
+                           const int32_t *const *send_p, const int32_t *n_recv_p, const int32_t *const *recv_p,
+                           const int32_t *n_send_e, const int32_t *const *send_e, const int32_t *n_recv_e,
+                           const int32_t *const *recv_e) {
+  CHECK_CTX(c);
+  if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
+  return fast_rccl_set_ghosts(c, n_peers, peer_ranks, n_send_p, send_p, n_recv_p, recv_p, n_send_e, send_e, n_recv_e, recv_e);
+}
+int mpmhip_rccl_steps(mpmhip_ctx *c, float dt, int32_t n, int64_t step_index, int32_t rebin_interval, const float *mesh_x,
+                      const float *mesh_v, const float *joint_verts_v, const float *joint_faces_v) {
+  CHECK_CTX(c);
+  if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
+  if (!c->st_bound || !c->md_bound) return fail(c, MPMHIP_ERR_STATE, "step: state/model not bound");
+  if ((mesh_x || mesh_v) && !c->mesh_points) return fail(c, MPMHIP_ERR_STATE, "step: mesh_x/mesh_v given but no body mesh");
+  c->fast_dt = dt;
+  int rc = fast_rccl_steps(c, dt, n, step_index, rebin_interval, mesh_x, mesh_v, joint_verts_v, joint_faces_v);
+  if (rc) return rc;
+  if (n > 0 && (mesh_x || mesh_v)) {
+    size_t nm = (size_t)c->num_mesh_v * 3;
+    hipLaunchKernelGGL(k_mesh_store, (unsigned)((nm + 255) / 256), 256, 0, c->stream, c->mesh_points, c->mesh_vel, mesh_x,
+                       mesh_v, c->cur_f, nm);
+  }
+  return MPMHIP_OK;
+}
+
 int mpmhip_synchronize(mpmhip_ctx *c) {
   CHECK_CTX(c);
   MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));

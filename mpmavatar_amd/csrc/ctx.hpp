@@ -166,6 +166,14 @@ int fast_dist_rebin(mpmhip_ctx *ctx, unsigned char *active_map);
 int fast_dist_set_peers(mpmhip_ctx *ctx, int n, const mpmhip_dist_peer *peers);
 int fast_dist_phase(mpmhip_ctx *ctx, int phase, const StepArgs &a);
 
+int fast_rccl_unique_id(char id[128], std::string &err);
+int fast_rccl_init(mpmhip_ctx *ctx, int rank, int world, const char id[128]);
+int fast_rccl_set_ghosts(mpmhip_ctx *ctx, int n, const int32_t *ranks, const int32_t *nsp, const int32_t *const *sp,
+                         const int32_t *nrp, const int32_t *const *rp, const int32_t *nse, const int32_t *const *se,
+                         const int32_t *nre, const int32_t *const *re);
+int fast_rccl_steps(mpmhip_ctx *ctx, float dt, int n, int64_t step_index, int rebin_interval, const float *mesh_x,
+                    const float *mesh_v, const float *jv, const float *jf);
+
 // shared small kernels (common.hip)
 int launch_pre_ops(mpmhip_ctx *ctx, float dt, float *v, const float *x, const float *mass, int n);
 int launch_select_box(mpmhip_ctx *ctx, const float *x, const float point[3], const float size[3], int32_t *mask);

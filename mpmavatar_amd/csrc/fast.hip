@@ -17,6 +17,9 @@
 #include <cstring>
 #include <string.h>
 #include <cstdlib>
+#include <dlfcn.h>
+
+#include <rccl/rccl.h>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -1133,6 +1136,10 @@ __global__ void k_ghost_unpack(const int *ids_p, int n_p_ids, const int *ids_e, 
     b.el.at(E_D + 2, s) = o[0]; b.el.at(E_D + 5, s) = o[1]; b.el.at(E_D + 8, s) = o[2];
   }
 }
+__global__ void k_shared_flags(const unsigned char *a, const unsigned char *b, int n, int *flag) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = (a[i] && b[i]) ? 1 : 0;
+}
 __global__ void k_flags_to_bytes(const int *flag, int n, unsigned char *out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = flag[i] ? 1 : 0;
@@ -1183,9 +1190,50 @@ struct DistPeer {
   float *ghost_send = nullptr, *ghost_recv = nullptr;
 };
 
+struct Rccl {  // entry points resolved with dlsym: libmpmhip.so itself does not link librccl
+  void *h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  bool load(std::string &err) {
+    if (h) return true;
+    h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { err = std::string("dlopen librccl.so.1: ") + dlerror(); return false; }
+    auto sym = [&](const char *n) { void *p = dlsym(h, n); if (!p) err = std::string("dlsym ") + n; return p; };
+    *(void **)&GetUniqueId = sym("ncclGetUniqueId"); *(void **)&CommInitRank = sym("ncclCommInitRank");
+    *(void **)&CommDestroy = sym("ncclCommDestroy"); *(void **)&GroupStart = sym("ncclGroupStart");
+    *(void **)&GroupEnd = sym("ncclGroupEnd"); *(void **)&Send = sym("ncclSend"); *(void **)&Recv = sym("ncclRecv");
+    *(void **)&AllGather = sym("ncclAllGather"); *(void **)&GetErrorString = sym("ncclGetErrorString");
+    return GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllGather && GetErrorString;
+  }
+};
+
+struct RcclPeer {  // one neighbour rank: static ghost lists + per-re-sort shared blocks, all buffers owned here
+  int rank = -1;
+  int *send_p = nullptr, *recv_p = nullptr, *send_e = nullptr, *recv_e = nullptr;
+  int n_send_p = 0, n_recv_p = 0, n_send_e = 0, n_recv_e = 0;
+  float *ghost_send = nullptr, *ghost_recv = nullptr;
+  int *blocks = nullptr, *flag = nullptr, *index = nullptr;
+  int n_blocks = 0, cap_blocks = 0;
+  float *halo_send = nullptr, *halo_recv = nullptr;
+};
+
 struct FastState {
+  Rccl rccl;
+  std::vector<RcclPeer> rpeers;
+  unsigned char *map_all = nullptr;  // [world][nblocks] active-block byte maps
   Dims d{};
   bool dist = false;  // multi-GPU: re-sorts only on request (all ranks re-sort together)
+  bool dist_keep_cur = false;  // re-sort inside mpmhip_rccl_steps: the caller's mesh pointers are valid
   std::vector<DistPeer> peers;
   StepArgs dist_args{};
   int blk_bits = 0, key_bits = 0;
@@ -1466,6 +1514,7 @@ int fast_init(mpmhip_ctx *c) {
 void fast_destroy(mpmhip_ctx *c) {
   FastState *f = c->fast;
   if (!f) return;
+  if (f->rccl.comm) (void)f->rccl.CommDestroy(f->rccl.comm);
   for (void *p : f->allocs) (void)hipFree(p);
   if (f->h_pin) (void)hipHostFree(f->h_pin);
   if (f->side) { (void)hipStreamSynchronize(f->side); (void)hipStreamDestroy(f->side); }
@@ -1688,10 +1737,12 @@ int fast_dist_rebin(mpmhip_ctx *c, unsigned char *active_map) {
   int rc;
   if (!c->st_bound || !c->md_bound) return fail(c, MPMHIP_ERR_STATE, "dist_rebin: state/model not bound");
   if (c->caller_dirty && (rc = do_import(c))) return rc;
-  // between substeps the caller's mesh tensors may be gone: bin the body faces from the context's own copy
-  c->cur_pts = c->mesh_points;
-  c->cur_vel = c->mesh_vel;
-  c->cur_f = 0.0f;
+  if (!f->dist_keep_cur) {
+    // between substeps the caller's mesh tensors may be gone: bin the body faces from the context's own copy
+    c->cur_pts = c->mesh_points;
+    c->cur_vel = c->mesh_vel;
+    c->cur_f = 0.0f;
+  }
   if ((rc = rebin(c))) return rc;
   if (active_map)
     hipLaunchKernelGGL(k_flags_to_bytes, nblk(f->nblocks), TPB, 0, c->stream, f->ab_flag, (int)f->nblocks, active_map);
@@ -1742,6 +1793,155 @@ int fast_dist_phase(mpmhip_ctx *c, int phase, const StepArgs &a) {
     if ((rc = step_phase_c(c, f->dist_args))) return rc;
   }
   MPM_HIP_CHECK(c, hipGetLastError());
+  return MPMHIP_OK;
+}
+
+// ---- RCCL transport inside the library ----------------------------------------------------------------------
+#define MPM_NCCL_CHECK(c, r, expr)                                                                                \
+  do {                                                                                                            \
+    ncclResult_t e_ = (expr);                                                                                     \
+    if (e_ != ncclSuccess) return fail(c, MPMHIP_ERR_HIP, std::string(#expr) + ": " + (r).GetErrorString(e_));   \
+  } while (0)
+
+int fast_rccl_unique_id(char id[128], std::string &err) {
+  Rccl r;
+  if (!r.load(err)) return MPMHIP_ERR_HIP;
+  ncclUniqueId uid;
+  ncclResult_t e = r.GetUniqueId(&uid);
+  if (e != ncclSuccess) { err = std::string("ncclGetUniqueId: ") + r.GetErrorString(e); return MPMHIP_ERR_HIP; }
+  static_assert(sizeof(uid) == 128, "ncclUniqueId size");
+  memcpy(id, &uid, 128);
+  return MPMHIP_OK;
+}
+
+int fast_rccl_init(mpmhip_ctx *c, int rank, int world, const char id[128]) {
+  FastState *f = c->fast;
+  if (world < 1 || rank < 0 || rank >= world) return fail(c, MPMHIP_ERR_INVALID, "rccl_init: bad rank/world");
+  if (!f->rccl.load(c->err)) return MPMHIP_ERR_HIP;
+  ncclUniqueId uid;
+  memcpy(&uid, id, 128);
+  MPM_NCCL_CHECK(c, f->rccl, f->rccl.CommInitRank(&f->rccl.comm, world, uid, rank));
+  f->rccl.rank = rank;
+  f->rccl.world = world;
+  f->dist = true;
+  int rc;
+  if ((rc = dalloc(c, &f->map_all, (size_t)world * f->nblocks))) return rc;
+  return MPMHIP_OK;
+}
+
+int fast_rccl_set_ghosts(mpmhip_ctx *c, int n, const int32_t *ranks, const int32_t *nsp, const int32_t *const *sp,
+                         const int32_t *nrp, const int32_t *const *rp, const int32_t *nse, const int32_t *const *se,
+                         const int32_t *nre, const int32_t *const *re) {
+  FastState *f = c->fast;
+  if (!f->rccl.comm) return fail(c, MPMHIP_ERR_STATE, "rccl_set_ghosts: call mpmhip_rccl_init first");
+  // one peer slot per other rank (shared blocks may exist without ghosts, e.g. traditional particles only)
+  f->rpeers.clear();
+  for (int q = 0; q < f->rccl.world; ++q) {
+    if (q == f->rccl.rank) continue;
+    RcclPeer p;
+    p.rank = q;
+    int rc;
+    if ((rc = dalloc(c, &p.flag, f->nblocks))) return rc;
+    if ((rc = dalloc(c, &p.index, f->nblocks))) return rc;
+    f->rpeers.push_back(p);
+  }
+  auto up = [&](int **dst, const int32_t *src, int cnt) -> int {
+    int rc = dalloc(c, dst, (size_t)std::max(cnt, 1), false);
+    if (rc) return rc;
+    if (cnt) MPM_HIP_CHECK(c, hipMemcpy(*dst, src, (size_t)cnt * sizeof(int), hipMemcpyHostToDevice));
+    return MPMHIP_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    RcclPeer *p = nullptr;
+    for (auto &q : f->rpeers) if (q.rank == ranks[i]) p = &q;
+    if (!p) return fail(c, MPMHIP_ERR_INVALID, "rccl_set_ghosts: bad peer rank");
+    int rc;
+    p->n_send_p = nsp[i]; p->n_recv_p = nrp[i]; p->n_send_e = nse[i]; p->n_recv_e = nre[i];
+    if ((rc = up(&p->send_p, sp[i], nsp[i])) || (rc = up(&p->recv_p, rp[i], nrp[i])) || (rc = up(&p->send_e, se[i], nse[i])) ||
+        (rc = up(&p->recv_e, re[i], nre[i])))
+      return rc;
+    if ((rc = dalloc(c, &p->ghost_send, (size_t)6 * nsp[i] + 3 * nse[i] + 1))) return rc;
+    if ((rc = dalloc(c, &p->ghost_recv, (size_t)6 * nrp[i] + 3 * nre[i] + 1))) return rc;
+  }
+  return MPMHIP_OK;
+}
+
+static int rccl_rebin(mpmhip_ctx *c) {
+  FastState *f = c->fast;
+  Rccl &r = f->rccl;
+  hipStream_t s = c->stream;
+  int rc, nb = (int)f->nblocks;
+  unsigned char *mine = f->map_all + (size_t)r.rank * f->nblocks;
+  if ((rc = fast_dist_rebin(c, mine))) return rc;
+  MPM_NCCL_CHECK(c, r, r.AllGather(mine, f->map_all, f->nblocks, ncclUint8, r.comm, s));
+  int CH = c->movers.empty() ? 4 : 8;
+  f->peers.clear();
+  for (auto &p : f->rpeers) {
+    hipLaunchKernelGGL(k_shared_flags, nblk(nb), TPB, 0, s, mine, f->map_all + (size_t)p.rank * f->nblocks, nb, p.flag);
+    if ((rc = scan_flags(c, p.flag, p.index, nb, &p.n_blocks))) return rc;
+    if (p.n_blocks > p.cap_blocks) {
+      int cap = std::max(p.n_blocks + p.n_blocks / 2, 256);
+      if ((rc = dalloc(c, &p.blocks, (size_t)cap, false))) return rc;
+      if ((rc = dalloc(c, &p.halo_send, (size_t)cap * 8 * 64, false))) return rc;
+      if ((rc = dalloc(c, &p.halo_recv, (size_t)cap * 8 * 64, false))) return rc;
+      p.cap_blocks = cap;
+    }
+    if (p.n_blocks) hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, p.flag, p.index, nb, p.blocks);
+    DistPeer q;
+    q.n_blocks = p.n_blocks; q.blocks = p.blocks; q.halo_send = p.halo_send; q.halo_recv = p.halo_recv;
+    q.n_send_p = p.n_send_p; q.n_recv_p = p.n_recv_p; q.n_send_e = p.n_send_e; q.n_recv_e = p.n_recv_e;
+    q.send_p = p.send_p; q.recv_p = p.recv_p; q.send_e = p.send_e; q.recv_e = p.recv_e;
+    q.ghost_send = p.ghost_send; q.ghost_recv = p.ghost_recv;
+    f->peers.push_back(q);
+  }
+  (void)CH;
+  return MPMHIP_OK;
+}
+
+// f->peers[i] corresponds to f->rpeers[i]
+static int rccl_exchange(mpmhip_ctx *c, bool halo) {
+  FastState *f = c->fast;
+  Rccl &r = f->rccl;
+  int CH = c->movers.empty() ? 4 : 8;
+  MPM_NCCL_CHECK(c, r, r.GroupStart());
+  for (size_t i = 0; i < f->peers.size(); ++i) {
+    const DistPeer &p = f->peers[i];
+    int peer = f->rpeers[i].rank;
+    size_t ns = halo ? (size_t)p.n_blocks * CH * 64 : (size_t)6 * p.n_send_p + 3 * p.n_send_e;
+    size_t nr = halo ? (size_t)p.n_blocks * CH * 64 : (size_t)6 * p.n_recv_p + 3 * p.n_recv_e;
+    if (ns) MPM_NCCL_CHECK(c, r, r.Send(halo ? p.halo_send : p.ghost_send, ns, ncclFloat, peer, r.comm, c->stream));
+    if (nr) MPM_NCCL_CHECK(c, r, r.Recv(halo ? p.halo_recv : p.ghost_recv, nr, ncclFloat, peer, r.comm, c->stream));
+  }
+  MPM_NCCL_CHECK(c, r, r.GroupEnd());
+  return MPMHIP_OK;
+}
+
+int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebin_interval, const float *mesh_x,
+                    const float *mesh_v, const float *jv, const float *jf) {
+  FastState *f = c->fast;
+  if (!f->rccl.comm) return fail(c, MPMHIP_ERR_STATE, "rccl_steps: call mpmhip_rccl_init first");
+  if (rebin_interval <= 0) rebin_interval = 32;
+  int rc;
+  for (int k = 0; k < n; ++k) {
+    int64_t idx = step_index + k;
+    StepArgs a{dt, mesh_x, mesh_v, (float)((double)dt * (double)idx), true, nullptr, 0, jv, jf};
+    c->cur_pts = a.mesh_x ? a.mesh_x : c->mesh_points;
+    c->cur_vel = a.mesh_v ? a.mesh_v : c->mesh_vel;
+    c->cur_f = (a.mesh_x && a.mesh_v) ? a.mesh_f : 0.0f;
+    if (idx % rebin_interval == 0 || c->caller_dirty) {
+      f->dist_keep_cur = true;
+      rc = rccl_rebin(c);
+      f->dist_keep_cur = false;
+      if (rc) return rc;
+    }
+    if ((rc = fast_dist_phase(c, 0, a))) return rc;
+    if ((rc = rccl_exchange(c, true))) return rc;
+    if ((rc = fast_dist_phase(c, 1, a))) return rc;
+    if ((rc = rccl_exchange(c, false))) return rc;
+    if ((rc = fast_dist_phase(c, 2, a))) return rc;
+    c->time = c->time + (double)dt;
+    c->substeps += 1;
+  }
   return MPMHIP_OK;
 }
 

@@ -15,6 +15,9 @@ Decomposition
     The body-face splat is replicated (each rank splats the faces that touch its active blocks).
   * all ranks re-sort at the same substep (every ``rebin_interval`` substeps); the shared-block lists are rebuilt
     there from an all_gather of the per-rank active-block maps.
+Transports: "rccl" (default with the nccl backend) runs the whole substep loop inside libmpmhip.so with its own
+RCCL communicator (ncclSend/ncclRecv groups on the solver stream, ncclAllGather of the block maps; no Python per
+substep); "torch" drives the three phases from Python with torch.distributed P2P ops (MPMHIP_DIST_TRANSPORT=torch).
 Backend "nccl" (= RCCL) exchanges device buffers; "gloo" stages through host memory and exists so that the whole
 path can be exercised with two processes on one GPU (tests/test_gpu_dist.py) and on CPU-only CI (partition logic).
 """
@@ -123,6 +126,7 @@ class ShardedSim:
     sim: object                        # harness.Sim of the local scene
     backend: str
     rebin_interval: int
+    transport: str = "torch"           # "rccl": loop inside libmpmhip.so; "torch": phases driven from Python
     steps_done: int = 0
     peers: list = field(default_factory=list)
     keep: list = field(default_factory=list)
@@ -151,7 +155,53 @@ def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int 
         ss.static[q]["gr"] = torch.zeros(max(n_r, 1), dtype=torch.float32, device=dev)
     nb = sv._lib.mpmhip_dist_num_blocks(sv._ctx)
     ss.static["map"] = torch.zeros(nb, dtype=torch.uint8, device=dev)
+    import os
+    want = os.environ.get("MPMHIP_DIST_TRANSPORT", "rccl" if ss.backend == "nccl" else "torch")
+    if want == "rccl":
+        # every rank must end up on the same transport: agree on success before switching
+        ok = 1
+        try:
+            _init_rccl(ss, rank, world)
+        except Exception as e:  # noqa: BLE001 - any failure means "use the torch transport"
+            print(f"[mpmavatar_amd.dist] rank {rank}: in-library RCCL transport unavailable ({e}); using torch.distributed", flush=True)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev if ss.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ss.transport = "rccl" if int(flag.item()) == 1 else "torch"
     return ss
+
+
+def _init_rccl(ss: ShardedSim, rank: int, world: int):
+    """Create the library's own RCCL communicator (unique id from rank 0, broadcast through torch.distributed) and hand
+    it the static ghost lists."""
+    import torch.distributed as dist
+    from . import _lib as L
+    sv, sh = ss.sim.solver, ss.shard
+    uid = (C.c_char * 128)()
+    if rank == 0:
+        L.check(sv._lib, None, sv._lib.mpmhip_rccl_unique_id(uid))
+    box = [bytes(uid.raw) if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    uid = (C.c_char * 128).from_buffer_copy(box[0])
+    sv._call("mpmhip_rccl_init", rank, world, uid)
+    peers = sorted(set(sh.send_p) | set(sh.recv_p))
+    n = len(peers)
+    I = lambda vals: (C.c_int32 * max(n, 1))(*vals)
+    keep = []
+
+    def ptrs(d):
+        arr = (L.ip * max(n, 1))()
+        for i, q in enumerate(peers):
+            a = np.ascontiguousarray(d[q], np.int32)
+            keep.append(a)
+            arr[i] = a.ctypes.data_as(L.ip)
+        return arr
+    sv._call("mpmhip_rccl_set_ghosts", n, I(peers), I([len(sh.send_p[q]) for q in peers]), ptrs(sh.send_p),
+             I([len(sh.recv_p[q]) for q in peers]), ptrs(sh.recv_p), I([len(sh.send_e[q]) for q in peers]), ptrs(sh.send_e),
+             I([len(sh.recv_e[q]) for q in peers]), ptrs(sh.recv_e))
+    ss.transport = "rccl"
 
 
 def _all_gather_maps(ss: ShardedSim):
@@ -240,6 +290,13 @@ def run(ss: ShardedSim, n_steps: int):
     dp = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
     jv, jf = sim.joint_verts_v, sim.joint_faces_v
     dummy = sv._dummy_ptr()
+    if ss.transport == "rccl":
+        jvp = None if jv is None else (dp(jv) or dummy)
+        jfp = None if jf is None else (dp(jf) or dummy)
+        sv._call("mpmhip_rccl_steps", float(sc.dt), int(n_steps), int(ss.steps_done), int(ss.rebin_interval),
+                 dp(sim.mesh_x0), dp(sim.mesh_v), jvp, jfp)
+        ss.steps_done += n_steps
+        return
     for _ in range(n_steps):
         if ss.steps_done % ss.rebin_interval == 0:
             rebin_all(ss)

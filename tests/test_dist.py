@@ -42,3 +42,15 @@ def test_partition_and_halo_sum_cpu(world, scene, oracle_lib):
 def test_sharded_matches_single_context(scene, steps):
     out = _launch(2, "gpu", scene, steps)
     assert "max rel dx" in out
+
+
+@pytest.mark.gpu
+def test_in_library_rccl_transport_single_rank():
+    """World size 1 through the library's own RCCL communicator (dlopen, ncclCommInitRank, ncclAllGather of the block
+    map, empty send/recv groups) -- the multi-rank send/recv itself cannot run on a one-GPU box."""
+    env = dict(os.environ, MPMHIP_DIST_TRANSPORT="rccl")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "gpu", "garment", "40"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "max rel dx" in r.stdout
