@@ -761,24 +761,35 @@ __global__ __launch_bounds__(64) void k_col_splat(const float *pts, const float 
   }
 }
 
-// particle with ORIGINAL index (off + t) gets prescribed velocity vel[t]
-__global__ void k_mover_splat(Bufs b, const int *inv, const float *vel, int n, int off, Dims d, GridPtrs g) {
+// Joint splat (add_velocity_{traditional,verts,faces}, mpm_solver.py:677-788) as ONE launch: 32 lanes per joint
+// particle, lane = stencil node (27 used), so every thread has a single short dependency chain instead of a 27-trip
+// loop of dependent loads.  Group 0: the last n_t traditional particles, group 1: the first n_v vertices, group 2:
+// the first n_f elements (caller-order indices; inv[] maps them to sorted slots).
+struct JointSplat {
+  const float *vel_t, *vel_v, *vel_f;
+  int n_t, n_v, n_f;
+  int off_t, off_v;  // caller-order index of the first particle of group 0 / group 1 (group 2 starts at 0)
+};
+__global__ void k_mover_splat(Bufs b, const int *inv, JointSplat js, Dims d, GridPtrs g) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  int sidx = inv[off + t];
-  Stencil s = make_stencil(ld3(b.all, A_X, sidx), d.inv_dx);
-  if (!splat_ok(d.G, s)) return;
-  V3 pv = load_v3(vel + 3 * (size_t)t);
-  for (int nn = 0; nn < 27; ++nn) {
-    int i = nn / 9, j = (nn / 3) % 3, k = nn % 3;
-    float w = sel3(i, s.w0.x, s.w1.x, s.w2.x) * sel3(j, s.w0.y, s.w1.y, s.w2.y) * sel3(k, s.w0.z, s.w1.z, s.w2.z);
-    int x = s.bx + i, y = s.by + j, z = s.bz + k;
-    int blk = blk_of(x, y, z, d.NB);
-    if (!g.ab_flag[blk]) { atomicAdd(g.counters + 1, 1); continue; }
-    float *p = g.mov + ((size_t)blk * GCH_MOV) * 64 + loc_of(x, y, z);
-    atomicAdd(p, w);
-    atomicAdd(p + 64, w * pv.x); atomicAdd(p + 128, w * pv.y); atomicAdd(p + 192, w * pv.z);
-  }
+  int q = t >> 5, nn = t & 31;
+  if (nn >= 27 || q >= js.n_t + js.n_v + js.n_f) return;
+  const float *vel;
+  int orig;
+  if (q < js.n_t) { vel = js.vel_t + 3 * (size_t)q; orig = js.off_t + q; }
+  else if (q < js.n_t + js.n_v) { vel = js.vel_v + 3 * (size_t)(q - js.n_t); orig = js.off_v + (q - js.n_t); }
+  else { vel = js.vel_f + 3 * (size_t)(q - js.n_t - js.n_v); orig = q - js.n_t - js.n_v; }
+  Stencil s = make_stencil(ld3(b.all, A_X, inv[orig]), d.inv_dx);
+  if (!splat_ok(d.G, s)) return;  // mpm_solver.py:692,730,767
+  int i = nn / 9, j = (nn / 3) % 3, k = nn % 3;
+  float w = sel3(i, s.w0.x, s.w1.x, s.w2.x) * sel3(j, s.w0.y, s.w1.y, s.w2.y) * sel3(k, s.w0.z, s.w1.z, s.w2.z);
+  int x = s.bx + i, y = s.by + j, z = s.bz + k;
+  int blk = blk_of(x, y, z, d.NB);
+  if (!g.ab_flag[blk]) { atomicAdd(g.counters + 1, 1); return; }
+  V3 pv = load_v3(vel);
+  float *p = g.mov + ((size_t)blk * GCH_MOV) * 64 + loc_of(x, y, z);
+  atomicAdd(p, w);
+  atomicAdd(p + 64, w * pv.x); atomicAdd(p + 128, w * pv.y); atomicAdd(p + 192, w * pv.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1619,15 +1630,10 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     }
     if (mov_on) {
       ScopedPhase ph(c, "apply_Particle_Moving_on_grid");
-      if (a.joint_t_v && a.n_joint_t > 0)
-        hipLaunchKernelGGL(k_mover_splat, nblk(a.n_joint_t), TPB, 0, ss, b, f->inv, a.joint_t_v, a.n_joint_t,
-                           d.n_nv - a.n_joint_t, d, f->g);
-      if (c->cfg.num_joint_v > 0)
-        hipLaunchKernelGGL(k_mover_splat, nblk(c->cfg.num_joint_v), TPB, 0, ss, b, f->inv, a.joint_v_v,
-                           c->cfg.num_joint_v, d.n_nv, d, f->g);
-      if (c->cfg.num_joint_f > 0)
-        hipLaunchKernelGGL(k_mover_splat, nblk(c->cfg.num_joint_f), TPB, 0, ss, b, f->inv, a.joint_f_v,
-                           c->cfg.num_joint_f, 0, d, f->g);
+      JointSplat js{a.joint_t_v, a.joint_v_v, a.joint_f_v, (a.joint_t_v ? a.n_joint_t : 0), c->cfg.num_joint_v,
+                    c->cfg.num_joint_f, d.n_nv - a.n_joint_t, d.n_nv};
+      int nj = js.n_t + js.n_v + js.n_f;
+      if (nj) hipLaunchKernelGGL(k_mover_splat, nblk((size_t)nj * 32), TPB, 0, ss, b, f->inv, js, d, f->g);
     }
   };
   if (side) {

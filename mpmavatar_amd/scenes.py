@@ -208,4 +208,6 @@ REGISTRY = {
     "sheet-500k": lambda: sheet(),
     "block-512k": lambda: block(),
     "demo-mix": lambda: demo_mix(),
+    # run_demo.py-sized stand-in: 250^3 grid, 100,000 sand particles (utils/demo_utils.py:6), 200x200 garment sheet
+    "demo-250": lambda: demo_mix(n_grid=250, n_sheet=200, sand=(200, 10, 50), n_steps=400),
 }
