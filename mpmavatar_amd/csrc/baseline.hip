@@ -50,31 +50,14 @@ __global__ void k_stress(mpmhip_state_ptrs st, mpmhip_model_ptrs md, mpmhip_mode
     atomicAdd(vf + 3 * v2 + 0, f2.x); atomicAdd(vf + 3 * v2 + 1, f2.y); atomicAdd(vf + 3 * v2 + 2, f2.z);
     atomicAdd(vf + 3 * v3i + 0, f3.x); atomicAdd(vf + 3 * v3i + 1, f3.y); atomicAdd(vf + 3 * v3i + 2, f3.z);
   } else {
-    M3 Ft = load_m3(st.particle_F_trial + 9 * (size_t)p);
-    M3 F = Ft;
-    float mu = md.mu[p], lam = md.lam[p];
+    M3 Ft = load_m3(st.particle_F_trial + 9 * (size_t)p), F;
+    float mu = md.mu[p], lam = md.lam[p], ys = md.yield_stress[p];
     int m = sc.material;
-    if (m == 1 || m == 5) {
-      float ys = md.yield_stress[p];
-      F = von_mises_return_mapping(Ft, ys, mu, lam, sc.hardening, sc.xi, sc.softening, m == 5);
-      md.yield_stress[p] = ys;
-      if (m == 5) { md.mu[p] = mu; md.lam[p] = lam; }
-    } else if (m == 2) {
-      F = sand_return_mapping(Ft, mu, lam, sc.alpha);
-    } else if (m == 3) {
-      F = viscoplasticity_return_mapping(Ft, md.yield_stress[p], mu, sc.plastic_viscosity, dt);
-    }
+    TradParams tp{m, sc.alpha, sc.hardening, sc.xi, sc.plastic_viscosity, sc.softening};
+    traditional_update(Ft, tp, mu, lam, ys, dt, F, stress);
+    if (m == 1 || m == 5) md.yield_stress[p] = ys;
+    if (m == 5) { md.mu[p] = mu; md.lam[p] = lam; }
     store_m3(st.particle_F + 9 * (size_t)p, F);
-    if (m == 0 || m == 1 || m == 2 || m == 3 || m == 5) {
-      float J = det(F);
-      M3 U, V;
-      V3 sig;
-      svd3(F, U, sig, V);
-      if (m == 0 || m == 5) stress = kirchhoff_FCR(F, U, V, J, mu, lam);
-      else if (m == 2) stress = kirchhoff_drucker_prager(F, U, V, sig, mu, lam);
-      else stress = kirchhoff_StVK(F, U, V, sig, mu, lam);
-      stress = 0.5f * (stress + transpose(stress));
-    }
   }
   store_m3(st.particle_stress + 9 * (size_t)p, stress);
 }

@@ -334,31 +334,14 @@ __global__ void k_stress_trad(Bufs b, Dims d, mpmhip_model_scalars sc, float dt)
   if (t >= d.n_t) return;
   int s = t + d.n_e;
   if (b.sel[s] != 0) return;
-  M3 Ft = ld9(b.tr, T_FT, t), F = Ft;
-  float mu = b.nv.at(N_MU, s), lam = b.nv.at(N_LAM, s);
+  M3 Ft = ld9(b.tr, T_FT, t), F, stress;
+  float mu = b.nv.at(N_MU, s), lam = b.nv.at(N_LAM, s), ys = b.tr.at(T_YS, t);
   int m = sc.material;
-  if (m == 1 || m == 5) {
-    float ys = b.tr.at(T_YS, t);
-    F = von_mises_return_mapping(Ft, ys, mu, lam, sc.hardening, sc.xi, sc.softening, m == 5);
-    b.tr.at(T_YS, t) = ys;
-    if (m == 5) { b.nv.at(N_MU, s) = mu; b.nv.at(N_LAM, s) = lam; }
-  } else if (m == 2) {
-    F = sand_return_mapping(Ft, mu, lam, sc.alpha);
-  } else if (m == 3) {
-    F = viscoplasticity_return_mapping(Ft, b.tr.at(T_YS, t), mu, sc.plastic_viscosity, dt);
-  }
+  TradParams tp{m, sc.alpha, sc.hardening, sc.xi, sc.plastic_viscosity, sc.softening};
+  traditional_update(Ft, tp, mu, lam, ys, dt, F, stress);
+  if (m == 1 || m == 5) b.tr.at(T_YS, t) = ys;
+  if (m == 5) { b.nv.at(N_MU, s) = mu; b.nv.at(N_LAM, s) = lam; }
   st9(b.tr, T_F, t, F);
-  M3 stress = m3_zero();
-  if (m == 0 || m == 1 || m == 2 || m == 3 || m == 5) {
-    float J = det(F);
-    M3 U, V;
-    V3 sig;
-    svd3(F, U, sig, V);
-    if (m == 0 || m == 5) stress = kirchhoff_FCR(F, U, V, J, mu, lam);
-    else if (m == 2) stress = kirchhoff_drucker_prager(F, U, V, sig, mu, lam);
-    else stress = kirchhoff_StVK(F, U, V, sig, mu, lam);
-    stress = 0.5f * (stress + transpose(stress));
-  }
   st9(b.nv, N_STRESS, s, stress);
 }
 

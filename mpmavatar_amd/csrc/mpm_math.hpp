@@ -92,35 +92,48 @@ __device__ __forceinline__ void store_v3(float *p, V3 v) { p[0] = v.x; p[1] = v.
 // s.z, |s| sorted descending -- the conventions of the McAdams routine behind wp.svd3.
 // Reference consumers: mpm_utils.py:217,265,322,369,1077.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void jacobi_pair(V3 &bp, V3 &bq, V3 &wp, V3 &wq) {
+// returns true while the pair is not yet orthogonal to fp32 resolution (drives the sweep loop's early exit)
+__device__ __forceinline__ bool jacobi_pair(V3 &bp, V3 &bq, V3 &wp, V3 &wq) {
   float app = dot(bp, bp), aqq = dot(bq, bq), apq = dot(bp, bq);
-  // skip when already orthogonal to fp32 resolution
-  bool rot = fabsf(apq) > 1e-9f * sqrtf(app * aqq);
-  float tau = (aqq - app) / (2.0f * (rot ? apq : 1.0f));
-  float t = copysignf(1.0f, tau) / (fabsf(tau) + sqrtf(1.0f + tau * tau));
-  float c = 1.0f / sqrtf(1.0f + t * t);
+  float lim = sqrtf(app * aqq);
+  bool rot = fabsf(apq) > 1e-9f * lim;
+  // v_rcp_f32 / v_rsq_f32 (1 ulp) instead of IEEE division sequences: the rotation only has to be orthonormal,
+  // which c = rsq(1 + t^2), s = c t guarantees to rounding, and Jacobi iterations are self-correcting
+  float tau = (aqq - app) * __builtin_amdgcn_rcpf(2.0f * (rot ? apq : 1.0f));
+  float t = copysignf(1.0f, tau) * __builtin_amdgcn_rcpf(fabsf(tau) + sqrtf(1.0f + tau * tau));
+  float c = __builtin_amdgcn_rsqf(1.0f + t * t);
   float s = c * t;
   c = rot ? c : 1.0f;
   s = rot ? s : 0.0f;
   V3 nbp = c * bp - s * bq, nbq = s * bp + c * bq;
   V3 nwp = c * wp - s * wq, nwq = s * wp + c * wq;
   bp = nbp; bq = nbq; wp = nwp; wq = nwq;
+  return fabsf(apq) > 4e-7f * lim;
 }
 
-__device__ __forceinline__ void cswap(bool c, V3 &a, V3 &b) {
-  V3 t = a;
+// conditional swap, component by component (a select on the V3 aggregate is lowered through scratch memory)
+__device__ __forceinline__ void cswapf(bool c, float &a, float &b) {
+  float t = a;
   a = c ? b : a;
   b = c ? t : b;
 }
+__device__ __forceinline__ void cswap(bool c, V3 &a, V3 &b) {
+  cswapf(c, a.x, b.x);
+  cswapf(c, a.y, b.y);
+  cswapf(c, a.z, b.z);
+}
 
-__device__ inline void svd3(const M3 &A, M3 &U, V3 &sig, M3 &V) {
+__device__ __forceinline__ void svd3(const M3 &A, M3 &U, V3 &sig, M3 &V) {
   V3 b0 = col0(A), b1 = col1(A), b2 = col2(A);
   V3 w0 = v3(1, 0, 0), w1 = v3(0, 1, 0), w2 = v3(0, 0, 1);
+  // cyclic sweeps; quadratic convergence: 2-3 sweeps for the near-rotations of elastic particles.  The exit test
+  // is wave-uniform (one more sweep costs less than a divergent loop).
 #pragma unroll 1
   for (int sweep = 0; sweep < 6; ++sweep) {
-    jacobi_pair(b0, b1, w0, w1);
-    jacobi_pair(b0, b2, w0, w2);
-    jacobi_pair(b1, b2, w1, w2);
+    bool big = jacobi_pair(b0, b1, w0, w1);
+    big |= jacobi_pair(b0, b2, w0, w2);
+    big |= jacobi_pair(b1, b2, w1, w2);
+    if (!__any(big)) break;
   }
   float n0 = dot(b0, b0), n1 = dot(b1, b1), n2 = dot(b2, b2);
   // sort by squared norm, descending (3-element network); count swaps to restore det V = +1
@@ -183,47 +196,36 @@ __device__ __forceinline__ M3 kirchhoff_drucker_prager(const M3 &F, const M3 &U,
 }
 
 // ---------------------------------------------------------------------------------
-// plastic return mappings, mpm_utils.py:212-399.  ys/mu/lam are the particle's model
-// entries; the von Mises variants update them in place like the reference does.
+// plastic return mappings, mpm_utils.py:212-399, in principal space.  Each takes the singular values of F_trial
+// and returns true when the elastic deformation gradient changes, with its singular values in s_new
+// (F = U diag(s_new) V^T).  Working on (U, s, V) lets the stress evaluation reuse the decomposition: the
+// reference's second svd3 of the mapped F (mpm_utils.py:1077) would return exactly (U, s_new, V).
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ M3 u_exp_vt(const M3 &U, V3 e, const M3 &V) {
-  return U * m3_diag(expf(e.x), expf(e.y), expf(e.z)) * transpose(V);
-}
-
-__device__ inline M3 von_mises_return_mapping(const M3 &Ft, float &ys, float &mu, float &lam, float hardening,
-                                              float xi, float softening, bool damage) {
-  M3 U, V;
-  V3 so;
-  svd3(Ft, U, so, V);
+__device__ __forceinline__ bool von_mises_map(V3 so, float &ys, float &mu, float &lam, float hardening, float xi,
+                                              float softening, bool damage, V3 &s_new) {
   V3 s = v3(fmaxf(so.x, 0.01f), fmaxf(so.y, 0.01f), fmaxf(so.z, 0.01f));
   V3 eps = v3(logf(s.x), logf(s.y), logf(s.z));
   float tr = eps.x + eps.y + eps.z, temp = tr / 3.0f;
   V3 tau = v3(2.0f * mu * eps.x + lam * tr, 2.0f * mu * eps.y + lam * tr, 2.0f * mu * eps.z + lam * tr);
   float st = tau.x + tau.y + tau.z;
   V3 cond = v3(tau.x - st / 3.0f, tau.y - st / 3.0f, tau.z - st / 3.0f);
-  if (length(cond) > ys) {
-    if (damage && ys <= 0.0f) return Ft;
-    V3 eh = v3(eps.x - temp, eps.y - temp, eps.z - temp);
-    float ehn = length(eh) + 1e-6f;
-    float dg = ehn - ys / (2.0f * mu);
-    V3 corr = (dg / ehn) * eh;
-    eps = eps - corr;
-    if (damage) {
-      ys = ys - softening * length(corr);
-      if (ys <= 0.0f) { mu = 0.0f; lam = 0.0f; }
-    }
-    M3 Fe = u_exp_vt(U, eps, V);
-    if (hardening == 1.0f) ys = ys + 2.0f * mu * xi * dg;
-    return Fe;
+  if (!(length(cond) > ys)) return false;
+  if (damage && ys <= 0.0f) return false;
+  V3 eh = v3(eps.x - temp, eps.y - temp, eps.z - temp);
+  float ehn = length(eh) + 1e-6f;
+  float dg = ehn - ys / (2.0f * mu);
+  V3 corr = (dg / ehn) * eh;
+  eps = eps - corr;
+  if (damage) {
+    ys = ys - softening * length(corr);
+    if (ys <= 0.0f) { mu = 0.0f; lam = 0.0f; }
   }
-  return Ft;
+  s_new = v3(expf(eps.x), expf(eps.y), expf(eps.z));
+  if (hardening == 1.0f) ys = ys + 2.0f * mu * xi * dg;
+  return true;
 }
 
-__device__ inline M3 viscoplasticity_return_mapping(const M3 &Ft, float ys, float mu, float plastic_viscosity,
-                                                    float dt) {
-  M3 U, V;
-  V3 so;
-  svd3(Ft, U, so, V);
+__device__ __forceinline__ bool viscoplastic_map(V3 so, float ys, float mu, float plastic_viscosity, float dt, V3 &s_new) {
   V3 s = v3(fmaxf(so.x, 0.01f), fmaxf(so.y, 0.01f), fmaxf(so.z, 0.01f));
   V3 b = v3(s.x * s.x, s.y * s.y, s.z * s.z);
   V3 eps = v3(logf(s.x), logf(s.y), logf(s.z));
@@ -232,33 +234,58 @@ __device__ inline M3 viscoplasticity_return_mapping(const M3 &Ft, float ys, floa
   V3 st = (2.0f * mu) * eh;
   float stn = length(st);
   float y = stn - sqrtf(2.0f / 3.0f) * ys;
-  if (y > 0.0f) {
-    float mu_hat = mu * (b.x + b.y + b.z) / 3.0f;
-    float snn = stn - y / (1.0f + plastic_viscosity / (2.0f * mu_hat * dt));
-    V3 sn = (snn / stn) * st;
-    float k = 1.0f / (2.0f * mu);
-    V3 en = v3(k * sn.x + tr / 3.0f, k * sn.y + tr / 3.0f, k * sn.z + tr / 3.0f);
-    return u_exp_vt(U, en, V);
-  }
-  return Ft;
+  if (!(y > 0.0f)) return false;
+  float mu_hat = mu * (b.x + b.y + b.z) / 3.0f;
+  float snn = stn - y / (1.0f + plastic_viscosity / (2.0f * mu_hat * dt));
+  V3 sn = (snn / stn) * st;
+  float k = 1.0f / (2.0f * mu);
+  s_new = v3(expf(k * sn.x + tr / 3.0f), expf(k * sn.y + tr / 3.0f), expf(k * sn.z + tr / 3.0f));
+  return true;
 }
 
-__device__ inline M3 sand_return_mapping(const M3 &Ft, float mu, float lam, float alpha) {
-  M3 U, V;
-  V3 sg;
-  svd3(Ft, U, sg, V);
+__device__ __forceinline__ bool sand_map(V3 sg, float mu, float lam, float alpha, V3 &s_new) {
   V3 eps = v3(logf(fmaxf(fabsf(sg.x), 1e-14f)), logf(fmaxf(fabsf(sg.y), 1e-14f)), logf(fmaxf(fabsf(sg.z), 1e-14f)));
   float tr = eps.x + eps.y + eps.z;
   V3 eh = v3(eps.x - tr / 3.0f, eps.y - tr / 3.0f, eps.z - tr / 3.0f);
   float ehn = length(eh);
   float dg = ehn + (3.0f * lam + 2.0f * mu) / (2.0f * mu) * tr * alpha;
-  M3 Fe = Ft;
-  if (dg > 0.0f && tr > 0.0f) Fe = U * transpose(V);
-  if (dg > 0.0f && tr <= 0.0f) {
-    float k = dg / ehn;
-    Fe = u_exp_vt(U, v3(eps.x - eh.x * k, eps.y - eh.y * k, eps.z - eh.z * k), V);
+  if (!(dg > 0.0f)) return false;                     // elastic (also the NaN case)
+  if (tr > 0.0f) { s_new = v3(1, 1, 1); return true; }  // expansion: F = U V^T
+  float k = dg / ehn;
+  s_new = v3(expf(eps.x - eh.x * k), expf(eps.y - eh.y * k), expf(eps.z - eh.z * k));
+  return true;
+}
+
+struct TradParams {  // MPMModelStruct scalars the traditional branch reads
+  int material;
+  float alpha, hardening, xi, plastic_viscosity, softening;
+};
+
+// compute_stress_from_F_trial for one traditional particle (mpm_utils.py:1047-1103) with a single SVD:
+// F_trial -> (F, stress); mu / lam / ys are updated in place for the damage / hardening models.
+__device__ __forceinline__ void traditional_update(const M3 &Ft, const TradParams &tp, float &mu, float &lam, float &ys,
+                                                   float dt, M3 &F, M3 &stress) {
+  int m = tp.material;
+  F = Ft;
+  stress = m3_zero();
+  if (!(m == 0 || m == 1 || m == 2 || m == 3 || m == 5)) return;  // snow / neo-hookean / cloth: F <- F_trial, stress 0 (quirk Q4)
+  M3 U, V;
+  V3 sig;
+  svd3(Ft, U, sig, V);
+  V3 sn = sig;
+  bool changed = false;
+  if (m == 1 || m == 5) changed = von_mises_map(sig, ys, mu, lam, tp.hardening, tp.xi, tp.softening, m == 5, sn);
+  else if (m == 2) changed = sand_map(sig, mu, lam, tp.alpha, sn);
+  else if (m == 3) changed = viscoplastic_map(sig, ys, mu, tp.plastic_viscosity, dt, sn);
+  if (changed) {
+    F = U * m3_diag(sn.x, sn.y, sn.z) * transpose(V);
+    sig = sn;
   }
-  return Fe;
+  float J = det(F);
+  if (m == 0 || m == 5) stress = kirchhoff_FCR(F, U, V, J, mu, lam);
+  else if (m == 2) stress = kirchhoff_drucker_prager(F, U, V, sig, mu, lam);
+  else stress = kirchhoff_StVK(F, U, V, sig, mu, lam);
+  stress = 0.5f * (stress + transpose(stress));
 }
 
 // ---------------------------------------------------------------------------------
