@@ -43,6 +43,28 @@ def phase_bytes(sc, n_active, n_coll, n_mov):
     }
 
 
+PHASE_KERNELS = {"p2g": ["k_p2g"], "g2p_v": ["k_g2p", "k_g2p_escaped"], "grid_update": ["k_grid"],
+                 "compute_stress_from_F_trial": ["k_stress_elem<true>", "k_stress_trad"], "g2p_e": ["k_elem_finalize"]}
+
+
+def pmc_traffic(phase, workload):
+    """HBM bytes per launch of a phase's kernels from the newest committed PMC summary (profiles/*_pmc.json, written by
+    tools/summarize_prof.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command; reads
+    carry the gfx950 x2 correction).  PMC counters cannot be collected from inside the process, so this is the profile of
+    the same workload, not of this very run; returns (None, None) when no profile of the workload is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files or workload != "sheet-500k":
+        return None, None
+    prof = json.load(open(files[-1]))
+    tot = 0.0
+    for k in PHASE_KERNELS.get(phase, []):
+        e = prof["kernels"].get(k)
+        if e:
+            tot += e["hbm_read_bytes"] + e["hbm_write_bytes"]
+    return (tot or None), os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(sc, budget_s=20.0):
     """Time the CPU oracle (OpenMP build, all host cores) on a bounded number of substeps of the same scene."""
     from oracle.scene_adapter import oracle_from_scene, run_scene
@@ -163,8 +185,9 @@ def main():
                 kernels.append(k)
             out["kernels"] = kernels
             dom = max((k for k in kernels if "alg_bytes" in k), key=lambda k: k["ms"])
+            traffic, src = pmc_traffic(dom["name"], args.scene)
             out["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": dom["frac"], "traffic": None,
+                               "unit": "GB/s", "frac": dom["frac"], "traffic": traffic, "traffic_source": src,
                                "alg_bytes_per_launch": dom["alg_bytes"], "ms_per_launch": dom["ms"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sc)

@@ -13,13 +13,13 @@ rows = list(csv.DictReader(open(f"{src}/fast_kernel_stats.csv")))
 out.append(f"# rocprofv3 --kernel-trace --stats  (bench.py --steps 200 --warmup 40, sheet-500k, fast mode) [{tag}]\n")
 out.append("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|")
 for r in rows[:16]:
-    m = re.search(r"\b(k_\w+)\(", r["Name"])
+    m = re.search(r"\b(k_\w+(?:<[^>]*>)?)\(", r["Name"])
     name = m.group(1) if m else re.sub(r"[<(].*", "", r["Name"])
     out.append(f"| {name[:60]} | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(f"{src}/pmc_*/pmc_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
-        m = re.search(r"\b(k_\w+)\(", row["Kernel_Name"])
+        m = re.search(r"\b(k_\w+(?:<[^>]*>)?)\(", row["Kernel_Name"])
         if m:
             agg[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
 if agg:
@@ -35,6 +35,13 @@ if agg:
         hit = a.get("TCC_HIT_sum", 0); miss = a.get("TCC_MISS_sum", 0)
         out.append(f"| {k} | {a.get('FETCH_SIZE',0):.0f} | {a.get('WRITE_SIZE',0):.0f} | {2*a.get('FETCH_SIZE',0)/1024:.1f} | {a.get('WRITE_SIZE',0)/1024:.1f} | "
                    f"{100*hit/max(hit+miss,1):.0f} | {a.get('SQ_INSTS_VALU',0):.0f} | {a.get('SQ_INSTS_LDS',0):.0f} | {a.get('SQ_WAVE_CYCLES',0):.0f} | {a.get('SQ_WAIT_ANY',0):.0f} |")
+pmc = {k: {c: sum(x) / len(x) for c, x in v.items()} for k, v in agg.items() if "FETCH_SIZE" in v}
+if pmc:
+    # machine-readable per-launch HBM traffic for bench.py's roofline.traffic (bytes; reads = 2 x FETCH_SIZE KiB, see above)
+    json.dump({"tag": tag, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), sheet-500k fast mode",
+               "kernels": {k: {"hbm_read_bytes": 2 * a.get("FETCH_SIZE", 0) * 1024, "hbm_write_bytes": a.get("WRITE_SIZE", 0) * 1024,
+                               "launches_sampled": len(agg[k]["FETCH_SIZE"])} for k, a in pmc.items()}},
+              open(f"profiles/{tag}_pmc.json", "w"), indent=1)
 open(f"profiles/{tag}_rocprof_summary.md", "w").write("\n".join(out) + "\n")
 for name in ("bench_fast.json", "bench_baseline.json"):
     p = f"gpurun_out/{name}"
