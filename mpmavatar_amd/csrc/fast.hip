@@ -131,33 +131,37 @@ __global__ void k_import(mpmhip_state_ptrs st, mpmhip_model_ptrs md, Bufs b, con
 // rebuilt in sorted index space at each re-sort.  Replaces the 9 scattered fp32 atomics per element of
 // kirchoff_stress_Anisotropy (mpm_utils.py:173-175): scattered global atomics run at ~21 G/s on MI355X.
 struct VAdj {
-  const int *adj;    // [K][n_v]: (element_slot << 2) | corner, -1 = empty
-  const float *ef;   // [6][n_e]: f2.xyz, f3.xyz per element (sorted slots)
+  const int *adj;     // [K][n_v]: (element_slot << 2) | corner, -1 = empty
+  const float4 *ef;   // [3][n_e] corner forces f1, f2, f3 (xyz, w unused) per element + one zero entry at 3*n_e
   int K, n_v, n_e;
 };
+// One incidence = one 16-byte load: entry (e, c) reads ef[c*n_e + e]; empty entries read the zero slot, so there is no
+// branch and all loads of a batch are in flight together.
+constexpr int ADJ_BATCH = 8;
+struct AdjBatch { int ent[ADJ_BATCH]; };
+__device__ __forceinline__ AdjBatch adj_load(const VAdj &a, int vl, int k0) {
+  AdjBatch r;
+#pragma unroll
+  for (int u = 0; u < ADJ_BATCH; ++u) r.ent[u] = (k0 + u < a.K) ? a.adj[(size_t)(k0 + u) * a.n_v + vl] : -1;
+  return r;
+}
+__device__ __forceinline__ V3 adj_gather(const VAdj &a, const AdjBatch &r, V3 f) {
+#pragma unroll
+  for (int h = 0; h < ADJ_BATCH; h += 4) {  // four 16-byte loads in flight at a time (register budget of p2g)
+    float4 g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int ent = r.ent[h + u];
+      g[u] = a.ef[ent < 0 ? 3 * a.n_e : (ent & 3) * a.n_e + (ent >> 2)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) f = f + v3(g[u].x, g[u].y, g[u].z);
+  }
+  return f;
+}
 __device__ __forceinline__ V3 vertex_force(const VAdj &a, int vl) {
   V3 f = v3(0, 0, 0);
-  // batches of 4 incident elements with all loads issued up front (no data-dependent early exit: a serial
-  // adj -> ef -> adj -> ef chain costs two memory latencies per incident element)
-  for (int k0 = 0; k0 < a.K; k0 += 4) {
-    int ent[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) ent[u] = (k0 + u < a.K) ? a.adj[(size_t)(k0 + u) * a.n_v + vl] : -1;
-    V3 f2[4], f3[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int e = ent[u] >> 2, c = ent[u] & 3;
-      f2[u] = v3(0, 0, 0);
-      f3[u] = v3(0, 0, 0);
-      if (ent[u] >= 0 && c != 2) f2[u] = v3(a.ef[e], a.ef[a.n_e + e], a.ef[2 * a.n_e + e]);
-      if (ent[u] >= 0 && c != 1) f3[u] = v3(a.ef[3 * a.n_e + e], a.ef[4 * a.n_e + e], a.ef[5 * a.n_e + e]);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int c = ent[u] & 3;
-      if (ent[u] >= 0) f = f + (c == 0 ? -1.0f * (f2[u] + f3[u]) : (c == 1 ? f2[u] : f3[u]));
-    }
-  }
+  for (int k0 = 0; k0 < a.K; k0 += ADJ_BATCH) f = adj_gather(a, adj_load(a, vl, k0), f);
   return f;
 }
 
@@ -284,12 +288,12 @@ __global__ void k_dilate(const int *plist, int n_P, int NB, int *ab_flag) {
 // director matrix less per substep.  The host runs the stand-alone k_elem_finalize instead whenever something needs
 // finished elements earlier (re-sort, read-back, pre-p2g operations, joint-face splats, multi-GPU ghosts).
 template <bool FINALIZE>
-__global__ void k_stress_elem(Bufs b, float *ef, Dims d, float friction_coeff, const int *face_slot,
+__global__ void k_stress_elem(Bufs b, float4 *ef, Dims d, float friction_coeff, const int *face_slot,
                               const unsigned *skeys, int blk_bits, int *counters) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.n_e) return;
   if (b.sel[e] == 1) {  // not simulated (selection == 2 marks a ghost copy: stress yes, transfers no)
-    for (int c = 0; c < 6; ++c) ef[c * d.n_e + e] = 0.0f;
+    for (int c = 0; c < 3; ++c) ef[c * d.n_e + e] = make_float4(0, 0, 0, 0);
     return;
   }
   M3 dm;
@@ -324,9 +328,9 @@ __global__ void k_stress_elem(Bufs b, float *ef, Dims d, float friction_coeff, c
   kirchhoff_anisotropy(q, r02, r12, r22, d3, ld3(b.el, E_RINV, e), b.nv.at(N_VOL, e), b.nv.at(N_MU, e),
                        b.nv.at(N_LAM, e), gamma, kappa, stress, f1, f2, f3);
   st9(b.nv, N_STRESS, e, stress);
-  (void)f1;
-  ef[e] = f2.x; ef[d.n_e + e] = f2.y; ef[2 * d.n_e + e] = f2.z;
-  ef[3 * d.n_e + e] = f3.x; ef[4 * d.n_e + e] = f3.y; ef[5 * d.n_e + e] = f3.z;
+  ef[e] = make_float4(f1.x, f1.y, f1.z, 0.0f);
+  ef[d.n_e + e] = make_float4(f2.x, f2.y, f2.z, 0.0f);
+  ef[2 * d.n_e + e] = make_float4(f3.x, f3.y, f3.z, 0.0f);
 }
 
 __global__ void k_stress_trad(Bufs b, Dims d, mpmhip_model_scalars sc, float dt) {
@@ -367,8 +371,10 @@ __device__ __forceinline__ int tile_idx(int i, int j, int k) { return i * TS_I +
 
 // One chunk = up to 256 particles of ONE particle block, all three classes packed back to back (elements, then
 // traditional, then vertices) so that lanes stay filled; lane t of chunk k takes combined index k*256 + t.
-struct ChunkMap {
-  int e0, ne, t0, nt, v0, nv;
+// The record is self-contained (32 bytes, one scalar load): a chunks -> plist -> ranges chain of three dependent
+// loads in front of every particle load was a measurable part of p2g / g2p (both start with nothing else to do).
+struct ChunkRec {
+  int blk, chunk, e0, ne, t0, nt, v0, nv;
   __device__ __forceinline__ bool map(int ci, int &cls, int &s) const {
     if (ci < ne) { cls = 0; s = e0 + ci; return true; }
     ci -= ne;
@@ -378,12 +384,208 @@ struct ChunkMap {
     return false;
   }
 };
-__device__ __forceinline__ ChunkMap chunk_map(const int *ranges, int n_P, int slot) {
-  ChunkMap m;
-  m.e0 = ranges[0 * n_P + slot]; m.ne = ranges[1 * n_P + slot] - m.e0;
-  m.t0 = ranges[2 * n_P + slot]; m.nt = ranges[3 * n_P + slot] - m.t0;
-  m.v0 = ranges[4 * n_P + slot]; m.nv = ranges[5 * n_P + slot] - m.v0;
-  return m;
+
+// ------------------------------------------------------------------------------------------------
+// body-face splat (compute_mesh, mpm_solver.py:829-880) and joint splat (:677-788) into active blocks
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool splat_ok(int G, const Stencil &s) {
+  return s.bx >= 0 && s.bx < G - 3 && s.by >= 0 && s.by < G - 3 && s.bz >= 0 && s.bz < G - 3;
+}
+
+// Body-mesh collider (compute_mesh, mpm_solver.py:829-880) with the same LDS-tile structure as p2g.  Faces are
+// binned by grid block at each re-sort (rocPRIM sort of the centroid's block key).  Per substep one wavefront per
+// ACTIVE block takes the faces binned there (lane = face: centroid, mean vertex velocity, unit normal with the
+// caller's mesh advection applied), accumulates weight / weight*velocity / weight*normal into a 7-channel fp64
+// LDS tile with ds_add_f64 and flushes the touched nodes to the block-major collider channels with coalesced
+// atomics.  Faces in blocks outside the active list cannot reach a node that carries mass and are skipped; a
+// face that drifted out of its tile margin since the last re-sort falls back to global atomics.
+// (Tried and dropped: gathering the faces per node block inside the grid stage -- no atomics at all, but the few
+// wavefronts next to the body serialise ~50 faces x 60 dependent instructions each and set the kernel's tail.)
+constexpr int COL_CH = 7;
+
+__device__ __forceinline__ int face_block(V3 fp, const Dims &d) {
+  int bx = (int)(fp.x * d.inv_dx - 0.5f), by = (int)(fp.y * d.inv_dx - 0.5f), bz = (int)(fp.z * d.inv_dx - 0.5f);
+  bx = min(max(bx, 0), d.G - 1); by = min(max(by, 0), d.G - 1); bz = min(max(bz, 0), d.G - 1);
+  return blk_of(bx, by, bz, d.NB);
+}
+__device__ __forceinline__ V3 face_centroid(const float *pts, const float *vel, float adv, const int32_t *idx, int f,
+                                            V3 &p0, V3 &p1, V3 &p2) {
+  int i0 = idx[3 * f], i1 = idx[3 * f + 1], i2 = idx[3 * f + 2];
+  p0 = mesh_point(pts, vel, adv, i0); p1 = mesh_point(pts, vel, adv, i1); p2 = mesh_point(pts, vel, adv, i2);
+  return v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
+}
+
+__global__ void k_face_keys(const float *pts, const float *vel, float adv, const int32_t *idx, int n_f, Dims d,
+                            unsigned *keys, int *iota) {
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_f) return;
+  V3 p0, p1, p2;
+  keys[f] = (unsigned)face_block(face_centroid(pts, vel, adv, idx, f, p0, p1, p2), d);
+  iota[f] = f;
+}
+
+__global__ void k_face_bins(const unsigned *skeys, int n_f, int *fb_start, int *fb_cnt) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_f) return;
+  unsigned k = skeys[j];
+  if (j == 0 || skeys[j - 1] != k) fb_start[k] = j;
+  atomicAdd(fb_cnt + k, 1);
+}
+
+// non-empty face bins that lie on the active list (order irrelevant), as self-contained records
+struct FaceBin { int blk, start, cnt, pad; };
+__global__ void k_fbin_compact(const int *alist, int n_A, const int *fb_start, const int *fb_cnt, FaceBin *list, int *counter) {
+  int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n_A) return;
+  int blk = alist[a];
+  int cnt = fb_cnt[blk];
+  if (cnt > 0) list[atomicAdd(counter, 1)] = FaceBin{blk, fb_start[blk], cnt, 0};
+}
+// vertex ids of the faces in bin order (one indirection less per substep)
+__global__ void k_face_sorted_idx(const int32_t *idx, const int *order, int n_f, int *fidx) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_f) return;
+  int f = order[j];
+  fidx[3 * j] = idx[3 * f]; fidx[3 * j + 1] = idx[3 * f + 1]; fidx[3 * j + 2] = idx[3 * f + 2];
+}
+
+// Joint splat (add_velocity_{traditional,verts,faces}, mpm_solver.py:677-788) as ONE launch: 32 lanes per joint
+// particle, lane = stencil node (27 used), so every thread has a single short dependency chain instead of a 27-trip
+// loop of dependent loads.  Group 0: the last n_t traditional particles, group 1: the first n_v vertices, group 2:
+// the first n_f elements (caller-order indices; inv[] maps them to sorted slots).
+struct JointSplatArgs {
+  const float *vel_t, *vel_v, *vel_f;
+  int n_t, n_v, n_f;
+  int off_t, off_v;  // caller-order index of the first particle of group 0 / group 1 (group 2 starts at 0)
+  const int *inv;    // caller order -> sorted slot
+};
+__device__ __forceinline__ void mover_splat_wg(const Bufs &b, const JointSplatArgs &js, int wg, const Dims &d,
+                                               const GridPtrs &g) {
+  const int *inv = js.inv;
+  int t = wg * TPB + (int)threadIdx.x;
+  int q = t >> 5, nn = t & 31;
+  if (nn >= 27 || q >= js.n_t + js.n_v + js.n_f) return;
+  const float *vel;
+  int orig;
+  if (q < js.n_t) { vel = js.vel_t + 3 * (size_t)q; orig = js.off_t + q; }
+  else if (q < js.n_t + js.n_v) { vel = js.vel_v + 3 * (size_t)(q - js.n_t); orig = js.off_v + (q - js.n_t); }
+  else { vel = js.vel_f + 3 * (size_t)(q - js.n_t - js.n_v); orig = q - js.n_t - js.n_v; }
+  Stencil s = make_stencil(ld3(b.all, A_X, inv[orig]), d.inv_dx);
+  if (!splat_ok(d.G, s)) return;  // mpm_solver.py:692,730,767
+  int i = nn / 9, j = (nn / 3) % 3, k = nn % 3;
+  float w = sel3(i, s.w0.x, s.w1.x, s.w2.x) * sel3(j, s.w0.y, s.w1.y, s.w2.y) * sel3(k, s.w0.z, s.w1.z, s.w2.z);
+  int x = s.bx + i, y = s.by + j, z = s.bz + k;
+  int blk = blk_of(x, y, z, d.NB);
+  if (!g.ab_flag[blk]) { atomicAdd(g.counters + 1, 1); return; }
+  V3 pv = load_v3(vel);
+  float *p = g.mov + ((size_t)blk * GCH_MOV) * 64 + loc_of(x, y, z);
+  atomicAdd(p, w);
+  atomicAdd(p + 64, w * pv.x); atomicAdd(p + 128, w * pv.y); atomicAdd(p + 192, w * pv.z);
+}
+
+// The two splats are small, latency-bound and independent of the particle transfer, so they ride along in the p2g
+// LAUNCH as extra workgroups (k_p2g: blockIdx < n_extra) instead of being kernels of their own: as separate launches
+// they either sit on the critical path (17 us) or, on a side stream, cost two cross-queue barrier packets per
+// substep (~6 us of idle GPU each, measured with rocprofv3 --kernel-trace).
+struct SplatArgs {
+  const float *pts, *vel;  // body mesh at this substep: pts + adv * vel
+  float adv;
+  const int *fidx;         // [n_f][3] vertex ids in bin order
+  const FaceBin *fbins;
+  int n_fbins;             // workgroups [0, n_fbins): one face bin each
+  JointSplatArgs js;       // workgroups [n_fbins, n_fbins + n_mov_wg): joints
+  int n_mov_wg;
+  int n_extra;             // n_fbins + n_mov_wg rounded up to a multiple of 8 (keeps the XCD mapping of the chunks)
+};
+
+// PASS 0: weight + weight*velocity (collider channels 0..3), PASS 1: weight*normal (channels 4..6); both passes use
+// the 4-channel fp64 tile of p2g.
+template <int PASS>
+__device__ __forceinline__ void col_splat_pass(double *tile, const FaceBin &fb, const SplatArgs &sa, int ox, int oy, int oz,
+                                               int bx, int by, int bz, unsigned long long act_mask, const Dims &d,
+                                               const GridPtrs &g) {
+  constexpr int NCH = PASS == 0 ? 4 : 3;
+  const int l = threadIdx.x;
+  for (int t = l; t < NCH * TILE_PAD; t += TPB) tile[t] = 0.0;
+  __syncthreads();
+  for (int jj = fb.start + l; jj < fb.start + fb.cnt; jj += TPB) {
+    int i0 = sa.fidx[3 * jj], i1 = sa.fidx[3 * jj + 1], i2 = sa.fidx[3 * jj + 2];
+    V3 p0 = mesh_point(sa.pts, sa.vel, sa.adv, i0), p1 = mesh_point(sa.pts, sa.vel, sa.adv, i1), p2 = mesh_point(sa.pts, sa.vel, sa.adv, i2);
+    V3 fp = v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
+    Stencil s = make_stencil(fp, d.inv_dx);
+    if (!splat_ok(d.G, s)) continue;  // mpm_solver.py:858
+    V3 a, fn;
+    {
+      V3 u0 = load_v3(sa.vel + 3 * i0), u1 = load_v3(sa.vel + 3 * i1), u2 = load_v3(sa.vel + 3 * i2);
+      a = v3((u0.x + u1.x + u2.x) / 3.0f, (u0.y + u1.y + u2.y) / 3.0f, (u0.z + u1.z + u2.z) / 3.0f);
+      fn = normalize(cross(p1 - p0, p2 - p0));  // wp.mesh_eval_face_normal
+    }
+    int lx = s.bx - ox, ly = s.by - oy, lz = s.bz - oz;
+    bool in_tile = !((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u);
+    int base = tile_idx(lx, ly, lz);
+    int n = l % 27, i = n / 9, j = (n / 3) % 3, k = n % 3;  // staggered start: neighbouring faces share nodes
+#pragma unroll 3
+    for (int t = 0; t < 27; ++t) {
+      float w = sel3(i, s.w0.x, s.w1.x, s.w2.x) * sel3(j, s.w0.y, s.w1.y, s.w2.y) * sel3(k, s.w0.z, s.w1.z, s.w2.z);
+      if (in_tile) {
+        double *p = tile + base + tile_idx(i, j, k);
+        if (PASS == 0) {
+          atomicAdd(p, (double)w);
+          atomicAdd(p + TILE_PAD, (double)(w * a.x)); atomicAdd(p + 2 * TILE_PAD, (double)(w * a.y));
+          atomicAdd(p + 3 * TILE_PAD, (double)(w * a.z));
+        } else {
+          atomicAdd(p, (double)(w * fn.x)); atomicAdd(p + TILE_PAD, (double)(w * fn.y));
+          atomicAdd(p + 2 * TILE_PAD, (double)(w * fn.z));
+        }
+      } else if (PASS == 0) {  // drifted out of the tile margin since the faces were binned
+        g.counters[6] = 1;
+        int x = s.bx + i, y = s.by + j, z = s.bz + k;
+        int nb = blk_of(x, y, z, d.NB);
+        if (g.ab_flag[nb]) {
+          float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
+          atomicAdd(p, w);
+          atomicAdd(p + 64, w * a.x); atomicAdd(p + 128, w * a.y); atomicAdd(p + 192, w * a.z);
+          atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
+        }
+      }
+      if (++k == 3) { k = 0; if (++j == 3) { j = 0; if (++i == 3) i = 0; } }
+    }
+  }
+  __syncthreads();
+  for (int t = l; t < TILE3; t += TPB) {
+    int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
+    const double *q = tile + tile_idx(ti, tj, tk);
+    float c0 = (float)q[0], c1 = (float)q[TILE_PAD], c2 = (float)q[2 * TILE_PAD];
+    float c3 = PASS == 0 ? (float)q[3 * TILE_PAD] : 0.0f;
+    if (PASS == 0 ? c0 == 0.0f : (c0 == 0.0f && c1 == 0.0f && c2 == 0.0f)) continue;
+    int x = ox + ti, y = oy + tj, z = oz + tk;
+    if (!in_grid(x, y, z, d.G)) continue;
+    int nb = blk_of(x, y, z, d.NB);
+    int nidx = (((x >> 2) - bx + 1) * 3 + ((y >> 2) - by + 1)) * 3 + ((z >> 2) - bz + 1);
+    if (!((act_mask >> nidx) & 1ull)) continue;  // inactive block: never read by g2p, never re-zeroed
+    float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z) + (PASS == 0 ? 0 : 256);
+    atomicAdd(p, c0); atomicAdd(p + 64, c1); atomicAdd(p + 128, c2);
+    if (PASS == 0) atomicAdd(p + 192, c3);
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, int bin, const Dims &d, const GridPtrs &g) {
+  const FaceBin fb = sa.fbins[bin];
+  int blk = fb.blk;
+  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
+  int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
+  // active flags of the 27 blocks the tile overlaps (lane n < 27 of every wavefront -> neighbour n)
+  bool nb_act = false;
+  int l = threadIdx.x & 63;
+  if (l < 27) {
+    int x = bx + l / 9 - 1, y = by + (l / 3) % 3 - 1, z = bz + l % 3 - 1;
+    if ((unsigned)x < (unsigned)d.NB && (unsigned)y < (unsigned)d.NB && (unsigned)z < (unsigned)d.NB)
+      nb_act = g.ab_flag[(x * d.NB + y) * d.NB + z] != 0;
+  }
+  unsigned long long act_mask = __ballot(nb_act);
+  col_splat_pass<0>(tile, fb, sa, ox, oy, oz, bx, by, bz, act_mask, d, g);
+  col_splat_pass<1>(tile, fb, sa, ox, oy, oz, bx, by, bz, act_mask, d, g);
 }
 
 struct P2GParticle {
@@ -402,22 +604,65 @@ __device__ __forceinline__ P2GParticle p2g_zero(int ox, int oy, int oz, const Di
   return q;
 }
 
-__device__ __forceinline__ P2GParticle p2g_load(const Bufs &b, const VAdj &va, int cls, int s, const Dims &d, float rpic,
-                                                float dt) {
+// All global loads of a particle are issued before anything waits on them: x, mass, C, v for every lane, stress / vol
+// when the wavefront holds any element or traditional particle, the first ADJ_BATCH adjacency entries when it holds
+// any vertex (wave-uniform branches; lanes of the other class read slot 0 and are masked afterwards).  The
+// per-class `if` ladder this replaces serialised stress -> adjacency -> corner-force latencies.
+struct P2GRaw {
+  V3 x, v;
+  float mass, vol;
+  M3 C, S;
+  AdjBatch ab;
+};
+__device__ __forceinline__ P2GRaw p2g_issue(const Bufs &b, const VAdj &va, bool valid, int cls, int s, const Dims &d,
+                                            bool w_nv, bool w_v) {
+  P2GRaw r;
+  int sa = valid ? s : 0;
+  r.x = ld3(b.all, A_X, sa);
+  r.mass = b.all.at(A_MASS, sa);
+  r.C = ld9(b.all, A_C, sa);
+  r.v = ld3(b.all, A_V, sa);
+  r.S = m3_zero();
+  r.vol = 1.0f;
+  if (w_nv) {
+    int sn = (valid && cls != 2) ? s : 0;
+    r.S = ld9(b.nv, N_STRESS, sn);
+    r.vol = b.nv.at(N_VOL, sn);
+  }
+#pragma unroll
+  for (int u = 0; u < ADJ_BATCH; ++u) r.ab.ent[u] = -1;
+  if (w_v) r.ab = adj_load(va, (valid && cls == 2) ? s - d.n_nv : 0, 0);
+  return r;
+}
+__device__ __forceinline__ P2GParticle p2g_finish(const P2GRaw &r, const VAdj &va, bool valid, int cls, int s,
+                                                  const Dims &d, float rpic, float dt, bool w_v, const P2GParticle &zero) {
+  V3 vf = v3(0, 0, 0);
+  if (w_v) {
+    vf = adj_gather(va, r.ab, vf);
+    int vl = (valid && cls == 2) ? s - d.n_nv : 0;
+    for (int k0 = ADJ_BATCH; k0 < va.K; k0 += ADJ_BATCH) vf = adj_gather(va, adj_load(va, vl, k0), vf);
+  }
+  if (!valid) return zero;
   P2GParticle q;
-  q.s = make_stencil(ld3(b.all, A_X, s), d.inv_dx);
-  q.mass = b.all.at(A_MASS, s);
-  M3 C = ld9(b.all, A_C, s);
+  q.s = make_stencil(r.x, d.inv_dx);
+  q.mass = r.mass;
+  M3 C = r.C;
   C = (1.0f - rpic) * C + (rpic / 2.0f) * (C - transpose(C));  // mpm_utils.py:530-532
   if (rpic < -0.001f) C = m3_zero();
-  q.a0 = ld3(b.all, A_V, s) - d.dx * (C * q.s.fx);
+  q.a0 = r.v - d.dx * (C * q.s.fx);
   q.Cdx = d.dx * C;
   q.Sdt = m3_zero();
   q.vfdt = v3(0, 0, 0);
-  if (cls == 0) q.Sdt = (-dt * d.inv_dx) * ld9(b.nv, N_STRESS, s);
-  else if (cls == 1) q.Sdt = (-dt * d.inv_dx * b.nv.at(N_VOL, s)) * ld9(b.nv, N_STRESS, s);
-  else q.vfdt = dt * vertex_force(va, s - d.n_nv);
+  if (cls == 0) q.Sdt = (-dt * d.inv_dx) * r.S;
+  else if (cls == 1) q.Sdt = (-dt * d.inv_dx * r.vol) * r.S;
+  else q.vfdt = dt * vf;
   return q;
+}
+// slow-path loader (escaped particles)
+__device__ __forceinline__ P2GParticle p2g_load(const Bufs &b, const VAdj &va, int cls, int s, const Dims &d, float rpic,
+                                                float dt) {
+  P2GRaw r = p2g_issue(b, va, true, cls, s, d, cls != 2, cls == 2);
+  return p2g_finish(r, va, true, cls, s, d, rpic, dt, cls == 2, P2GParticle{});
 }
 
 // ---- wave-level pre-reduction -------------------------------------------------------------------------
@@ -519,26 +764,33 @@ __device__ __forceinline__ void p2g_escaped(const Bufs &b, const VAdj &va, int c
   }
 }
 
-__global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const int *plist, const int *ranges,
-                                             const int *chunks, int n_chunks, int n_P, Dims d, float rpic, float dt,
-                                             GridPtrs g) {
+__global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *recs, int n_chunks, Dims d, float rpic,
+                                             float dt, GridPtrs g, SplatArgs sa) {
   __shared__ double tile[4 * TILE_PAD];
   __shared__ int esc[CHUNK];
   __shared__ int esc_n;
-  int w = xcd_slice(blockIdx.x, n_chunks);
+  if ((int)blockIdx.x < sa.n_extra) {  // extra workgroups first: they are the long-latency ones
+    int e = blockIdx.x;
+    if (e < sa.n_fbins) col_splat_wg(tile, sa, e, d, g);
+    else if (e < sa.n_fbins + sa.n_mov_wg) mover_splat_wg(b, sa.js, e - sa.n_fbins, d, g);
+    return;
+  }
+  int w = xcd_slice((int)blockIdx.x - sa.n_extra, n_chunks);
   if (w < 0) return;
-  int slot = chunks[2 * w], chunk = chunks[2 * w + 1];
-  int blk = plist[slot];
+  const ChunkRec cm = recs[w];
+  int blk = cm.blk, chunk = cm.chunk;
   int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
   int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
-  ChunkMap cm = chunk_map(ranges, n_P, slot);
   int cls = 0, s = 0;
   bool valid = cm.map(chunk * CHUNK + (int)threadIdx.x, cls, s);
   // issue the particle loads before the tile is cleared so that their latency overlaps
-  P2GParticle q = p2g_zero(ox, oy, oz, d);
-  if (valid) q = p2g_load(b, va, cls, s, d, rpic, dt);
+  bool w_nv = __any(valid && cls != 2), w_v = __any(valid && cls == 2);
+  if (g.dbg & 8) w_v = false;
+  if (g.dbg & 16) w_nv = false;
+  P2GRaw raw = p2g_issue(b, va, valid, cls, s, d, w_nv, w_v);
   for (int t = threadIdx.x; t < 4 * TILE_PAD; t += TPB) tile[t] = 0.0;
   if (threadIdx.x == 0) esc_n = 0;
+  P2GParticle q = p2g_finish(raw, va, valid, cls, s, d, rpic, dt, w_v, p2g_zero(ox, oy, oz, d));
   __syncthreads();
   int key = -2 - (int)(threadIdx.x & 63), base = 0;
   if (valid) {
@@ -610,169 +862,6 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const int *plist, 
     atomicAdd(p, m);
     atomicAdd(p + 64, px); atomicAdd(p + 128, py); atomicAdd(p + 192, pz);
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// body-face splat (compute_mesh, mpm_solver.py:829-880) and joint splat (:677-788) into active blocks
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool splat_ok(int G, const Stencil &s) {
-  return s.bx >= 0 && s.bx < G - 3 && s.by >= 0 && s.by < G - 3 && s.bz >= 0 && s.bz < G - 3;
-}
-
-// Body-mesh collider (compute_mesh, mpm_solver.py:829-880) with the same LDS-tile structure as p2g.  Faces are
-// binned by grid block at each re-sort (rocPRIM sort of the centroid's block key).  Per substep one wavefront per
-// ACTIVE block takes the faces binned there (lane = face: centroid, mean vertex velocity, unit normal with the
-// caller's mesh advection applied), accumulates weight / weight*velocity / weight*normal into a 7-channel fp64
-// LDS tile with ds_add_f64 and flushes the touched nodes to the block-major collider channels with coalesced
-// atomics.  Faces in blocks outside the active list cannot reach a node that carries mass and are skipped; a
-// face that drifted out of its tile margin since the last re-sort falls back to global atomics.
-// (Tried and dropped: gathering the faces per node block inside the grid stage -- no atomics at all, but the few
-// wavefronts next to the body serialise ~50 faces x 60 dependent instructions each and set the kernel's tail.)
-constexpr int COL_CH = 7;
-
-__device__ __forceinline__ int face_block(V3 fp, const Dims &d) {
-  int bx = (int)(fp.x * d.inv_dx - 0.5f), by = (int)(fp.y * d.inv_dx - 0.5f), bz = (int)(fp.z * d.inv_dx - 0.5f);
-  bx = min(max(bx, 0), d.G - 1); by = min(max(by, 0), d.G - 1); bz = min(max(bz, 0), d.G - 1);
-  return blk_of(bx, by, bz, d.NB);
-}
-__device__ __forceinline__ V3 face_centroid(const float *pts, const float *vel, float adv, const int32_t *idx, int f,
-                                            V3 &p0, V3 &p1, V3 &p2) {
-  int i0 = idx[3 * f], i1 = idx[3 * f + 1], i2 = idx[3 * f + 2];
-  p0 = mesh_point(pts, vel, adv, i0); p1 = mesh_point(pts, vel, adv, i1); p2 = mesh_point(pts, vel, adv, i2);
-  return v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
-}
-
-__global__ void k_face_keys(const float *pts, const float *vel, float adv, const int32_t *idx, int n_f, Dims d,
-                            unsigned *keys, int *iota) {
-  int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= n_f) return;
-  V3 p0, p1, p2;
-  keys[f] = (unsigned)face_block(face_centroid(pts, vel, adv, idx, f, p0, p1, p2), d);
-  iota[f] = f;
-}
-
-__global__ void k_face_bins(const unsigned *skeys, int n_f, int *fb_start, int *fb_cnt) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_f) return;
-  unsigned k = skeys[j];
-  if (j == 0 || skeys[j - 1] != k) fb_start[k] = j;
-  atomicAdd(fb_cnt + k, 1);
-}
-
-// non-empty face bins that lie on the active list (order irrelevant)
-__global__ void k_fbin_compact(const int *alist, int n_A, const int *fb_cnt, int *list, int *counter) {
-  int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= n_A) return;
-  int blk = alist[a];
-  if (fb_cnt[blk] > 0) list[atomicAdd(counter, 1)] = blk;
-}
-
-__global__ __launch_bounds__(64) void k_col_splat(const float *pts, const float *vel, float adv, const int32_t *idx,
-                                                  const int *order, const int *fb_start, const int *fb_cnt,
-                                                  const int *fbins, int n_fbins, Dims d, GridPtrs g) {
-  __shared__ double tile[COL_CH * TILE_PAD];
-  if ((int)blockIdx.x >= n_fbins) return;
-  int blk = fbins[blockIdx.x];
-  int cnt = fb_cnt[blk];
-  int j0 = fb_start[blk], l = threadIdx.x;
-  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
-  int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
-  for (int t = l; t < COL_CH * TILE_PAD; t += 64) tile[t] = 0.0;
-  // active flags of the 27 blocks the tile overlaps, fetched once (lane n < 27 -> neighbour n)
-  bool nb_act = false;
-  if (l < 27) {
-    int x = bx + l / 9 - 1, y = by + (l / 3) % 3 - 1, z = bz + l % 3 - 1;
-    if ((unsigned)x < (unsigned)d.NB && (unsigned)y < (unsigned)d.NB && (unsigned)z < (unsigned)d.NB)
-      nb_act = g.ab_flag[(x * d.NB + y) * d.NB + z] != 0;
-  }
-  unsigned long long act_mask = __ballot(nb_act);
-  __syncthreads();
-  for (int jj = j0; jj < j0 + cnt; jj += 64) {
-    if (jj + l >= j0 + cnt) continue;
-    int f = order[jj + l];
-    V3 p0, p1, p2;
-    V3 fp = face_centroid(pts, vel, adv, idx, f, p0, p1, p2);
-    Stencil s = make_stencil(fp, d.inv_dx);
-    if (!splat_ok(d.G, s)) continue;  // mpm_solver.py:858
-    int i0 = idx[3 * f], i1 = idx[3 * f + 1], i2 = idx[3 * f + 2];
-    V3 u0 = load_v3(vel + 3 * i0), u1 = load_v3(vel + 3 * i1), u2 = load_v3(vel + 3 * i2);
-    V3 fv = v3((u0.x + u1.x + u2.x) / 3.0f, (u0.y + u1.y + u2.y) / 3.0f, (u0.z + u1.z + u2.z) / 3.0f);
-    V3 fn = normalize(cross(p1 - p0, p2 - p0));  // wp.mesh_eval_face_normal
-    int lx = s.bx - ox, ly = s.by - oy, lz = s.bz - oz;
-    bool in_tile = !((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u);
-    int base = tile_idx(lx, ly, lz);
-    int n = l % 27, i = n / 9, j = (n / 3) % 3, k = n % 3;  // staggered start: neighbouring faces share nodes
-#pragma unroll 3
-    for (int t = 0; t < 27; ++t) {
-      float w = sel3(i, s.w0.x, s.w1.x, s.w2.x) * sel3(j, s.w0.y, s.w1.y, s.w2.y) * sel3(k, s.w0.z, s.w1.z, s.w2.z);
-      if (in_tile) {
-        double *p = tile + base + tile_idx(i, j, k);
-        atomicAdd(p, (double)w);
-        atomicAdd(p + TILE_PAD, (double)(w * fv.x)); atomicAdd(p + 2 * TILE_PAD, (double)(w * fv.y));
-        atomicAdd(p + 3 * TILE_PAD, (double)(w * fv.z));
-        atomicAdd(p + 4 * TILE_PAD, (double)(w * fn.x)); atomicAdd(p + 5 * TILE_PAD, (double)(w * fn.y));
-        atomicAdd(p + 6 * TILE_PAD, (double)(w * fn.z));
-      } else {  // drifted out of the tile margin since the faces were binned
-        g.counters[6] = 1;
-        int x = s.bx + i, y = s.by + j, z = s.bz + k;
-        int nb = blk_of(x, y, z, d.NB);
-        if (g.ab_flag[nb]) {
-          float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
-          atomicAdd(p, w);
-          atomicAdd(p + 64, w * fv.x); atomicAdd(p + 128, w * fv.y); atomicAdd(p + 192, w * fv.z);
-          atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
-        }
-      }
-      if (++k == 3) { k = 0; if (++j == 3) { j = 0; if (++i == 3) i = 0; } }
-    }
-  }
-  __syncthreads();
-  for (int t = l; t < TILE3; t += 64) {
-    int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
-    const double *q = tile + tile_idx(ti, tj, tk);
-    float w = (float)q[0];
-    if (w == 0.0f) continue;
-    int x = ox + ti, y = oy + tj, z = oz + tk;
-    if (!in_grid(x, y, z, d.G)) continue;
-    int nb = blk_of(x, y, z, d.NB);
-    int nidx = (((x >> 2) - bx + 1) * 3 + ((y >> 2) - by + 1)) * 3 + ((z >> 2) - bz + 1);
-    if (!((act_mask >> nidx) & 1ull)) continue;  // inactive block: never read by g2p, never re-zeroed
-    float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
-    atomicAdd(p, w);
-    atomicAdd(p + 64, (float)q[TILE_PAD]); atomicAdd(p + 128, (float)q[2 * TILE_PAD]); atomicAdd(p + 192, (float)q[3 * TILE_PAD]);
-    atomicAdd(p + 256, (float)q[4 * TILE_PAD]); atomicAdd(p + 320, (float)q[5 * TILE_PAD]); atomicAdd(p + 384, (float)q[6 * TILE_PAD]);
-  }
-}
-
-// Joint splat (add_velocity_{traditional,verts,faces}, mpm_solver.py:677-788) as ONE launch: 32 lanes per joint
-// particle, lane = stencil node (27 used), so every thread has a single short dependency chain instead of a 27-trip
-// loop of dependent loads.  Group 0: the last n_t traditional particles, group 1: the first n_v vertices, group 2:
-// the first n_f elements (caller-order indices; inv[] maps them to sorted slots).
-struct JointSplat {
-  const float *vel_t, *vel_v, *vel_f;
-  int n_t, n_v, n_f;
-  int off_t, off_v;  // caller-order index of the first particle of group 0 / group 1 (group 2 starts at 0)
-};
-__global__ void k_mover_splat(Bufs b, const int *inv, JointSplat js, Dims d, GridPtrs g) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int q = t >> 5, nn = t & 31;
-  if (nn >= 27 || q >= js.n_t + js.n_v + js.n_f) return;
-  const float *vel;
-  int orig;
-  if (q < js.n_t) { vel = js.vel_t + 3 * (size_t)q; orig = js.off_t + q; }
-  else if (q < js.n_t + js.n_v) { vel = js.vel_v + 3 * (size_t)(q - js.n_t); orig = js.off_v + (q - js.n_t); }
-  else { vel = js.vel_f + 3 * (size_t)(q - js.n_t - js.n_v); orig = q - js.n_t - js.n_v; }
-  Stencil s = make_stencil(ld3(b.all, A_X, inv[orig]), d.inv_dx);
-  if (!splat_ok(d.G, s)) return;  // mpm_solver.py:692,730,767
-  int i = nn / 9, j = (nn / 3) % 3, k = nn % 3;
-  float w = sel3(i, s.w0.x, s.w1.x, s.w2.x) * sel3(j, s.w0.y, s.w1.y, s.w2.y) * sel3(k, s.w0.z, s.w1.z, s.w2.z);
-  int x = s.bx + i, y = s.by + j, z = s.bz + k;
-  int blk = blk_of(x, y, z, d.NB);
-  if (!g.ab_flag[blk]) { atomicAdd(g.counters + 1, 1); return; }
-  V3 pv = load_v3(vel);
-  float *p = g.mov + ((size_t)blk * GCH_MOV) * 64 + loc_of(x, y, z);
-  atomicAdd(p, w);
-  atomicAdd(p + 64, w * pv.x); atomicAdd(p + 128, w * pv.y); atomicAdd(p + 192, w * pv.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -945,16 +1034,14 @@ __device__ __forceinline__ void g2p_write(const Bufs &b, int cls, int s, V3 x, V
   if (cls == 1) st9(b.tr, T_FT, s - d.n_e, (m3_identity() + dt * r.F) * ld9(b.tr, T_F, s - d.n_e));
 }
 
-__global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const int *plist, const int *ranges, const int *chunks,
-                                             int n_chunks, int n_P, Dims d, float dt, GridPtrs g) {
+__global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const ChunkRec *recs, int n_chunks, Dims d, float dt, GridPtrs g) {
   __shared__ float tile[3 * TILE_PAD];
   int w = xcd_slice(blockIdx.x, n_chunks);
   if (w < 0) return;
-  int slot = chunks[2 * w], chunk = chunks[2 * w + 1];
-  int blk = plist[slot];
+  const ChunkRec cm = recs[w];
+  int blk = cm.blk, chunk = cm.chunk;
   int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
   int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
-  ChunkMap cm = chunk_map(ranges, n_P, slot);
   int cls = 0, s = 0;
   bool valid = cm.map(chunk * CHUNK + (int)threadIdx.x, cls, s);
   // particle loads first: their latency overlaps the tile staging below
@@ -1239,11 +1326,10 @@ struct FastState {
   unsigned *fkeys[2] = {nullptr, nullptr};
   int *forder = nullptr, *fiota = nullptr, *fb_start = nullptr, *fb_cnt = nullptr;
   bool faces_binned = false;
-  hipStream_t side = nullptr;            // collider / mover splats overlap stress + p2g
-  hipEvent_t ev_ready = nullptr, ev_side = nullptr;
-  int *fbins = nullptr;
+  FaceBin *fbins = nullptr;
+  int *fidx = nullptr;  // [n_f][3] face vertex ids in bin order
   int cap_fbins = 0, n_fbins = 0;
-  float *eforce = nullptr;   // [6][n_e]
+  float4 *eforce = nullptr;  // [3][n_e] + zero slot
   int *adj_cnt = nullptr, *adj_o = nullptr, *adj_s = nullptr;
   int adj_K = 0, adj_cap = 0;
   VAdj va() const { return VAdj{adj_s, eforce, adj_K, d.n_v, d.n_e}; }
@@ -1253,12 +1339,14 @@ struct FastState {
   size_t sort_tmp_bytes = 0, scan_tmp_bytes = 0;
   GridPtrs g{};
   int *pb_flag = nullptr, *pb_index = nullptr, *ab_flag = nullptr, *ab_index = nullptr;
-  int *plist = nullptr, *alist = nullptr, *ranges = nullptr, *chunks = nullptr;
+  int *plist = nullptr, *alist = nullptr, *ranges = nullptr;
+  ChunkRec *chunks = nullptr;
   int cap_P = 0, cap_A = 0, cap_chunks = 0, cap_R = 0;
   int64_t stat_steps = 0;
   int n_P = 0, n_A = 0, n_chunks = 0;
   int *h_pin = nullptr;  // pinned host scratch
-  std::vector<int> h_ranges, h_chunks;
+  std::vector<int> h_ranges, h_plist;
+  std::vector<ChunkRec> h_chunks;
   bool elem_pending = false;  // element finalise of the last substep still to be done (fused into the next stress)
   int steps_since_rebin = 0;
   hipEvent_t ev_flag = nullptr;
@@ -1358,7 +1446,7 @@ int do_import(mpmhip_ctx *c) {
     MPM_HIP_CHECK(c, hipMemsetAsync(f->adj_o, 0xff, (size_t)K * d.n_v * sizeof(int), s));
     MPM_HIP_CHECK(c, hipMemsetAsync(f->adj_cnt, 0, (size_t)d.n_v * sizeof(int), s));
     hipLaunchKernelGGL(k_adj_build, nblk(d.n_e), TPB, 0, s, c->st.faces, d.n_e, d.n_v, f->adj_cnt, f->adj_o, K, 1);
-    MPM_HIP_CHECK(c, hipMemsetAsync(f->eforce, 0, (size_t)6 * d.n_e * sizeof(float), s));
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->eforce, 0, ((size_t)3 * d.n_e + 1) * sizeof(float4), s));
   }
   f->elem_pending = false;
   c->caller_dirty = false;
@@ -1407,22 +1495,27 @@ int rebin(mpmhip_ctx *c) {
   if ((rc = scan_flags(c, f->ab_flag, f->ab_index, nb, &f->n_A))) return rc;
   if ((rc = ensure_cap(c, &f->alist, &f->cap_A, f->n_A, 1))) return rc;
   hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, f->ab_flag, f->ab_index, nb, f->alist);
-  // chunk list on the host from the compact ranges
+  // chunk records on the host from the compact ranges
   f->h_ranges.resize((size_t)f->n_P * 6);
+  f->h_plist.resize((size_t)f->n_P);
   MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_ranges.data(), f->ranges, (size_t)f->n_P * 6 * sizeof(int), hipMemcpyDeviceToHost, s));
+  MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_plist.data(), f->plist, (size_t)f->n_P * sizeof(int), hipMemcpyDeviceToHost, s));
   MPM_HIP_CHECK(c, hipStreamSynchronize(s));
   f->h_chunks.clear();
   for (int p = 0; p < f->n_P; ++p) {
-    int tot = 0;  // the three classes of a block are packed back to back (ChunkMap)
-    for (int cl = 0; cl < 3; ++cl)
-      tot += f->h_ranges[(size_t)(cl * 2 + 1) * f->n_P + p] - f->h_ranges[(size_t)(cl * 2) * f->n_P + p];
-    int nch = (tot + CHUNK - 1) / CHUNK;
-    for (int k = 0; k < nch; ++k) { f->h_chunks.push_back(p); f->h_chunks.push_back(k); }
+    auto R = [&](int k) { return f->h_ranges[(size_t)k * f->n_P + p]; };
+    ChunkRec r{f->h_plist[p], 0, R(0), R(1) - R(0), R(2), R(3) - R(2), R(4), R(5) - R(4)};
+    int tot = r.ne + r.nt + r.nv;  // the three classes of a block are packed back to back
+    for (int k = 0; k * CHUNK < tot; ++k) { r.chunk = k; f->h_chunks.push_back(r); }
   }
-  f->n_chunks = (int)(f->h_chunks.size() / 2);
-  if ((rc = ensure_cap(c, &f->chunks, &f->cap_chunks, f->n_chunks, 2))) return rc;
+  f->n_chunks = (int)f->h_chunks.size();
+  if (f->n_chunks > f->cap_chunks) {
+    int cap = f->n_chunks + f->n_chunks / 4 + 64;
+    if ((rc = dalloc(c, &f->chunks, (size_t)cap, false))) return rc;
+    f->cap_chunks = cap;
+  }
   if (f->n_chunks)
-    MPM_HIP_CHECK(c, hipMemcpyAsync(f->chunks, f->h_chunks.data(), f->h_chunks.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    MPM_HIP_CHECK(c, hipMemcpyAsync(f->chunks, f->h_chunks.data(), f->h_chunks.size() * sizeof(ChunkRec), hipMemcpyHostToDevice, s));
   MPM_HIP_CHECK(c, hipStreamSynchronize(s));  // h_chunks is pageable: the copy must finish before it is reused
   if (!c->colliders.empty() && c->num_mesh_f) {
     int nf = c->num_mesh_f;
@@ -1439,10 +1532,15 @@ int rebin(mpmhip_ctx *c) {
                                                0u, (unsigned)f->blk_bits, s));
     MPM_HIP_CHECK(c, hipMemsetAsync(f->fb_cnt, 0, f->nblocks * sizeof(int), s));
     hipLaunchKernelGGL(k_face_bins, nblk(nf), TPB, 0, s, f->fkeys[1], nf, f->fb_start, f->fb_cnt);
-    if ((rc = ensure_cap(c, &f->fbins, &f->cap_fbins, std::min(nf, f->n_A), 1))) return rc;
+    if (std::min(nf, f->n_A) > f->cap_fbins) {
+      int cap = std::min(nf, f->n_A) * 2 + 64;
+      if ((rc = dalloc(c, &f->fbins, (size_t)cap, false))) return rc;
+      f->cap_fbins = cap;
+    }
+    hipLaunchKernelGGL(k_face_sorted_idx, nblk(nf), TPB, 0, s, c->mesh_idx, f->forder, nf, f->fidx);
     int *cnt = f->g.counters + 5;
     MPM_HIP_CHECK(c, hipMemsetAsync(cnt, 0, sizeof(int), s));
-    if (f->n_A) hipLaunchKernelGGL(k_fbin_compact, nblk(f->n_A), TPB, 0, s, f->alist, f->n_A, f->fb_cnt, f->fbins, cnt);
+    if (f->n_A) hipLaunchKernelGGL(k_fbin_compact, nblk(f->n_A), TPB, 0, s, f->alist, f->n_A, f->fb_start, f->fb_cnt, f->fbins, cnt);
     MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 20, cnt, sizeof(int), hipMemcpyDeviceToHost, s));
     MPM_HIP_CHECK(c, hipStreamSynchronize(s));
     f->n_fbins = f->h_pin[20];
@@ -1483,7 +1581,7 @@ int fast_init(mpmhip_ctx *c) {
   }
   if ((rc = dalloc(c, &f->inv, (size_t)d.n_p))) return rc;
   if ((rc = dalloc(c, &f->face_slot, (size_t)3 * d.n_e))) return rc;
-  if ((rc = dalloc(c, &f->eforce, (size_t)6 * d.n_e))) return rc;
+  if ((rc = dalloc(c, &f->eforce, (size_t)3 * d.n_e + 1))) return rc;
   if ((rc = dalloc(c, &f->adj_cnt, (size_t)d.n_v + 1))) return rc;
   if ((rc = dalloc(c, &f->order, (size_t)d.n_p))) return rc;
   if ((rc = dalloc(c, &f->iota, (size_t)d.n_p))) return rc;
@@ -1498,9 +1596,6 @@ int fast_init(mpmhip_ctx *c) {
   f->g.ab_flag = f->ab_flag;
   if (const char *e = getenv("MPMHIP_DBG")) f->g.dbg = atoi(e);
   MPM_HIP_CHECK(c, hipHostMalloc((void **)&f->h_pin, 64 * sizeof(int), hipHostMallocDefault));
-  MPM_HIP_CHECK(c, hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
-  MPM_HIP_CHECK(c, hipEventCreateWithFlags(&f->ev_ready, hipEventDisableTiming));
-  MPM_HIP_CHECK(c, hipEventCreateWithFlags(&f->ev_side, hipEventDisableTiming));
   MPM_HIP_CHECK(c, hipEventCreateWithFlags(&f->ev_flag, hipEventDisableTiming));
   return MPMHIP_OK;
 }
@@ -1511,9 +1606,6 @@ void fast_destroy(mpmhip_ctx *c) {
   if (f->rccl.comm) (void)f->rccl.CommDestroy(f->rccl.comm);
   for (void *p : f->allocs) (void)hipFree(p);
   if (f->h_pin) (void)hipHostFree(f->h_pin);
-  if (f->side) { (void)hipStreamSynchronize(f->side); (void)hipStreamDestroy(f->side); }
-  if (f->ev_ready) (void)hipEventDestroy(f->ev_ready);
-  if (f->ev_side) (void)hipEventDestroy(f->ev_side);
   if (f->ev_flag) (void)hipEventDestroy(f->ev_flag);
   delete f;
   c->fast = nullptr;
@@ -1526,6 +1618,7 @@ int fast_add_collider_storage(mpmhip_ctx *c, MeshCollider &mc) {
   for (int i = 0; i < 2; ++i)
     if ((rc = dalloc(c, &f->fkeys[i], (size_t)nf))) return rc;
   if ((rc = dalloc(c, &f->forder, (size_t)nf))) return rc;
+  if ((rc = dalloc(c, &f->fidx, (size_t)3 * nf))) return rc;
   if ((rc = dalloc(c, &f->fiota, (size_t)nf))) return rc;
   if ((rc = dalloc(c, &f->fb_start, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->fb_cnt, f->nblocks))) return rc;
@@ -1597,34 +1690,25 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     }
   }
   Bufs &b = f->buf[f->cur];
-  // The body-face and joint splats only need the particle positions and the (re-zeroed) collider / mover
-  // channels, so they run on a side stream concurrently with stress + p2g and are joined before the grid stage.
-  // With profiling on (one sync per phase, like the reference's ScopedTimer) everything stays on one stream.
+  // The body-face and joint splats ride along in the p2g launch as extra workgroups (SplatArgs).  With profiling on
+  // (one sync per phase, like the reference's ScopedTimer) they get a launch of their own under the reference's
+  // phase names: the same kernel with no particle chunks.
   bool has_col = !c->colliders.empty() && c->num_mesh_f && f->n_fbins;
   bool mov_on = a.joint_v_v && a.joint_f_v && !c->movers.empty();
-  if (mov_on && c->cfg.num_joint_f > 0) flush_elements(c);  // joint-face splats read element positions
-  bool side = !c->profiling && (has_col || mov_on);
-  hipStream_t ss = side ? f->side : s;
-  auto launch_splats = [&]() {
-    if (has_col) {
-      ScopedPhase ph(c, "apply_Mesh_Collision_on_grid");
-      hipLaunchKernelGGL(k_col_splat, (unsigned)f->n_fbins, 64, 0, ss, c->cur_pts, c->cur_vel, c->cur_f, c->mesh_idx,
-                         f->forder, f->fb_start, f->fb_cnt, f->fbins, f->n_fbins, d, f->g);
-    }
-    if (mov_on) {
-      ScopedPhase ph(c, "apply_Particle_Moving_on_grid");
-      JointSplat js{a.joint_t_v, a.joint_v_v, a.joint_f_v, (a.joint_t_v ? a.n_joint_t : 0), c->cfg.num_joint_v,
-                    c->cfg.num_joint_f, d.n_nv - a.n_joint_t, d.n_nv};
-      int nj = js.n_t + js.n_v + js.n_f;
-      if (nj) hipLaunchKernelGGL(k_mover_splat, nblk((size_t)nj * 32), TPB, 0, ss, b, f->inv, js, d, f->g);
-    }
-  };
-  if (side) {
-    MPM_HIP_CHECK(c, hipEventRecord(f->ev_ready, s));
-    MPM_HIP_CHECK(c, hipStreamWaitEvent(f->side, f->ev_ready, 0));
-    launch_splats();
-    MPM_HIP_CHECK(c, hipEventRecord(f->ev_side, f->side));
+  SplatArgs sa{};
+  SplatArgs none{};
+  if (has_col) {
+    sa.pts = c->cur_pts; sa.vel = c->cur_vel; sa.adv = c->cur_f; sa.fidx = f->fidx; sa.fbins = f->fbins;
+    sa.n_fbins = f->n_fbins;
   }
+  if (mov_on) {
+    sa.js = JointSplatArgs{a.joint_t_v, a.joint_v_v, a.joint_f_v, (a.joint_t_v ? a.n_joint_t : 0), c->cfg.num_joint_v,
+                           c->cfg.num_joint_f, d.n_nv - a.n_joint_t, d.n_nv, f->inv};
+    int nj = sa.js.n_t + sa.js.n_v + sa.js.n_f;
+    sa.n_mov_wg = (int)nblk((size_t)nj * 32);
+    if (nj == 0) sa.n_mov_wg = 0;
+  }
+  sa.n_extra = (sa.n_fbins + sa.n_mov_wg + 7) & ~7;
   {
     ScopedPhase ph(c, "compute_stress_from_F_trial");
     if (d.n_e) {
@@ -1638,14 +1722,33 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     }
     if (d.n_t) hipLaunchKernelGGL(k_stress_trad, nblk(d.n_t), TPB, 0, s, b, d, c->sc, dt);
   }
-  {
+  if (c->profiling && sa.n_extra) {
+    {
+      ScopedPhase ph(c, "p2g");
+      if (f->n_chunks)
+        hipLaunchKernelGGL(k_p2g, xcd_grid(f->n_chunks), TPB, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
+                           c->sc.rpic_damping, dt, f->g, none);
+    }
+    if (sa.n_fbins) {
+      ScopedPhase ph(c, "apply_Mesh_Collision_on_grid");
+      SplatArgs only = sa;
+      only.n_mov_wg = 0;
+      only.n_extra = (only.n_fbins + 7) & ~7;
+      hipLaunchKernelGGL(k_p2g, (unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only);
+    }
+    if (sa.n_mov_wg) {
+      ScopedPhase ph(c, "apply_Particle_Moving_on_grid");
+      SplatArgs only = sa;
+      only.n_fbins = 0;
+      only.n_extra = (only.n_mov_wg + 7) & ~7;
+      hipLaunchKernelGGL(k_p2g, (unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only);
+    }
+  } else {
     ScopedPhase ph(c, "p2g");
-    if (f->n_chunks)
-      hipLaunchKernelGGL(k_p2g, xcd_grid(f->n_chunks), TPB, 0, s, b, f->va(), f->plist, f->ranges, f->chunks,
-                         f->n_chunks, f->n_P, d, c->sc.rpic_damping, dt, f->g);
+    if (f->n_chunks || sa.n_extra)
+      hipLaunchKernelGGL(k_p2g, xcd_grid(f->n_chunks) + (unsigned)sa.n_extra, TPB, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
+                         c->sc.rpic_damping, dt, f->g, sa);
   }
-  if (side) MPM_HIP_CHECK(c, hipStreamWaitEvent(s, f->ev_side, 0));
-  else launch_splats();
   return MPMHIP_OK;
 }
 
@@ -1674,8 +1777,7 @@ static int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
   {
     ScopedPhase ph(c, "g2p_v");
     if (f->n_chunks) {
-      hipLaunchKernelGGL(k_g2p, xcd_grid(f->n_chunks), TPB, 0, s, b, f->plist, f->ranges, f->chunks, f->n_chunks,
-                         f->n_P, d, dt, f->g);
+      hipLaunchKernelGGL(k_g2p, xcd_grid(f->n_chunks), TPB, 0, s, b, f->chunks, f->n_chunks, d, dt, f->g);
       hipLaunchKernelGGL(k_g2p_escaped, 1, TPB, 0, s, b, f->keys[1], f->blk_bits, d, dt, f->g);
     }
   }
