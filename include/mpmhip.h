@@ -54,7 +54,8 @@ typedef struct {
   int32_t num_joint_t, num_joint_v, num_joint_f;
   int32_t device;         /* HIP device ordinal */
   int32_t mode;           /* MPMHIP_MODE_* */
-  int32_t rebin_interval; /* fast mode: substeps between particle re-sorts; 0 = default */
+  int32_t rebin_interval; /* fast mode: max substeps between particle re-sorts (a device-side drift flag triggers
+                             earlier ones); 0 = default (256); < 0 = exactly every -n substeps, drift flag ignored */
   int32_t own_stream;     /* 1: create a private non-blocking stream and ignore `stream` */
   void *stream;           /* own_stream == 0: hipStream_t to launch on (NULL = the HIP null stream), e.g.
                              torch.cuda.current_stream().cuda_stream so that solver work is ordered with the

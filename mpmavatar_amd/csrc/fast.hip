@@ -1046,16 +1046,12 @@ __global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const ChunkRec *recs, int n
   bool valid = cm.map(chunk * CHUNK + (int)threadIdx.x, cls, s);
   // particle loads first: their latency overlaps the tile staging below
   V3 x = v3(0, 0, 0), d3 = v3(0, 0, 0);
+  bool escaped = false;
   if (valid) {
     x = ld3(b.all, A_X, s);
     if (cls == 0) d3 = v3(b.el.at(E_D + 2, s), b.el.at(E_D + 5, s), b.el.at(E_D + 8, s));
     int lx = (int)(x.x * d.inv_dx - 0.5f) - ox, ly = (int)(x.y * d.inv_dx - 0.5f) - oy, lz = (int)(x.z * d.inv_dx - 0.5f) - oz;
-    if ((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u) {
-      // drifted out of the tile margin: queued for k_g2p_escaped.  (Doing this here, before the gather, matters:
-      // an early exit after the gather made hipcc allocate 180 instead of 104 VGPRs for this kernel.)
-      g.esc_list[atomicAdd(g.counters + 7, 1)] = s;
-      valid = false;
-    }
+    escaped = (unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u;  // drifted out of the tile margin
   }
   for (int t = threadIdx.x; t < TILE3; t += TPB) {
     int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
@@ -1069,28 +1065,25 @@ __global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const ChunkRec *recs, int n
     q[0] = v.x; q[TILE_PAD] = v.y; q[2 * TILE_PAD] = v.z;
   }
   __syncthreads();
-  if (!valid) return;
-  G2PResult r = g2p_gather(tile, ox, oy, oz, x, d);
-  g2p_write(b, cls, s, x, d3, r, ox, oy, oz, d, dt, g);
-}
-
-// the (rare) particles that left their tile margin since the last re-sort: one workgroup walks the queue
-__global__ __launch_bounds__(TPB) void k_g2p_escaped(Bufs b, const unsigned *skeys, int blk_bits, Dims d, float dt,
-                                                     GridPtrs g) {
-  int n = g.counters[7];
-  for (int q = threadIdx.x; q < n; q += TPB) {
-    int s = g.esc_list[q];
-    int cls = s < d.n_e ? 0 : (s < d.n_nv ? 1 : 2);
-    int blk = key_block(skeys[s], blk_bits);
-    int oz = 4 * (blk % d.NB) - 1, oy = 4 * ((blk / d.NB) % d.NB) - 1, ox = 4 * (blk / (d.NB * d.NB)) - 1;
-    V3 x = ld3(b.all, A_X, s), d3 = v3(0, 0, 0);
-    if (cls == 0) d3 = v3(b.el.at(E_D + 2, s), b.el.at(E_D + 5, s), b.el.at(E_D + 8, s));
-    G2PResult r = g2p_gather_global(x, d, g);
-    g2p_write(b, cls, s, x, d3, r, ox, oy, oz, d, dt, g);
-    atomicAdd(g.counters + 0, 1);
+  {
+    // lanes without a particle in the tile margin gather from the tile corner (in range, result unused)
+    bool fit = valid && !escaped;
+    V3 xg = fit ? x : v3((float)(ox + 2) * d.dx, (float)(oy + 2) * d.dx, (float)(oz + 2) * d.dx);
+    G2PResult r = g2p_gather(tile, ox, oy, oz, xg, d);
+    if (fit) g2p_write(b, cls, s, x, d3, r, ox, oy, oz, d, dt, g);
   }
-  __syncthreads();
-  if (threadIdx.x == 0) g.counters[7] = 0;
+  // A particle outside the tile margin (rare, and only until the re-sort its drift flag has already requested) is
+  // finished here from the global grid with a rolled loop.  The empty asm makes its inputs opaque: otherwise the
+  // optimizer shares stencil weights and store addresses with the tile path above and keeps them live across it
+  // (202 instead of ~110 VGPRs).  A follow-up kernel for these particles cost 4.7 us per substep for nothing.
+  if (__any(escaped)) {
+    asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(s), "+v"(cls), "+v"(d3.x), "+v"(d3.y), "+v"(d3.z));
+    if (escaped) {
+      G2PResult r = g2p_gather_global(x, d, g);
+      g2p_write(b, cls, s, x, d3, r, ox, oy, oz, d, dt, g);
+      atomicAdd(g.counters + 0, 1);
+    }
+  }
 }
 
 // second half of g2p_e (mpm_utils.py:838-857): x, v = mean of the three updated vertices; d1, d2 = edges
@@ -1354,6 +1347,7 @@ struct FastState {
   bool have_order = false;
   int64_t rebins = 0;
   int rebin_interval = 32;
+  bool adaptive_rebin = true;  // false: ignore the drift flag (tests of the out-of-margin paths)
   std::vector<void *> allocs;
 };
 
@@ -1572,7 +1566,8 @@ int fast_init(mpmhip_ctx *c) {
   f->key_bits = f->blk_bits + 6 + 1 + 2;
   if (f->key_bits > 32) return fail(c, MPMHIP_ERR_INVALID, "grid too large for 32-bit sort keys");
   // upper bound between re-sorts; the drift flag normally triggers one earlier (or never, for slow scenes)
-  f->rebin_interval = cfg.rebin_interval > 0 ? cfg.rebin_interval : 256;
+  f->rebin_interval = cfg.rebin_interval > 0 ? cfg.rebin_interval : (cfg.rebin_interval < 0 ? -cfg.rebin_interval : 256);
+  f->adaptive_rebin = cfg.rebin_interval >= 0;
   int rc;
   for (int i = 0; i < 2; ++i) {
     if ((rc = alloc_bufs(c, f->buf[i]))) return rc;
@@ -1682,7 +1677,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     if (f->flag_pending && (f->steps_since_rebin & 7) == 0) {
       MPM_HIP_CHECK(c, hipEventSynchronize(f->ev_flag));
       f->flag_pending = false;
-      if (f->h_pin[24]) f->steps_since_rebin = 1 << 30;
+      if (f->h_pin[24] && f->adaptive_rebin) f->steps_since_rebin = 1 << 30;
     }
     if (f->steps_since_rebin >= f->rebin_interval) {
       ScopedPhase ph(c, "rebin");
@@ -1778,7 +1773,6 @@ static int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
     ScopedPhase ph(c, "g2p_v");
     if (f->n_chunks) {
       hipLaunchKernelGGL(k_g2p, xcd_grid(f->n_chunks), TPB, 0, s, b, f->chunks, f->n_chunks, d, dt, f->g);
-      hipLaunchKernelGGL(k_g2p_escaped, 1, TPB, 0, s, b, f->keys[1], f->blk_bits, d, dt, f->g);
     }
   }
   return MPMHIP_OK;
