@@ -709,6 +709,7 @@ __device__ __forceinline__ float seg_scan(float v, const SegMask &sm) {
 // and this kernel is VALU-bound.  The four chains are interleaved so that a register written by one DPP op is
 // read through DPP only three instructions later (gfx9 needs 2 wait states between a VALU write and a DPP
 // read of the same VGPR); the leading s_nop covers values produced right before the block.
+template <int STEPS>
 __device__ __forceinline__ void seg_scan4(float &a, float &b, float &c, float &d, const SegMask &sm) {
   asm volatile(
       "s_nop 1\n"
@@ -720,16 +721,26 @@ __device__ __forceinline__ void seg_scan4(float &a, float &b, float &c, float &d
       "v_fmac_f32_dpp %1, %1, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n"
       "v_fmac_f32_dpp %2, %2, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n"
       "v_fmac_f32_dpp %3, %3, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_fmac_f32_dpp %0, %0, %6 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_fmac_f32_dpp %1, %1, %6 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_fmac_f32_dpp %2, %2, %6 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_fmac_f32_dpp %3, %3, %6 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_fmac_f32_dpp %0, %0, %7 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_fmac_f32_dpp %1, %1, %7 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_fmac_f32_dpp %2, %2, %7 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_fmac_f32_dpp %3, %3, %7 row_shr:8 row_mask:0xf bank_mask:0xf\n"
       : "+v"(a), "+v"(b), "+v"(c), "+v"(d)
-      : "v"(sm.m1), "v"(sm.m2), "v"(sm.m4), "v"(sm.m8));
+      : "v"(sm.m1), "v"(sm.m2));
+  if (STEPS >= 3)
+    asm volatile(
+        "s_nop 0\n"
+        "v_fmac_f32_dpp %0, %0, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %1, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %2, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %3, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d)
+        : "v"(sm.m4));
+  if (STEPS >= 4)
+    asm volatile(
+        "s_nop 0\n"
+        "v_fmac_f32_dpp %0, %0, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %1, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %2, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %3, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d)
+        : "v"(sm.m8));
 }
 
 // contribution of q to stencil node (i,j,k) in the reference's form (mpm_utils.py:519-556); slow path only
@@ -764,6 +775,7 @@ __device__ __forceinline__ void p2g_escaped(const Bufs &b, const VAdj &va, int c
   }
 }
 
+template <int STEPS>
 __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *recs, int n_chunks, Dims d, float rpic,
                                              float dt, GridPtrs g, SplatArgs sa) {
   __shared__ double tile[4 * TILE_PAD];
@@ -806,7 +818,10 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *re
   }
   if (!(g.dbg & 2) && __any(valid)) {  // wave-uniform: DPP needs converged lanes
     SegMask sm = seg_masks(key);
-    bool do_add = sm.tail && valid;
+    // STEPS scan steps sum windows of 2^STEPS lanes: lanes at distances 0, W, 2W, ... from their segment's tail issue
+    unsigned long long tails = __ballot(sm.tail);
+    int dist = __ffsll((unsigned long long)(tails >> (threadIdx.x & 63))) - 1;
+    bool do_add = valid && (dist & ((1 << STEPS) - 1)) == 0;
     const Stencil &st = q.s;
     // factored stencil: add_ijk = wm (B_ij + k Cz) + wz_k P_ij + dwz_k Q_ij, wm = wxy_ij (wz_k m)
     float wzm0 = st.w0.z * q.mass, wzm1 = st.w1.z * q.mass, wzm2 = st.w2.z * q.mass;
@@ -830,7 +845,7 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *re
           V3 vel = Bij + (float)k * Cz;
           V3 add = wm * vel + wzk * P + dwzk * Q;
           float r0 = wm, r1 = add.x, r2 = add.y, r3 = add.z;
-          seg_scan4(r0, r1, r2, r3, sm);
+          seg_scan4<STEPS>(r0, r1, r2, r3, sm);
           if (do_add) {
             double *p = tile + base + tile_idx(i, j, k);
             atomicAdd(p, (double)r0);
@@ -1647,6 +1662,19 @@ int fast_pull(mpmhip_ctx *c) {
 //   A: [re-sort] pre-ops, body/joint splats (side stream), stress, p2g          -> halo exchange of shared blocks
 //   B: grid stage, g2p (+ escaped queue)                                         -> ghost x/v/d3 exchange
 //   C: element finalise, drift-flag bookkeeping
+static int p2g_scan_steps() {
+  static int v = [] { const char *e = getenv("MPMHIP_P2G_SCAN"); int k = e ? atoi(e) : 3; return k < 2 ? 2 : (k > 4 ? 4 : k); }();
+  return v;
+}
+#define P2G_LAUNCH(...)                                                          \
+  do {                                                                           \
+    switch (p2g_scan_steps()) {                                                  \
+      case 2: hipLaunchKernelGGL(k_p2g<2>, __VA_ARGS__); break;                  \
+      case 3: hipLaunchKernelGGL(k_p2g<3>, __VA_ARGS__); break;                  \
+      default: hipLaunchKernelGGL(k_p2g<4>, __VA_ARGS__); break;                 \
+    }                                                                            \
+  } while (0)
+
 static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   FastState *f = c->fast;
   const Dims &d = f->d;
@@ -1721,7 +1749,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     {
       ScopedPhase ph(c, "p2g");
       if (f->n_chunks)
-        hipLaunchKernelGGL(k_p2g, xcd_grid(f->n_chunks), TPB, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
+        P2G_LAUNCH(xcd_grid(f->n_chunks), TPB, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
                            c->sc.rpic_damping, dt, f->g, none);
     }
     if (sa.n_fbins) {
@@ -1729,19 +1757,19 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       SplatArgs only = sa;
       only.n_mov_wg = 0;
       only.n_extra = (only.n_fbins + 7) & ~7;
-      hipLaunchKernelGGL(k_p2g, (unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only);
+      P2G_LAUNCH((unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only);
     }
     if (sa.n_mov_wg) {
       ScopedPhase ph(c, "apply_Particle_Moving_on_grid");
       SplatArgs only = sa;
       only.n_fbins = 0;
       only.n_extra = (only.n_mov_wg + 7) & ~7;
-      hipLaunchKernelGGL(k_p2g, (unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only);
+      P2G_LAUNCH((unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only);
     }
   } else {
     ScopedPhase ph(c, "p2g");
     if (f->n_chunks || sa.n_extra)
-      hipLaunchKernelGGL(k_p2g, xcd_grid(f->n_chunks) + (unsigned)sa.n_extra, TPB, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
+      P2G_LAUNCH(xcd_grid(f->n_chunks) + (unsigned)sa.n_extra, TPB, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
                          c->sc.rpic_damping, dt, f->g, sa);
   }
   return MPMHIP_OK;
