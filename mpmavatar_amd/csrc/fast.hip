@@ -130,9 +130,10 @@ __global__ void k_import(mpmhip_state_ptrs st, mpmhip_model_ptrs md, Bufs b, con
 // 168-170) and every vertex sums over its incident (element, corner) pairs through an ELL adjacency table that is
 // rebuilt in sorted index space at each re-sort.  Replaces the 9 scattered fp32 atomics per element of
 // kirchoff_stress_Anisotropy (mpm_utils.py:173-175): scattered global atomics run at ~21 G/s on MI355X.
+struct F3 { float x, y, z; };
 struct VAdj {
   const int *adj;     // [K][n_v]: (element_slot << 2) | corner, -1 = empty
-  const float4 *ef;   // [3][n_e] corner forces f1, f2, f3 (xyz, w unused) per element + one zero entry at 3*n_e
+  const F3 *ef;       // [3][n_e] corner forces f1, f2, f3 per element + one zero entry at 3*n_e (12-byte loads)
   int K, n_v, n_e;
 };
 // One incidence = one 16-byte load: entry (e, c) reads ef[c*n_e + e]; empty entries read the zero slot, so there is no
@@ -148,7 +149,7 @@ __device__ __forceinline__ AdjBatch adj_load(const VAdj &a, int vl, int k0) {
 __device__ __forceinline__ V3 adj_gather(const VAdj &a, const AdjBatch &r, V3 f) {
 #pragma unroll
   for (int h = 0; h < ADJ_BATCH; h += 4) {  // four 16-byte loads in flight at a time (register budget of p2g)
-    float4 g[4];
+    F3 g[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       int ent = r.ent[h + u];
@@ -288,12 +289,12 @@ __global__ void k_dilate(const int *plist, int n_P, int NB, int *ab_flag) {
 // director matrix less per substep.  The host runs the stand-alone k_elem_finalize instead whenever something needs
 // finished elements earlier (re-sort, read-back, pre-p2g operations, joint-face splats, multi-GPU ghosts).
 template <bool FINALIZE>
-__global__ void k_stress_elem(Bufs b, float4 *ef, Dims d, float friction_coeff, const int *face_slot,
+__global__ void k_stress_elem(Bufs b, F3 *ef, Dims d, float friction_coeff, const int *face_slot,
                               const unsigned *skeys, int blk_bits, int *counters) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.n_e) return;
   if (b.sel[e] == 1) {  // not simulated (selection == 2 marks a ghost copy: stress yes, transfers no)
-    for (int c = 0; c < 3; ++c) ef[c * d.n_e + e] = make_float4(0, 0, 0, 0);
+    for (int c = 0; c < 3; ++c) ef[c * d.n_e + e] = F3{0.0f, 0.0f, 0.0f};
     return;
   }
   M3 dm;
@@ -313,8 +314,8 @@ __global__ void k_stress_elem(Bufs b, float4 *ef, Dims d, float friction_coeff, 
     V3 d3o = v3(b.el.at(E_D + 2, e), b.el.at(E_D + 5, e), b.el.at(E_D + 8, e));
     V3 d1 = x2 - x1, d2 = x3 - x1;
     dm = m3_cols(d1, d2, d3o);
-    b.el.at(E_D + 0, e) = d1.x; b.el.at(E_D + 3, e) = d1.y; b.el.at(E_D + 6, e) = d1.z;
-    b.el.at(E_D + 1, e) = d2.x; b.el.at(E_D + 4, e) = d2.y; b.el.at(E_D + 7, e) = d2.z;
+    // d1, d2 are not stored here: nothing reads them before the next finalize (every consumer of finished elements --
+    // re-sort, read-back, ghosts -- runs k_elem_finalize first, which recomputes them from the vertices)
   } else {
     dm = ld9(b.el, E_D, e);
   }
@@ -328,9 +329,9 @@ __global__ void k_stress_elem(Bufs b, float4 *ef, Dims d, float friction_coeff, 
   kirchhoff_anisotropy(q, r02, r12, r22, d3, ld3(b.el, E_RINV, e), b.nv.at(N_VOL, e), b.nv.at(N_MU, e),
                        b.nv.at(N_LAM, e), gamma, kappa, stress, f1, f2, f3);
   st9(b.nv, N_STRESS, e, stress);
-  ef[e] = make_float4(f1.x, f1.y, f1.z, 0.0f);
-  ef[d.n_e + e] = make_float4(f2.x, f2.y, f2.z, 0.0f);
-  ef[2 * d.n_e + e] = make_float4(f3.x, f3.y, f3.z, 0.0f);
+  ef[e] = F3{f1.x, f1.y, f1.z};
+  ef[d.n_e + e] = F3{f2.x, f2.y, f2.z};
+  ef[2 * d.n_e + e] = F3{f3.x, f3.y, f3.z};
 }
 
 __global__ void k_stress_trad(Bufs b, Dims d, mpmhip_model_scalars sc, float dt) {
@@ -1337,7 +1338,7 @@ struct FastState {
   FaceBin *fbins = nullptr;
   int *fidx = nullptr;  // [n_f][3] face vertex ids in bin order
   int cap_fbins = 0, n_fbins = 0;
-  float4 *eforce = nullptr;  // [3][n_e] + zero slot
+  F3 *eforce = nullptr;  // [3][n_e] + zero slot
   int *adj_cnt = nullptr, *adj_o = nullptr, *adj_s = nullptr;
   int adj_K = 0, adj_cap = 0;
   VAdj va() const { return VAdj{adj_s, eforce, adj_K, d.n_v, d.n_e}; }
@@ -1455,7 +1456,7 @@ int do_import(mpmhip_ctx *c) {
     MPM_HIP_CHECK(c, hipMemsetAsync(f->adj_o, 0xff, (size_t)K * d.n_v * sizeof(int), s));
     MPM_HIP_CHECK(c, hipMemsetAsync(f->adj_cnt, 0, (size_t)d.n_v * sizeof(int), s));
     hipLaunchKernelGGL(k_adj_build, nblk(d.n_e), TPB, 0, s, c->st.faces, d.n_e, d.n_v, f->adj_cnt, f->adj_o, K, 1);
-    MPM_HIP_CHECK(c, hipMemsetAsync(f->eforce, 0, ((size_t)3 * d.n_e + 1) * sizeof(float4), s));
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->eforce, 0, ((size_t)3 * d.n_e + 1) * sizeof(F3), s));
   }
   f->elem_pending = false;
   c->caller_dirty = false;
