@@ -58,6 +58,39 @@ __device__ __forceinline__ bool apply_bc(const BC &bc, V3 &v, int gx, int gy, in
   return false;
 }
 
+// Conservative box test for apply_bc: false only if bc cannot change any node with indices in [lo, hi] (per axis) at this
+// time.  g2p evaluates nodes tile by tile and skips the BC loop for tiles no BC can reach.
+__device__ __forceinline__ bool bc_may_touch(const BC &bc, int lox, int loy, int loz, int hix, int hiy, int hiz, int G,
+                                             float dx, float time, float dt) {
+  if (bc.type == BC_GRIDMASK) return true;
+  bool in_window = time >= bc.start_time && time < bc.end_time;
+  if (bc.type == BC_SURFACE) {
+    if (!in_window) return false;
+    // dp is affine in the node index: its minimum over the box is taken at a corner (same float ops as apply_bc)
+    float lo[3] = {(float)lox * dx - bc.point[0], (float)loy * dx - bc.point[1], (float)loz * dx - bc.point[2]};
+    float hi[3] = {(float)hix * dx - bc.point[0], (float)hiy * dx - bc.point[1], (float)hiz * dx - bc.point[2]};
+    float dpmin = 0.0f, mag = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+      dpmin += fminf(lo[a] * bc.normal[a], hi[a] * bc.normal[a]);
+      mag += fmaxf(fabsf(lo[a] * bc.normal[a]), fabsf(hi[a] * bc.normal[a]));
+    }
+    return dpmin < 1e-5f * mag + 1e-30f;  // margin for the different summation order
+  }
+  if (bc.type == BC_CUBOID) {
+    if (!in_window) return bc.reset == 1 && time < bc.end_time + 15.0f * dt;
+    // |g dx - p| < size somewhere in [lo, hi]: g dx - p is monotone in g
+    return ((float)lox * dx - bc.point[0] < bc.size[0]) && ((float)hix * dx - bc.point[0] > -bc.size[0]) &&
+           ((float)loy * dx - bc.point[1] < bc.size[1]) && ((float)hiy * dx - bc.point[1] > -bc.size[1]) &&
+           ((float)loz * dx - bc.point[2] < bc.size[2]) && ((float)hiz * dx - bc.point[2] > -bc.size[2]);
+  }
+  if (bc.type == BC_BBOX) {
+    const int padding = 3;
+    return in_window && (lox < padding || loy < padding || loz < padding || hix >= G - padding || hiy >= G - padding ||
+                         hiz >= G - padding);
+  }
+  return false;
+}
+
 // host-side `modify` of set_velocity_on_cuboid, mpm_solver.py:975-981
 inline void bc_host_modify(BC &bc, float time, float dt) {
   if (bc.type == BC_CUBOID && time >= bc.start_time && time < bc.end_time)

@@ -282,6 +282,134 @@ __global__ void k_dilate(const int *plist, int n_P, int NB, int *ab_flag) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// grid stage: grid_normalization_and_gravity (mpm_utils.py:561-572), damping (:1162-1174), mesh collide
+// (mpm_solver.py:882-917), mover overwrite (:790-799), BCs in registration order (:487-501), and the re-zeroing of the
+// accumulators (replaces zero_grid, :411-417).  In the fused substep there is no grid kernel: g2p evaluates the nodes
+// of its tile on the fly (node_update<false>) and the accumulators are cleared by extra workgroups of the next
+// substep's stress launch.
+// ------------------------------------------------------------------------------------------------
+struct GridPtrs {
+  float *mv;        // [block][4][64]: m, momentum xyz
+  float *vout;      // [block][4][64]: v_out xyz, m (copy kept for introspection)
+  float *col;       // [block][8][64]: weight, v_in xyz, normal xyz, pad
+  float *mov;       // [block][4][64]: weight, velocity xyz
+  const int *ab_flag;
+  int *col_flag;    // [block] 1 = the body-face splat may have written this block's collider channels this substep
+  int *m_flag;      // [block] 1 = p2g (or a halo sum) may have written this block's mass / momentum this substep
+  int *counters;    // [0] particles outside their tile margin, [1] dropped contributions (inactive block)
+  int dbg;          // MPMHIP_DBG bitmask (perf experiments only): 1 skip p2g flush, 2 skip p2g LDS atomics
+};
+
+struct GridParams {
+  float dt, gx, gy, gz, damping, time;
+  int has_col, has_mov, mov_on;
+  float col_friction;
+  int count;
+};
+
+// One node of the grid stage.  ZERO = true consumes the accumulators (re-zeroes what it read); ZERO = false only reads
+// them (g2p evaluates nodes on the fly while it stages its tile, k_zero_blocks / the zeroing workgroups of the next
+// stress launch clear them afterwards).  Returns the node's v_out; m_out = accumulated mass.
+template <bool ZERO>
+__device__ __forceinline__ V3 node_update(int blk, int l, const Dims &d, const GridPtrs &g, const GridParams &gp,
+                                          const BCList &bcl, float &m_out, int &ncol, int &nmov, bool use_col = true,
+                                          unsigned bc_mask = 0xffffffffu) {
+  float *pm = g.mv + ((size_t)blk * GCH_MV) * 64 + l;
+  float m = pm[0], px = pm[64], py = pm[128], pz = pm[192];
+  V3 v = v3(0, 0, 0);
+  if (m > 1e-15f) {
+    float inv = 1.0f / m;
+    v = v3(px * inv + gp.dt * gp.gx, py * inv + gp.dt * gp.gy, pz * inv + gp.dt * gp.gz);
+  }
+  if (gp.damping < 1.0f) v = v - (1.0f - gp.damping) * v;
+  if (ZERO && (m != 0.0f || px != 0.0f || py != 0.0f || pz != 0.0f)) { pm[0] = 0.0f; pm[64] = 0.0f; pm[128] = 0.0f; pm[192] = 0.0f; }
+  if (gp.has_col && use_col) {  // normalize_grid + collide, mpm_solver.py:882-917
+    float *pc = g.col + ((size_t)blk * GCH_COL) * 64 + l;
+    float wc = pc[0];
+    if (wc != 0.0f) {
+      V3 vin = v3(pc[64], pc[128], pc[192]), nrm = v3(pc[256], pc[320], pc[384]);
+      if (wc > 1e-15f) { v = collide_node(v, (1.0f / wc) * vin, nrm, gp.col_friction); ncol = 1; }
+      if (ZERO) { pc[0] = 0.0f; pc[64] = 0.0f; pc[128] = 0.0f; pc[192] = 0.0f; pc[256] = 0.0f; pc[320] = 0.0f; pc[384] = 0.0f; }
+    }
+  }
+  if (gp.has_mov && gp.mov_on) {
+    float *pv = g.mov + ((size_t)blk * GCH_MOV) * 64 + l;
+    float wv = pv[0];
+    if (wv != 0.0f) {
+      if (wv > 1e-15f) { v = (1.0f / wv) * v3(pv[64], pv[128], pv[192]); nmov = 1; }
+      if (ZERO) { pv[0] = 0.0f; pv[64] = 0.0f; pv[128] = 0.0f; pv[192] = 0.0f; }
+    }
+  }
+  if (bcl.n > 0 && bc_mask != 0u) {
+    int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
+    int gxn = 4 * bx + (l >> 4), gyn = 4 * by + ((l >> 2) & 3), gzn = 4 * bz + (l & 3);
+    if (in_grid(gxn, gyn, gzn, d.G)) {
+      size_t dense = ((size_t)gxn * d.G + gyn) * d.G + gzn;
+      for (int k = 0; k < bcl.n; ++k)
+        if ((bc_mask >> k) & 1u) apply_bc(bcl.bc[k], v, gxn, gyn, gzn, d.G, d.dx, gp.time, gp.dt, dense);
+    }
+  }
+  m_out = m;
+  return v;
+}
+
+// Stand-alone grid stage: writes v_out (and the node mass, for introspection).  ZERO = true is the classic form
+// (profiling runs, where every phase of the reference gets its own launch); ZERO = false materialises v_out after a
+// fused substep for export_grid / stats without disturbing the accumulators.
+template <bool ZERO>
+__global__ __launch_bounds__(TPB) void k_grid(const int *alist, int n_A, Dims d, GridPtrs g, GridParams gp, BCList bcl) {
+  int w = xcd_slice(blockIdx.x, (n_A + 3) / 4);
+  if (w < 0) return;
+  int a = w * 4 + (threadIdx.x >> 6);
+  if (a >= n_A) return;
+  int blk = alist[a], l = threadIdx.x & 63;
+  int ncol = 0, nmov = 0;
+  float m;
+  V3 v = node_update<ZERO>(blk, l, d, g, gp, bcl, m, ncol, nmov);
+  float *po = g.vout + ((size_t)blk * GCH_VOUT) * 64 + l;
+  po[0] = v.x; po[64] = v.y; po[128] = v.z; po[192] = m;
+  if (ZERO && l == 0) { g.m_flag[blk] = 0; if (gp.has_col) g.col_flag[blk] = 0; }
+  if (gp.count) {  // statistics for the algorithmic-bytes formula (N_coll, N_mov), one atomic per wavefront
+    unsigned long long bc = __ballot(ncol), bm = __ballot(nmov);
+    if (l == 0) {
+      if (bc) atomicAdd(g.counters + 2, __popcll(bc));
+      if (bm) atomicAdd(g.counters + 3, __popcll(bm));
+    }
+  }
+}
+
+// Clear the accumulators of one block after a fused substep (what node_update<true> would have cleared).
+__device__ __forceinline__ void zero_block(int blk, int l, const GridPtrs &g, int has_col, int has_mov) {
+  if (g.m_flag[blk]) {  // wave-uniform
+    float *pm = g.mv + ((size_t)blk * GCH_MV) * 64 + l;
+    float m = pm[0], px = pm[64], py = pm[128], pz = pm[192];
+    if (m != 0.0f || px != 0.0f || py != 0.0f || pz != 0.0f) { pm[0] = 0.0f; pm[64] = 0.0f; pm[128] = 0.0f; pm[192] = 0.0f; }
+    if (l == 0) g.m_flag[blk] = 0;
+  }
+  if (has_col && g.col_flag[blk]) {  // wave-uniform
+    float *pc = g.col + ((size_t)blk * GCH_COL) * 64 + l;
+    if (pc[0] != 0.0f) { pc[0] = 0.0f; pc[64] = 0.0f; pc[128] = 0.0f; pc[192] = 0.0f; pc[256] = 0.0f; pc[320] = 0.0f; pc[384] = 0.0f; }
+    if (l == 0) g.col_flag[blk] = 0;
+  }
+  if (has_mov) {
+    float *pv = g.mov + ((size_t)blk * GCH_MOV) * 64 + l;
+    if (pv[0] != 0.0f) { pv[0] = 0.0f; pv[64] = 0.0f; pv[128] = 0.0f; pv[192] = 0.0f; }
+  }
+}
+// The zeroing rides in the next substep's stress launch as extra workgroups (ZeroArgs); stand-alone only before a
+// re-sort (the active list is about to change) or when no stress kernel runs.
+struct ZeroArgs {
+  const int *alist;
+  int n_A, n_wg;  // n_wg = workgroups [0, n_wg) of the launch that clear 4 blocks each (0: nothing to clear)
+  int has_col, has_mov;
+};
+__device__ __forceinline__ void zero_blocks_wg(const ZeroArgs &z, int wg, const GridPtrs &g) {
+  int a = wg * 4 + (int)(threadIdx.x >> 6);
+  if (a < z.n_A) zero_block(z.alist[a], threadIdx.x & 63, g, z.has_col, z.has_mov);
+}
+__global__ __launch_bounds__(TPB) void k_zero_blocks(ZeroArgs z, GridPtrs g) { zero_blocks_wg(z, blockIdx.x, g); }
+
+// ------------------------------------------------------------------------------------------------
 // stress (compute_stress_from_F_trial, mpm_utils.py:1017-1105) on the sorted SoA state
 // ------------------------------------------------------------------------------------------------
 // FINALIZE = true fuses the tail of the previous substep's g2p_e (x, v = mean of the three updated vertices,
@@ -290,7 +418,9 @@ __global__ void k_dilate(const int *plist, int n_P, int NB, int *ab_flag) {
 // finished elements earlier (re-sort, read-back, pre-p2g operations, joint-face splats, multi-GPU ghosts).
 template <bool FINALIZE>
 __global__ void k_stress_elem(Bufs b, F3 *ef, Dims d, float friction_coeff, const int *face_slot,
-                              const unsigned *skeys, int blk_bits, int *counters) {
+                              const unsigned *skeys, int blk_bits, int *counters, ZeroArgs z, GridPtrs g) {
+  const int n_main = (d.n_e + TPB - 1) / TPB;  // the zeroing workgroups come last: they fill the tail of the launch
+  if ((int)blockIdx.x >= n_main) { zero_blocks_wg(z, (int)blockIdx.x - n_main, g); return; }
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.n_e) return;
   if (b.sel[e] == 1) {  // not simulated (selection == 2 marks a ghost copy: stress yes, transfers no)
@@ -334,7 +464,9 @@ __global__ void k_stress_elem(Bufs b, F3 *ef, Dims d, float friction_coeff, cons
   ef[2 * d.n_e + e] = F3{f3.x, f3.y, f3.z};
 }
 
-__global__ void k_stress_trad(Bufs b, Dims d, mpmhip_model_scalars sc, float dt) {
+__global__ void k_stress_trad(Bufs b, Dims d, mpmhip_model_scalars sc, float dt, ZeroArgs z, GridPtrs g) {
+  const int n_main = (d.n_t + TPB - 1) / TPB;
+  if ((int)blockIdx.x >= n_main) { zero_blocks_wg(z, (int)blockIdx.x - n_main, g); return; }
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= d.n_t) return;
   int s = t + d.n_e;
@@ -353,16 +485,6 @@ __global__ void k_stress_trad(Bufs b, Dims d, mpmhip_model_scalars sc, float dt)
 // ------------------------------------------------------------------------------------------------
 // p2g (p2g_apic_with_stress, mpm_utils.py:484-557): LDS tile accumulation per particle-block chunk
 // ------------------------------------------------------------------------------------------------
-struct GridPtrs {
-  float *mv;        // [block][4][64]: m, momentum xyz
-  float *vout;      // [block][4][64]: v_out xyz, m (copy kept for introspection)
-  float *col;       // [block][8][64]: weight, v_in xyz, normal xyz, pad
-  float *mov;       // [block][4][64]: weight, velocity xyz
-  const int *ab_flag;
-  int *esc_list;    // [n_p] sorted indices of particles queued for k_g2p_escaped
-  int *counters;    // [0] particles outside their tile margin, [1] dropped contributions (inactive block)
-  int dbg;          // MPMHIP_DBG bitmask (perf experiments only): 1 skip p2g flush, 2 skip p2g LDS atomics
-};
 
 // The LDS tile is stored with padded strides (i*99 + j*9 + k) so that the 27 nodes of a 3x3x3 stencil fall into
 // different banks (99 = 3 mod 32, 9, 1).
@@ -544,6 +666,7 @@ __device__ __forceinline__ void col_splat_pass(double *tile, const FaceBin &fb, 
         int nb = blk_of(x, y, z, d.NB);
         if (g.ab_flag[nb]) {
           float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
+          g.col_flag[nb] = 1;
           atomicAdd(p, w);
           atomicAdd(p + 64, w * a.x); atomicAdd(p + 128, w * a.y); atomicAdd(p + 192, w * a.z);
           atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
@@ -566,7 +689,7 @@ __device__ __forceinline__ void col_splat_pass(double *tile, const FaceBin &fb, 
     if (!((act_mask >> nidx) & 1ull)) continue;  // inactive block: never read by g2p, never re-zeroed
     float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z) + (PASS == 0 ? 0 : 256);
     atomicAdd(p, c0); atomicAdd(p + 64, c1); atomicAdd(p + 128, c2);
-    if (PASS == 0) atomicAdd(p + 192, c3);
+    if (PASS == 0) { atomicAdd(p + 192, c3); g.col_flag[nb] = 1; }
   }
   __syncthreads();
 }
@@ -771,6 +894,7 @@ __device__ __forceinline__ void p2g_escaped(const Bufs &b, const VAdj &va, int c
     int blk = blk_of(x, y, z, d.NB);
     if (!g.ab_flag[blk]) { atomicAdd(g.counters + 1, 1); continue; }
     float *p = g.mv + ((size_t)blk * GCH_MV) * 64 + loc_of(x, y, z);
+    g.m_flag[blk] = 1;
     atomicAdd(p, wm);
     atomicAdd(p + 64, add.x); atomicAdd(p + 128, add.y); atomicAdd(p + 192, add.z);
   }
@@ -874,72 +998,11 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *re
     if (m == 0.0f && px == 0.0f && py == 0.0f && pz == 0.0f) continue;
     int x = ox + ti, y = oy + tj, z = oz + tk;
     if (!in_grid(x, y, z, d.G)) continue;
-    float *p = g.mv + ((size_t)blk_of(x, y, z, d.NB) * GCH_MV) * 64 + loc_of(x, y, z);
+    int nb = blk_of(x, y, z, d.NB);
+    float *p = g.mv + ((size_t)nb * GCH_MV) * 64 + loc_of(x, y, z);
+    g.m_flag[nb] = 1;
     atomicAdd(p, m);
     atomicAdd(p + 64, px); atomicAdd(p + 128, py); atomicAdd(p + 192, pz);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// grid stage over active blocks: grid_normalization_and_gravity (mpm_utils.py:561-572), damping
-// (:1162-1174), mesh collide (mpm_solver.py:882-917), mover overwrite (:790-799), BCs in registration
-// order (:487-501); then re-zero the accumulators for the next substep (replaces zero_grid, :411-417).
-// One wavefront per block, lane = node.
-// ------------------------------------------------------------------------------------------------
-struct GridParams {
-  float dt, gx, gy, gz, damping, time;
-  int has_col, has_mov, mov_on;
-  float col_friction;
-  int count;
-};
-
-__global__ __launch_bounds__(TPB) void k_grid(const int *alist, int n_A, Dims d, GridPtrs g, GridParams gp, BCList bcl) {
-  int w = xcd_slice(blockIdx.x, (n_A + 3) / 4);
-  if (w < 0) return;
-  int a = w * 4 + (threadIdx.x >> 6);
-  if (a >= n_A) return;
-  int blk = alist[a], l = threadIdx.x & 63;
-  float *pm = g.mv + ((size_t)blk * GCH_MV) * 64 + l;
-  float m = pm[0], px = pm[64], py = pm[128], pz = pm[192];
-  V3 v = v3(0, 0, 0);
-  int ncol = 0, nmov = 0;
-  if (m > 1e-15f) {
-    float inv = 1.0f / m;
-    v = v3(px * inv + gp.dt * gp.gx, py * inv + gp.dt * gp.gy, pz * inv + gp.dt * gp.gz);
-  }
-  if (gp.damping < 1.0f) v = v - (1.0f - gp.damping) * v;
-  if (m != 0.0f || px != 0.0f || py != 0.0f || pz != 0.0f) { pm[0] = 0.0f; pm[64] = 0.0f; pm[128] = 0.0f; pm[192] = 0.0f; }
-  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
-  int gxn = 4 * bx + (l >> 4), gyn = 4 * by + ((l >> 2) & 3), gzn = 4 * bz + (l & 3);
-  if (gp.has_col) {  // normalize_grid + collide, mpm_solver.py:882-917
-    float *pc = g.col + ((size_t)blk * GCH_COL) * 64 + l;
-    float wc = pc[0];
-    if (wc != 0.0f) {
-      V3 vin = v3(pc[64], pc[128], pc[192]), nrm = v3(pc[256], pc[320], pc[384]);
-      if (wc > 1e-15f) { v = collide_node(v, (1.0f / wc) * vin, nrm, gp.col_friction); ncol = 1; }
-      pc[0] = 0.0f; pc[64] = 0.0f; pc[128] = 0.0f; pc[192] = 0.0f; pc[256] = 0.0f; pc[320] = 0.0f; pc[384] = 0.0f;
-    }
-  }
-  if (gp.has_mov && gp.mov_on) {
-    float *pv = g.mov + ((size_t)blk * GCH_MOV) * 64 + l;
-    float wv = pv[0];
-    if (wv != 0.0f) {
-      if (wv > 1e-15f) { v = (1.0f / wv) * v3(pv[64], pv[128], pv[192]); nmov = 1; }
-      pv[0] = 0.0f; pv[64] = 0.0f; pv[128] = 0.0f; pv[192] = 0.0f;
-    }
-  }
-  if (bcl.n > 0 && in_grid(gxn, gyn, gzn, d.G)) {
-    size_t dense = ((size_t)gxn * d.G + gyn) * d.G + gzn;
-    for (int k = 0; k < bcl.n; ++k) apply_bc(bcl.bc[k], v, gxn, gyn, gzn, d.G, d.dx, gp.time, gp.dt, dense);
-  }
-  float *po = g.vout + ((size_t)blk * GCH_VOUT) * 64 + l;
-  po[0] = v.x; po[64] = v.y; po[128] = v.z; po[192] = m;
-  if (gp.count) {  // statistics for the algorithmic-bytes formula (N_coll, N_mov), one atomic per wavefront
-    unsigned long long bc = __ballot(ncol), bm = __ballot(nmov);
-    if (l == 0) {
-      if (bc) atomicAdd(g.counters + 2, __popcll(bc));
-      if (bm) atomicAdd(g.counters + 3, __popcll(bm));
-    }
   }
 }
 
@@ -1002,7 +1065,9 @@ __device__ __forceinline__ G2PResult g2p_gather(const float *tile, int ox, int o
 
 // same sums for a particle that drifted out of its tile margin: rolled loop over the global grid (zero outside
 // active blocks); kept small so that it does not set the kernel's register budget
-__device__ __forceinline__ G2PResult g2p_gather_global(V3 x, const Dims &d, const GridPtrs &g) {
+template <bool FUSED>
+__device__ __forceinline__ G2PResult g2p_gather_global(V3 x, const Dims &d, const GridPtrs &g, const GridParams &gp,
+                                                       const BCList &bcl) {
   Stencil s = make_stencil(x, d.inv_dx);
   V3 nv = v3(0, 0, 0), Mx = v3(0, 0, 0), My = v3(0, 0, 0), Mz = v3(0, 0, 0);
   V3 Fx = v3(0, 0, 0), Fy = v3(0, 0, 0), Fz = v3(0, 0, 0);
@@ -1016,8 +1081,14 @@ __device__ __forceinline__ G2PResult g2p_gather_global(V3 x, const Dims &d, cons
     if (in_grid(x_, y_, z_, d.G)) {
       int blk = blk_of(x_, y_, z_, d.NB);
       if (g.ab_flag[blk]) {
-        const float *p = g.vout + ((size_t)blk * GCH_VOUT) * 64 + loc_of(x_, y_, z_);
-        u = v3(p[0], p[64], p[128]);
+        if (FUSED) {
+          float m;
+          int nc = 0, nm = 0;
+          u = node_update<false>(blk, loc_of(x_, y_, z_), d, g, gp, bcl, m, nc, nm);
+        } else {
+          const float *p = g.vout + ((size_t)blk * GCH_VOUT) * 64 + loc_of(x_, y_, z_);
+          u = v3(p[0], p[64], p[128]);
+        }
       }
     }
     float w = wx * wy * wz;
@@ -1050,7 +1121,13 @@ __device__ __forceinline__ void g2p_write(const Bufs &b, int cls, int s, V3 x, V
   if (cls == 1) st9(b.tr, T_FT, s - d.n_e, (m3_identity() + dt * r.F) * ld9(b.tr, T_F, s - d.n_e));
 }
 
-__global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const ChunkRec *recs, int n_chunks, Dims d, float dt, GridPtrs g) {
+// FUSED = true: there is no grid kernel in the substep; the tile is staged from the accumulators and every node goes
+// through node_update<false> on the way (normalise, gravity, damping, collide, mover, BCs).  Nodes shared by several
+// tiles are evaluated once per tile (about 2x redundant arithmetic, ~50 VALU instructions per node) in exchange for
+// one launch, one v_out round trip through HBM and one grid-wide dependency less per substep.
+template <bool FUSED>
+__global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const ChunkRec *recs, int n_chunks, Dims d, float dt, GridPtrs g,
+                                             GridParams gp, BCList bcl) {
   __shared__ float tile[3 * TILE_PAD];
   int w = xcd_slice(blockIdx.x, n_chunks);
   if (w < 0) return;
@@ -1069,13 +1146,40 @@ __global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const ChunkRec *recs, int n
     int lx = (int)(x.x * d.inv_dx - 0.5f) - ox, ly = (int)(x.y * d.inv_dx - 0.5f) - oy, lz = (int)(x.z * d.inv_dx - 0.5f) - oz;
     escaped = (unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u;  // drifted out of the tile margin
   }
+  // tile-level shortcuts for the fused node evaluation (both wave-uniform): which of the 27 overlapped blocks may
+  // carry body-collider data this substep (flags set by the splat), and which BCs can reach this tile at all
+  unsigned long long col_mask = 0, m_mask = 0;
+  unsigned bc_mask = 0;
+  if (FUSED) {
+    int l = threadIdx.x & 63, fl = 0, fm = 0;
+    if (l < 27) {
+      int nx = bx + l / 9 - 1, ny = by + (l / 3) % 3 - 1, nz = bz + l % 3 - 1;
+      if ((unsigned)nx < (unsigned)d.NB && (unsigned)ny < (unsigned)d.NB && (unsigned)nz < (unsigned)d.NB) {
+        fm = g.m_flag[(nx * d.NB + ny) * d.NB + nz];
+        if (gp.has_col) fl = g.col_flag[(nx * d.NB + ny) * d.NB + nz];
+      }
+    }
+    col_mask = __ballot(fl != 0);
+    m_mask = __ballot(fm != 0);  // a block nobody scattered into: its nodes carry no mass, hence no weight in any gather
+    for (int k = 0; k < bcl.n; ++k)
+      if (bc_may_touch(bcl.bc[k], ox, oy, oz, ox + 7, oy + 7, oz + 7, d.G, d.dx, gp.time, gp.dt)) bc_mask |= 1u << k;
+  }
+#pragma unroll
   for (int t = threadIdx.x; t < TILE3; t += TPB) {
     int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
     int gx = ox + ti, gy = oy + tj, gz = oz + tk;
     V3 v = v3(0, 0, 0);
     if (in_grid(gx, gy, gz, d.G)) {
-      const float *p = g.vout + ((size_t)blk_of(gx, gy, gz, d.NB) * GCH_VOUT) * 64 + loc_of(gx, gy, gz);
-      v = v3(p[0], p[64], p[128]);
+      int nb = blk_of(gx, gy, gz, d.NB), nl = loc_of(gx, gy, gz);
+      if (FUSED) {
+        float m;
+        int nc = 0, nm = 0;
+        int nidx = (((gx >> 2) - bx + 1) * 3 + ((gy >> 2) - by + 1)) * 3 + ((gz >> 2) - bz + 1);
+        if ((m_mask >> nidx) & 1ull) v = node_update<false>(nb, nl, d, g, gp, bcl, m, nc, nm, (col_mask >> nidx) & 1ull, bc_mask);
+      } else {
+        const float *p = g.vout + ((size_t)nb * GCH_VOUT) * 64 + nl;
+        v = v3(p[0], p[64], p[128]);
+      }
     }
     float *q = tile + tile_idx(ti, tj, tk);
     q[0] = v.x; q[TILE_PAD] = v.y; q[2 * TILE_PAD] = v.z;
@@ -1095,7 +1199,7 @@ __global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const ChunkRec *recs, int n
   if (__any(escaped)) {
     asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(s), "+v"(cls), "+v"(d3.x), "+v"(d3.y), "+v"(d3.z));
     if (escaped) {
-      G2PResult r = g2p_gather_global(x, d, g);
+      G2PResult r = g2p_gather_global<FUSED>(x, d, g, gp, bcl);
       g2p_write(b, cls, s, x, d3, r, ox, oy, oz, d, dt, g);
       atomicAdd(g.counters + 0, 1);
     }
@@ -1193,7 +1297,7 @@ __global__ void k_halo_add(const int *blocks, int n, GridPtrs g, int with_mov, c
   int blk = blocks[i];
   float v = in[t];
   if (v == 0.0f) return;
-  if (ch < 4) g.mv[((size_t)blk * GCH_MV + ch) * 64 + l] += v;
+  if (ch < 4) { g.mv[((size_t)blk * GCH_MV + ch) * 64 + l] += v; g.m_flag[blk] = 1; }
   else g.mov[((size_t)blk * GCH_MOV + (ch - 4)) * 64 + l] += v;
 }
 // ghosts: x, v of vertices / traditional particles (6 floats) and the director d3 of elements (3 floats);
@@ -1363,7 +1467,13 @@ struct FastState {
   bool have_order = false;
   int64_t rebins = 0;
   int rebin_interval = 32;
-  bool adaptive_rebin = true;  // false: ignore the drift flag (tests of the out-of-margin paths)
+  bool adaptive_rebin = true;
+  // fused grid stage: after a substep the accumulators of the active blocks are still loaded (g2p only read them);
+  // they are cleared by the next substep's stress launch (ZeroArgs) or, before a re-sort, by k_zero_blocks
+  bool fuse_grid = true, grid_dirty = false;
+  int dirty_col = 0, dirty_mov = 0;
+  GridParams last_gp{};
+  BCList last_bcl{};  // false: ignore the drift flag (tests of the out-of-margin paths)
   std::vector<void *> allocs;
 };
 
@@ -1465,11 +1575,33 @@ int do_import(mpmhip_ctx *c) {
   return MPMHIP_OK;
 }
 
+static ZeroArgs take_zero(FastState *f) {
+  ZeroArgs z{f->alist, f->n_A, 0, f->dirty_col, f->dirty_mov};
+  if (f->grid_dirty && f->n_A) z.n_wg = (f->n_A + 3) / 4;
+  f->grid_dirty = false;
+  return z;
+}
+// clear the accumulators now (the active list is about to change, or nothing else will do it)
+static void flush_grid(mpmhip_ctx *c) {
+  FastState *f = c->fast;
+  ZeroArgs z = take_zero(f);
+  if (z.n_wg) hipLaunchKernelGGL(k_zero_blocks, (unsigned)z.n_wg, TPB, 0, c->stream, z, f->g);
+}
+// v_out of the last (fused) substep for export_grid / stats; the accumulators stay as they are
+static void materialize_grid(mpmhip_ctx *c, bool count) {
+  FastState *f = c->fast;
+  if (!f->grid_dirty || !f->n_A) return;
+  GridParams gp = f->last_gp;
+  gp.count = count ? 1 : 0;
+  hipLaunchKernelGGL(k_grid<false>, xcd_grid((f->n_A + 3) / 4), TPB, 0, c->stream, f->alist, f->n_A, f->d, f->g, gp, f->last_bcl);
+}
+
 int rebin(mpmhip_ctx *c) {
   FastState *f = c->fast;
   const Dims &d = f->d;
   hipStream_t s = c->stream;
   int cur = f->cur, alt = 1 - cur;
+  flush_grid(c);
   if (d.n_p == 0) { f->n_P = f->n_A = f->n_chunks = 0; f->steps_since_rebin = 0; return MPMHIP_OK; }
   flush_elements(c);
   hipLaunchKernelGGL(k_keys, nblk(d.n_p), TPB, 0, s, f->buf[cur], d, f->blk_bits, f->keys[0], f->iota);
@@ -1598,14 +1730,16 @@ int fast_init(mpmhip_ctx *c) {
   if ((rc = dalloc(c, &f->iota, (size_t)d.n_p))) return rc;
   if ((rc = dalloc(c, &f->g.mv, f->nblocks * GCH_MV * 64))) return rc;
   if ((rc = dalloc(c, &f->g.vout, f->nblocks * GCH_VOUT * 64))) return rc;
+  if ((rc = dalloc(c, &f->g.col_flag, f->nblocks))) return rc;
+  if ((rc = dalloc(c, &f->g.m_flag, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->g.counters, 8))) return rc;
-  if ((rc = dalloc(c, &f->g.esc_list, (size_t)d.n_p))) return rc;
   if ((rc = dalloc(c, &f->pb_flag, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->pb_index, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->ab_flag, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->ab_index, f->nblocks))) return rc;
   f->g.ab_flag = f->ab_flag;
   if (const char *e = getenv("MPMHIP_DBG")) f->g.dbg = atoi(e);
+  if (const char *e = getenv("MPMHIP_FUSE_GRID")) f->fuse_grid = atoi(e) != 0;
   MPM_HIP_CHECK(c, hipHostMalloc((void **)&f->h_pin, 64 * sizeof(int), hipHostMallocDefault));
   MPM_HIP_CHECK(c, hipEventCreateWithFlags(&f->ev_flag, hipEventDisableTiming));
   return MPMHIP_OK;
@@ -1735,16 +1869,22 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   sa.n_extra = (sa.n_fbins + sa.n_mov_wg + 7) & ~7;
   {
     ScopedPhase ph(c, "compute_stress_from_F_trial");
+    ZeroArgs z = take_zero(f), z0{f->alist, 0, 0, 0, 0};  // clears what the previous fused substep left loaded
     if (d.n_e) {
       if (f->elem_pending)
-        hipLaunchKernelGGL(k_stress_elem<true>, nblk(d.n_e), TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff, f->face_slot,
-                           f->keys[1], f->blk_bits, f->g.counters);
+        hipLaunchKernelGGL(k_stress_elem<true>, nblk(d.n_e) + z.n_wg, TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff,
+                           f->face_slot, f->keys[1], f->blk_bits, f->g.counters, z, f->g);
       else
-        hipLaunchKernelGGL(k_stress_elem<false>, nblk(d.n_e), TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff, f->face_slot,
-                           f->keys[1], f->blk_bits, f->g.counters);
+        hipLaunchKernelGGL(k_stress_elem<false>, nblk(d.n_e) + z.n_wg, TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff,
+                           f->face_slot, f->keys[1], f->blk_bits, f->g.counters, z, f->g);
       f->elem_pending = false;
+      z = z0;
     }
-    if (d.n_t) hipLaunchKernelGGL(k_stress_trad, nblk(d.n_t), TPB, 0, s, b, d, c->sc, dt);
+    if (d.n_t) {
+      hipLaunchKernelGGL(k_stress_trad, nblk(d.n_t) + z.n_wg, TPB, 0, s, b, d, c->sc, dt, z, f->g);
+      z = z0;
+    }
+    if (z.n_wg) hipLaunchKernelGGL(k_zero_blocks, (unsigned)z.n_wg, TPB, 0, s, z, f->g);
   }
   if (c->profiling && sa.n_extra) {
     {
@@ -1785,24 +1925,41 @@ static int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
   const float dt = a.dt;
   Bufs &b = f->buf[f->cur];
   bool mov_on = a.joint_v_v && a.joint_f_v && !c->movers.empty();
-  {
+  GridParams gp{dt, c->sc.g[0], c->sc.g[1], c->sc.g[2], c->sc.grid_v_damping_scale, (float)c->time,
+                (c->colliders.empty() || !c->num_mesh_f) ? 0 : 1, c->movers.empty() ? 0 : 1, mov_on ? 1 : 0,
+                c->colliders.empty() ? 0.0f : c->colliders[0].friction, 0};
+  BCList bcl{};
+  bcl.n = (int)c->bcs.size();
+  for (int k = 0; k < bcl.n; ++k) bcl.bc[k] = c->bcs[k];
+  const bool fused = f->fuse_grid && !c->profiling;
+  if (!fused) {
     ScopedPhase ph(c, "grid_update");
-    GridParams gp{dt, c->sc.g[0], c->sc.g[1], c->sc.g[2], c->sc.grid_v_damping_scale, (float)c->time,
-                  (c->colliders.empty() || !c->num_mesh_f) ? 0 : 1, c->movers.empty() ? 0 : 1, mov_on ? 1 : 0,
-                  c->colliders.empty() ? 0.0f : c->colliders[0].friction, 1};
+    gp.count = 1;
     f->stat_steps += 1;
-    BCList bcl{};
-    bcl.n = (int)c->bcs.size();
-    for (int k = 0; k < bcl.n; ++k) bcl.bc[k] = c->bcs[k];
     if (f->n_A)
-      hipLaunchKernelGGL(k_grid, xcd_grid((f->n_A + 3) / 4), TPB, 0, s, f->alist, f->n_A, d, f->g, gp, bcl);
-    for (auto &bc : c->bcs) bc_host_modify(bc, (float)c->time, dt);
+      hipLaunchKernelGGL(k_grid<true>, xcd_grid((f->n_A + 3) / 4), TPB, 0, s, f->alist, f->n_A, d, f->g, gp, bcl);
   }
+  for (auto &bc : c->bcs) bc_host_modify(bc, (float)c->time, dt);
   {
     ScopedPhase ph(c, "g2p_v");
     if (f->n_chunks) {
-      hipLaunchKernelGGL(k_g2p, xcd_grid(f->n_chunks), TPB, 0, s, b, f->chunks, f->n_chunks, d, dt, f->g);
+      if (fused) {
+        GridParams gq = gp;
+        BCList bq = bcl;
+        if (f->g.dbg & 32) gq.has_col = 0;
+        if (f->g.dbg & 64) bq.n = 0;
+        hipLaunchKernelGGL(k_g2p<true>, xcd_grid(f->n_chunks), TPB, 0, s, b, f->chunks, f->n_chunks, d, dt, f->g, gq, bq);
+      }
+      else
+        hipLaunchKernelGGL(k_g2p<false>, xcd_grid(f->n_chunks), TPB, 0, s, b, f->chunks, f->n_chunks, d, dt, f->g, gp, bcl);
     }
+  }
+  if (fused) {
+    f->grid_dirty = true;
+    f->dirty_col = gp.has_col;
+    f->dirty_mov = gp.has_mov && gp.mov_on;
+    f->last_gp = gp;
+    f->last_bcl = bcl;
   }
   return MPMHIP_OK;
 }
@@ -2066,6 +2223,7 @@ int fast_export_grid(mpmhip_ctx *c, float *m, float *v_in, float *v_out) {
   if (m) MPM_HIP_CHECK(c, hipMemsetAsync(m, 0, n * sizeof(float), c->stream));
   if (v_in) MPM_HIP_CHECK(c, hipMemsetAsync(v_in, 0, 3 * n * sizeof(float), c->stream));  // consumed by the grid stage
   if (v_out) MPM_HIP_CHECK(c, hipMemsetAsync(v_out, 0, 3 * n * sizeof(float), c->stream));
+  materialize_grid(c, false);
   if (f->n_A) hipLaunchKernelGGL(k_export_grid, (unsigned)((f->n_A + 3) / 4), TPB, 0, c->stream, f->alist, f->n_A, d, f->g, m, v_out);
   MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
   return MPMHIP_OK;
@@ -2076,6 +2234,11 @@ int fast_stats(mpmhip_ctx *c, mpmhip_stats *out) {
   out->rebins = f->rebins;
   out->n_active_blocks = f->n_A;
   int *dcnt = f->g.counters + 4;
+  if (f->grid_dirty) {  // fused substeps do not count collider / mover nodes: count the last substep now
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + 2, 0, 2 * sizeof(int), c->stream));
+    materialize_grid(c, true);
+    f->stat_steps = 1;
+  }
   MPM_HIP_CHECK(c, hipMemsetAsync(dcnt, 0, sizeof(int), c->stream));
   if (f->n_A) hipLaunchKernelGGL(k_count_active, (unsigned)((f->n_A + 3) / 4), TPB, 0, c->stream, f->alist, f->n_A, f->g, dcnt);
   MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 8, f->g.counters, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
