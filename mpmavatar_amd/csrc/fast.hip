@@ -2,16 +2,21 @@
 //
 // Data layout:
 //   * particles live in a solver-owned SoA copy (component-major fp32 arrays), ordered class-major
-//     (elements | traditional | vertices) and, inside each class, by (4x4x4-cell grid block, cell).  The
-//     order is rebuilt every `rebin_interval` substeps (rocPRIM radix sort of 30-bit keys + one gather
-//     pass); between rebuilds a particle may drift by up to one cell, which the transfer tiles absorb.
+//     (elements | traditional | vertices) and, inside each class, by (4x4x4-cell grid block, cell).  The order is
+//     rebuilt (rocPRIM radix sort of 30-bit keys + one gather pass) when a device-side drift flag asks for it, at the
+//     latest every `rebin_interval` substeps; until then a particle may sit up to one cell outside its block, which
+//     the transfer tiles absorb, and anything further out takes global-memory paths inside the same kernels.
 //   * the grid is stored block-major: block b = (x>>2,y>>2,z>>2) owns 64 nodes, channel-major inside the
 //     block ([block][channel][64 nodes]) so one wavefront reads one channel of one block as 256 B.
-//     Only blocks on the active list (27-neighbourhoods of particle blocks) are ever swept or zeroed.
-// Kernels per substep:
-//   stress (per-particle map)  ->  p2g (one workgroup per particle block chunk: LDS 8x8x8-node tile,
-//   ds_add_f32 accumulation, coalesced flush)  [+ body-face / joint splats]  ->  grid (normalise, gravity,
-//   collider, mover, BCs, re-zero)  ->  g2p (LDS-staged 8x8x8 v_out tile)  ->  element finalise.
+//     Only blocks on the active list (27-neighbourhoods of particle blocks) are ever touched.
+// Launches per substep (single stream, no events):
+//   1. stress      per-particle map; fuses the tail of the previous substep's g2p_e (element finalise) and carries
+//                  extra workgroups that clear the grid accumulators the previous substep left loaded
+//   2. p2g         one workgroup per 256-particle chunk of a block: fp64 LDS tile (8x8x8 nodes), DPP pre-reduction,
+//                  ds_add_f64, coalesced flush; extra workgroups do the body-face and joint splats
+//   3. g2p         same chunks; the tile is staged from the accumulators and every node goes through the grid stage
+//                  (normalise, gravity, damping, collide, mover, BCs) on the way -- there is no grid kernel
+// Profiling runs (one sync per reference phase) and export use the stand-alone k_grid instead.
 // Reference semantics: /root/reference/warp_mpm/mpm_utils.py, mpm_solver.py:229-536 (cited per kernel).
 #include <algorithm>
 #include <cstring>
@@ -297,7 +302,8 @@ struct GridPtrs {
   int *col_flag;    // [block] 1 = the body-face splat may have written this block's collider channels this substep
   int *m_flag;      // [block] 1 = p2g (or a halo sum) may have written this block's mass / momentum this substep
   int *counters;    // [0] particles outside their tile margin, [1] dropped contributions (inactive block)
-  int dbg;          // MPMHIP_DBG bitmask (perf experiments only): 1 skip p2g flush, 2 skip p2g LDS atomics
+  int dbg;          // MPMHIP_DBG bitmask (perf experiments only, results are wrong): 1 skip p2g flush, 2 skip the p2g
+                    // scatter, 8 / 16 skip vertex-force / stress loads, 128 skip the LDS atomics only
 };
 
 struct GridParams {
@@ -947,6 +953,7 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *re
     unsigned long long tails = __ballot(sm.tail);
     int dist = __ffsll((unsigned long long)(tails >> (threadIdx.x & 63))) - 1;
     bool do_add = valid && (dist & ((1 << STEPS) - 1)) == 0;
+    if (g.dbg & 128) do_add = false;
     const Stencil &st = q.s;
     // factored stencil: add_ijk = wm (B_ij + k Cz) + wz_k P_ij + dwz_k Q_ij, wm = wxy_ij (wz_k m)
     float wzm0 = st.w0.z * q.mass, wzm1 = st.w1.z * q.mass, wzm2 = st.w2.z * q.mass;
@@ -1943,13 +1950,8 @@ static int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
   {
     ScopedPhase ph(c, "g2p_v");
     if (f->n_chunks) {
-      if (fused) {
-        GridParams gq = gp;
-        BCList bq = bcl;
-        if (f->g.dbg & 32) gq.has_col = 0;
-        if (f->g.dbg & 64) bq.n = 0;
-        hipLaunchKernelGGL(k_g2p<true>, xcd_grid(f->n_chunks), TPB, 0, s, b, f->chunks, f->n_chunks, d, dt, f->g, gq, bq);
-      }
+      if (fused)
+        hipLaunchKernelGGL(k_g2p<true>, xcd_grid(f->n_chunks), TPB, 0, s, b, f->chunks, f->n_chunks, d, dt, f->g, gp, bcl);
       else
         hipLaunchKernelGGL(k_g2p<false>, xcd_grid(f->n_chunks), TPB, 0, s, b, f->chunks, f->n_chunks, d, dt, f->g, gp, bcl);
     }
