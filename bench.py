@@ -151,7 +151,7 @@ def main():
         "metric": "MPM substeps/sec (500k particles, 256^3 grid)", "value": args.steps / elapsed, "unit": "substeps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": sc.name, "n_particles": sc.n_particles, "n_elements": sc.n_elements,
+        "config": {"workload": args.scene, "scene_name": sc.name, "n_particles": sc.n_particles, "n_elements": sc.n_elements,
                    "n_vertices": sc.n_vertices, "n_traditional": sc.n_traditional, "n_grid": sc.n_grid,
                    "dt": sc.dt, "mode": args.mode, "parallelism": f"slab{world}" if world > 1 else "single"},
     }
