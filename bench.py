@@ -125,10 +125,12 @@ def main():
         else:
             dist.init_process_group(backend)
         sim = mdist.build_sharded(sc, dev, rank, world, rebin_interval=args.rebin_interval)
+        transport = sim.transport
         run = lambda n: mdist.run(sim, n)
         barrier = lambda: dist.barrier()
     else:
         sim = harness.build_solver(sc, dev, mode=args.mode, rebin_interval=args.rebin_interval)
+        transport = None
         run = lambda n: harness.run(sim, n, fused=True)
         barrier = lambda: None
 
@@ -153,7 +155,8 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.scene, "scene_name": sc.name, "n_particles": sc.n_particles, "n_elements": sc.n_elements,
                    "n_vertices": sc.n_vertices, "n_traditional": sc.n_traditional, "n_grid": sc.n_grid,
-                   "dt": sc.dt, "mode": args.mode, "parallelism": f"slab{world}" if world > 1 else "single"},
+                   "dt": sc.dt, "mode": args.mode, "parallelism": f"slab{world}" if world > 1 else "single",
+                   "exchange": transport},
     }
 
     if world == 1:

@@ -1288,51 +1288,80 @@ __global__ void k_count_active(const int *alist, int n_A, GridPtrs g, int *out) 
 
 // ---- multi-GPU exchange helpers (mpmavatar_amd/dist.py drives them) ---------------------------------------
 // halo: the (m, momentum) and mover channels of the grid blocks two ranks both have on their active lists
-__global__ void k_halo_pack(const int *blocks, int n, GridPtrs g, int with_mov, float *out) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int CH = with_mov ? 8 : 4;
-  if (t >= n * CH * 64) return;
-  int l = t & 63, ch = (t >> 6) % CH, i = t / (CH * 64);
-  int blk = blocks[i];
-  out[t] = ch < 4 ? g.mv[((size_t)blk * GCH_MV + ch) * 64 + l] : g.mov[((size_t)blk * GCH_MOV + (ch - 4)) * 64 + l];
+// One launch serves up to PEER_TAB neighbours: workgroups [wg_off[p], wg_off[p+1]) belong to peer p.
+constexpr int PEER_TAB = 8;
+struct HaloTab {
+  int n, with_mov;
+  int wg_off[PEER_TAB + 1];
+  const int *blocks[PEER_TAB];
+  int n_blocks[PEER_TAB];
+  float *buf[PEER_TAB];
+};
+struct GhostTab {
+  int n;
+  int wg_off[PEER_TAB + 1];
+  const int *ids_p[PEER_TAB], *ids_e[PEER_TAB];
+  int n_p[PEER_TAB], n_e[PEER_TAB];
+  float *buf[PEER_TAB];
+};
+template <class Tab>
+__device__ __forceinline__ int tab_peer(const Tab &t, int wg) {
+  int p = 0;
+  while (p + 1 < t.n && wg >= t.wg_off[p + 1]) ++p;
+  return p;
 }
-__global__ void k_halo_add(const int *blocks, int n, GridPtrs g, int with_mov, const float *in) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int CH = with_mov ? 8 : 4;
-  if (t >= n * CH * 64) return;
+__global__ void k_halo_pack(HaloTab tb, GridPtrs g) {
+  int p = tab_peer(tb, blockIdx.x);
+  int t = ((int)blockIdx.x - tb.wg_off[p]) * blockDim.x + threadIdx.x;
+  int CH = tb.with_mov ? 8 : 4;
+  if (t >= tb.n_blocks[p] * CH * 64) return;
   int l = t & 63, ch = (t >> 6) % CH, i = t / (CH * 64);
-  int blk = blocks[i];
-  float v = in[t];
+  int blk = tb.blocks[p][i];
+  tb.buf[p][t] = ch < 4 ? g.mv[((size_t)blk * GCH_MV + ch) * 64 + l] : g.mov[((size_t)blk * GCH_MOV + (ch - 4)) * 64 + l];
+}
+// a block can be shared with more than one peer (slabs thinner than two blocks): atomic adds
+__global__ void k_halo_add(HaloTab tb, GridPtrs g) {
+  int p = tab_peer(tb, blockIdx.x);
+  int t = ((int)blockIdx.x - tb.wg_off[p]) * blockDim.x + threadIdx.x;
+  int CH = tb.with_mov ? 8 : 4;
+  if (t >= tb.n_blocks[p] * CH * 64) return;
+  int l = t & 63, ch = (t >> 6) % CH, i = t / (CH * 64);
+  int blk = tb.blocks[p][i];
+  float v = tb.buf[p][t];
   if (v == 0.0f) return;
-  if (ch < 4) { g.mv[((size_t)blk * GCH_MV + ch) * 64 + l] += v; g.m_flag[blk] = 1; }
-  else g.mov[((size_t)blk * GCH_MOV + (ch - 4)) * 64 + l] += v;
+  if (ch < 4) { atomicAdd(g.mv + ((size_t)blk * GCH_MV + ch) * 64 + l, v); g.m_flag[blk] = 1; }
+  else atomicAdd(g.mov + ((size_t)blk * GCH_MOV + (ch - 4)) * 64 + l, v);
 }
 // ghosts: x, v of vertices / traditional particles (6 floats) and the director d3 of elements (3 floats);
 // ids are the caller-order particle indices of this rank's solver, inv[] maps them to sorted slots
-__global__ void k_ghost_pack(const int *ids_p, int n_p_ids, const int *ids_e, int n_e_ids, const int *inv, Bufs b,
-                             float *out) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_ghost_pack(GhostTab tb, const int *inv, Bufs b) {
+  int p = tab_peer(tb, blockIdx.x);
+  int t = ((int)blockIdx.x - tb.wg_off[p]) * blockDim.x + threadIdx.x;
+  int n_p_ids = tb.n_p[p], n_e_ids = tb.n_e[p];
+  float *out = tb.buf[p];
   if (t < n_p_ids) {
-    int s = inv[ids_p[t]];
+    int s = inv[tb.ids_p[p][t]];
     V3 x = ld3(b.all, A_X, s), v = ld3(b.all, A_V, s);
     float *o = out + 6 * (size_t)t;
     o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = v.x; o[4] = v.y; o[5] = v.z;
   } else if (t < n_p_ids + n_e_ids) {
-    int i = t - n_p_ids, s = inv[ids_e[i]];
+    int i = t - n_p_ids, s = inv[tb.ids_e[p][i]];
     float *o = out + 6 * (size_t)n_p_ids + 3 * (size_t)i;
     o[0] = b.el.at(E_D + 2, s); o[1] = b.el.at(E_D + 5, s); o[2] = b.el.at(E_D + 8, s);
   }
 }
-__global__ void k_ghost_unpack(const int *ids_p, int n_p_ids, const int *ids_e, int n_e_ids, const int *inv, Bufs b,
-                               const float *in) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_ghost_unpack(GhostTab tb, const int *inv, Bufs b) {
+  int p = tab_peer(tb, blockIdx.x);
+  int t = ((int)blockIdx.x - tb.wg_off[p]) * blockDim.x + threadIdx.x;
+  int n_p_ids = tb.n_p[p], n_e_ids = tb.n_e[p];
+  const float *in = tb.buf[p];
   if (t < n_p_ids) {
-    int s = inv[ids_p[t]];
+    int s = inv[tb.ids_p[p][t]];
     const float *o = in + 6 * (size_t)t;
     st3(b.all, A_X, s, v3(o[0], o[1], o[2]));
     st3(b.all, A_V, s, v3(o[3], o[4], o[5]));
   } else if (t < n_p_ids + n_e_ids) {
-    int i = t - n_p_ids, s = inv[ids_e[i]];
+    int i = t - n_p_ids, s = inv[tb.ids_e[p][i]];
     const float *o = in + 6 * (size_t)n_p_ids + 3 * (size_t)i;
     b.el.at(E_D + 2, s) = o[0]; b.el.at(E_D + 5, s) = o[1]; b.el.at(E_D + 8, s) = o[2];
   }
@@ -1975,9 +2004,10 @@ static int step_phase_c(mpmhip_ctx *c, const StepArgs &a) {
   Bufs &b = f->buf[f->cur];
   {
     ScopedPhase ph(c, "g2p_e");
-    // single-GPU, unprofiled: defer into the next substep's stress kernel (k_stress_elem<true>)
+    // unprofiled: deferred into the next substep's stress kernel (k_stress_elem<true>); multi-GPU ranks have unpacked
+    // their ghost vertices by now, so the same holds there
     f->elem_pending = d.n_e > 0;
-    if (f->dist || c->profiling) flush_elements(c);
+    if (c->profiling) flush_elements(c);
   }
   f->steps_since_rebin += 1;
   if (!f->dist && !f->flag_pending && (f->steps_since_rebin & 7) == 0) {
@@ -2038,31 +2068,57 @@ int fast_dist_set_peers(mpmhip_ctx *c, int n, const mpmhip_dist_peer *peers) {
   return MPMHIP_OK;
 }
 
+// halo (send = true: pack into halo_send, false: add halo_recv) for all peers, PEER_TAB per launch
+static void launch_halo(mpmhip_ctx *c, bool send) {
+  FastState *f = c->fast;
+  int with_mov = c->movers.empty() ? 0 : 1, CH = with_mov ? 8 : 4;
+  for (size_t i0 = 0; i0 < f->peers.size(); i0 += PEER_TAB) {
+    HaloTab tb{};
+    tb.with_mov = with_mov;
+    for (size_t i = i0; i < std::min(f->peers.size(), i0 + PEER_TAB); ++i) {
+      const DistPeer &p = f->peers[i];
+      if (!p.n_blocks) continue;
+      int k = tb.n++;
+      tb.blocks[k] = p.blocks; tb.n_blocks[k] = p.n_blocks; tb.buf[k] = send ? p.halo_send : p.halo_recv;
+      tb.wg_off[k + 1] = tb.wg_off[k] + (int)nblk((size_t)p.n_blocks * CH * 64);
+    }
+    if (!tb.n) continue;
+    if (send) hipLaunchKernelGGL(k_halo_pack, (unsigned)tb.wg_off[tb.n], TPB, 0, c->stream, tb, f->g);
+    else hipLaunchKernelGGL(k_halo_add, (unsigned)tb.wg_off[tb.n], TPB, 0, c->stream, tb, f->g);
+  }
+}
+static void launch_ghosts(mpmhip_ctx *c, bool send) {
+  FastState *f = c->fast;
+  for (size_t i0 = 0; i0 < f->peers.size(); i0 += PEER_TAB) {
+    GhostTab tb{};
+    for (size_t i = i0; i < std::min(f->peers.size(), i0 + PEER_TAB); ++i) {
+      const DistPeer &p = f->peers[i];
+      int np = send ? p.n_send_p : p.n_recv_p, ne = send ? p.n_send_e : p.n_recv_e;
+      if (np + ne == 0) continue;
+      int k = tb.n++;
+      tb.ids_p[k] = send ? p.send_p : p.recv_p; tb.ids_e[k] = send ? p.send_e : p.recv_e;
+      tb.n_p[k] = np; tb.n_e[k] = ne; tb.buf[k] = send ? p.ghost_send : p.ghost_recv;
+      tb.wg_off[k + 1] = tb.wg_off[k] + (int)nblk((size_t)(np + ne));
+    }
+    if (!tb.n) continue;
+    if (send) hipLaunchKernelGGL(k_ghost_pack, (unsigned)tb.wg_off[tb.n], TPB, 0, c->stream, tb, f->inv, f->buf[f->cur]);
+    else hipLaunchKernelGGL(k_ghost_unpack, (unsigned)tb.wg_off[tb.n], TPB, 0, c->stream, tb, f->inv, f->buf[f->cur]);
+  }
+}
+
 int fast_dist_phase(mpmhip_ctx *c, int phase, const StepArgs &a) {
   FastState *f = c->fast;
-  hipStream_t s = c->stream;
   int rc;
-  int with_mov = c->movers.empty() ? 0 : 1, CH = with_mov ? 8 : 4;
   if (phase == 0) {
     f->dist_args = a;
     if ((rc = step_phase_a(c, a))) return rc;
-    for (auto &p : f->peers)
-      if (p.n_blocks)
-        hipLaunchKernelGGL(k_halo_pack, nblk((size_t)p.n_blocks * CH * 64), TPB, 0, s, p.blocks, p.n_blocks, f->g, with_mov, p.halo_send);
+    launch_halo(c, true);
   } else if (phase == 1) {
-    for (auto &p : f->peers)
-      if (p.n_blocks)
-        hipLaunchKernelGGL(k_halo_add, nblk((size_t)p.n_blocks * CH * 64), TPB, 0, s, p.blocks, p.n_blocks, f->g, with_mov, p.halo_recv);
+    launch_halo(c, false);
     if ((rc = step_phase_b(c, f->dist_args))) return rc;
-    for (auto &p : f->peers)
-      if (p.n_send_p + p.n_send_e)
-        hipLaunchKernelGGL(k_ghost_pack, nblk(p.n_send_p + p.n_send_e), TPB, 0, s, p.send_p, p.n_send_p, p.send_e, p.n_send_e,
-                           f->inv, f->buf[f->cur], p.ghost_send);
+    launch_ghosts(c, true);
   } else {
-    for (auto &p : f->peers)
-      if (p.n_recv_p + p.n_recv_e)
-        hipLaunchKernelGGL(k_ghost_unpack, nblk(p.n_recv_p + p.n_recv_e), TPB, 0, s, p.recv_p, p.n_recv_p, p.recv_e, p.n_recv_e,
-                           f->inv, f->buf[f->cur], p.ghost_recv);
+    launch_ghosts(c, false);
     if ((rc = step_phase_c(c, f->dist_args))) return rc;
   }
   MPM_HIP_CHECK(c, hipGetLastError());
