@@ -74,14 +74,7 @@ def cpu_baseline(sc, budget_s=20.0):
     run_scene(o, sc, 1)  # warm caches / page in the dense grids
     n, t0 = 0, time.perf_counter()
     while True:
-        k = n
-        kw = {}
-        if sc.mesh_vertices is not None:
-            import numpy as np
-            kw = dict(mesh_x=(sc.mesh_vertices + np.float32(sc.dt * (k + 1)) * sc.mesh_v).astype("float32"), mesh_v=sc.mesh_v)
-        if sc.joint_verts_v is not None:
-            kw.update(joint_verts_v=sc.joint_verts_v, joint_faces_v=sc.joint_faces_v)
-        o.p2g2p(sc.dt, **kw)
+        run_scene(o, sc, 1, k0=n + 1)
         n += 1
         el = time.perf_counter() - t0
         if el > budget_s or n >= 50:

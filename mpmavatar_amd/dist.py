@@ -138,6 +138,8 @@ def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int 
     import torch.distributed as dist
     from . import harness
     from . import _lib as L
+    if getattr(sc, "joint_t_hold", 0) > 0:
+        raise NotImplementedError("staged joint_traditional_v (held trailing particles) is not supported by the sharded driver")
     shard = partition(sc, world)[rank]
     sim = harness.build_solver(shard.scene, device, mode="fast")
     sv = sim.solver

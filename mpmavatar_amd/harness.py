@@ -72,22 +72,34 @@ def build_solver(sc: Scene, device="cuda:0", mode=None, rebin_interval=0) -> Sim
 
 def run(sim: Sim, n_steps: int, fused: bool = False):
     """Advance ``n_steps`` substeps.  fused=False issues one ``p2g2p`` per substep with the mesh advected
-    on the torch side like the reference loop; fused=True hands the whole loop to ``mpmhip_steps``."""
+    on the torch side like the reference loop; fused=True hands runs of substeps to ``mpmhip_steps`` (split where the
+    scene's staged sand release changes the length of ``joint_traditional_v``)."""
     sc, sv = sim.scene, sim.solver
-    kw = dict(joint_traditional_v=None, joint_verts_v=sim.joint_verts_v, joint_faces_v=sim.joint_faces_v)
-    if fused:
-        mx = None
-        if sim.mesh_x0 is not None:
-            mx = sim.mesh_x0 + np.float32(sc.dt * sim.steps_done) * sim.mesh_v
-        sv.p2g2p_n(sim.model, sim.state, sc.dt, n_steps, mesh_x=mx, mesh_v=sim.mesh_v, **kw)
-        sim.steps_done += n_steps
-        return
-    for _ in range(n_steps):
-        mx = None
-        if sim.mesh_x0 is not None:
-            mx = sim.mesh_x0 + np.float32(sc.dt * sim.steps_done) * sim.mesh_v
-        sv.p2g2p(sim.model, sim.state, sc.dt, mesh_x=mx, mesh_v=sim.mesh_v, **kw)
-        sim.steps_done += 1
+    dev = sim.state.particle_x.device
+
+    def kwargs(step):
+        n_jt = sc.joint_t_count(step)
+        jt = torch.zeros((n_jt, 3), dtype=torch.float32, device=dev) if sc.joint_t_hold > 0 else None
+        return dict(joint_traditional_v=jt, joint_verts_v=sim.joint_verts_v, joint_faces_v=sim.joint_faces_v)
+
+    def mesh(step):
+        if sim.mesh_x0 is None:
+            return None
+        return sim.mesh_x0 + np.float32(sc.dt * step) * sim.mesh_v
+
+    end = sim.steps_done + n_steps
+    while sim.steps_done < end:
+        k0 = sim.steps_done
+        n = 1
+        if fused:
+            n = end - k0
+            if sc.joint_t_hold > 0:  # stop the fused run at the next change of the held count
+                c0 = sc.joint_t_count(k0)
+                n = next((j for j in range(1, n) if sc.joint_t_count(k0 + j) != c0), n)
+            sv.p2g2p_n(sim.model, sim.state, sc.dt, n, mesh_x=mesh(k0), mesh_v=sim.mesh_v, **kwargs(k0))
+        else:
+            sv.p2g2p(sim.model, sim.state, sc.dt, mesh_x=mesh(k0), mesh_v=sim.mesh_v, **kwargs(k0))
+        sim.steps_done += n
 
 
 def algorithmic_bytes(sc: Scene, n_active=0, n_collider=0, n_mover=0) -> dict:

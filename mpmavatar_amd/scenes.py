@@ -49,6 +49,19 @@ class Scene:
     n_steps: int = 100
     has_mover: Optional[bool] = None             # None: a particle mover is registered iff the scene has joints
     selection: Optional[np.ndarray] = None       # particle_selection (0 simulate, 1 frozen, 2 ghost copy); None = all 0
+    # staged release of the trailing traditional particles (run_demo.py:524: the mover holds the sand at zero velocity,
+    # then lets go of `joint_t_rate` more particles every `joint_t_every` substeps from substep `joint_t_start` on)
+    joint_t_hold: int = 0
+    joint_t_start: int = 0
+    joint_t_every: int = 1
+    joint_t_rate: int = 0
+
+    def joint_t_count(self, step: int) -> int:
+        """Length of joint_traditional_v at this substep (max(n_t - max(i - 100, 0) * 1000, 0) per frame in the reference)."""
+        if self.joint_t_hold <= 0:
+            return 0
+        stages = max(step - self.joint_t_start, 0) // max(self.joint_t_every, 1) if step >= self.joint_t_start else 0
+        return max(self.joint_t_hold - stages * self.joint_t_rate, 0)
 
     @property
     def n_particles(self):
@@ -154,10 +167,12 @@ def sheet(n=408, n_grid=256, collider_subdiv=5, n_steps=1000, seed=1, name=None,
                         n_steps=n_steps)
 
 
-def demo_mix(n_grid=64, n_sheet=24, sand=(24, 4, 12), n_steps=200, seed=3) -> Scene:
+def demo_mix(n_grid=64, n_sheet=24, sand=(24, 4, 12), n_steps=200, seed=3, hold=None) -> Scene:
     """Reduced stand-in of the run_demo.py scene: cloth sheet + sand block (material 2)
-    + floor plane (sticky surface collider) + body mesh collider + particle mover holding the sand for
-    the first frames (run_demo.py:309-315,377-379,524)."""
+    + floor plane (sticky surface collider) + body mesh collider + particle mover that pins the first sheet row and
+    holds the sand, releasing it in stages (run_demo.py:309-315,377-379,524).  hold = (start, every, rate) in
+    substeps / particles; default: everything held for 40 substeps, then 1/8 of the sand released every 10;
+    hold=False: the sand is free from the start."""
     verts, faces = garment.grid_sheet(n_sheet, n_sheet, 0.7, 1.3, 0.7, 1.3, 1.25)
     init_dir, rest_dir, e_vol, v_vol = garment.compute_dir_vol(verts, faces, thickness=1e-5)
     R_inv = garment.compute_rest_dir_inv(rest_dir)
@@ -176,7 +191,9 @@ def demo_mix(n_grid=64, n_sheet=24, sand=(24, 4, 12), n_steps=200, seed=3) -> Sc
     jv = np.zeros((njv, 3), np.float32)
     params = {"material": "sand", "g": [0.0, -9.8, 0.0], "density": 1.0, "grid_v_damping_scale": 1.1,
               "friction_angle": 40.0}
-    return Scene(name="demo-mix", n_grid=n_grid, grid_lim=2.0, n_elements=faces.shape[0], n_traditional=pts.shape[0],
+    start, every, rate = hold if hold else (40, 10, max(pts.shape[0] // 8, 1))
+    return Scene(name="demo-mix", joint_t_hold=0 if hold is False else pts.shape[0], joint_t_start=start, joint_t_every=every, joint_t_rate=rate,
+                 n_grid=n_grid, grid_lim=2.0, n_elements=faces.shape[0], n_traditional=pts.shape[0],
                  n_vertices=verts.shape[0], x=x, v=np.zeros_like(x), vol=vol, faces=faces.astype(np.int32), d=init_dir,
                  R_inv=R_inv, params=params, mesh_vertices=mv, mesh_faces=mf, mesh_v=np.zeros_like(mv),
                  mesh_friction=0.5, num_joint_v=njv, num_joint_f=0, joint_verts_v=jv,
@@ -209,5 +226,7 @@ REGISTRY = {
     "block-512k": lambda: block(),
     "demo-mix": lambda: demo_mix(),
     # run_demo.py-sized stand-in: 250^3 grid, 100,000 sand particles (utils/demo_utils.py:6), 200x200 garment sheet
-    "demo-250": lambda: demo_mix(n_grid=250, n_sheet=200, sand=(200, 10, 50), n_steps=400),
+    # (sand held for 100 substeps, then 1000 particles released every 4 substeps: the reference's per-frame schedule
+    # compressed so that a few hundred timed substeps see held, mixed and free sand)
+    "demo-250": lambda: demo_mix(n_grid=250, n_sheet=200, sand=(200, 10, 50), n_steps=400, hold=(100, 4, 1000)),
 }

@@ -37,7 +37,7 @@ def oracle_from_scene(sc, omp=False, n_threads=1) -> OracleMPM:
     return o
 
 
-def run_scene(sim, sc, n_steps=None, step_fn=None):
+def run_scene(sim, sc, n_steps=None, step_fn=None, k0=0):
     """Drive ``sim`` (oracle, twin, or anything with p2g2p/step) through the scene's substeps with the
     reference's mesh advection mesh_x + k*dt*mesh_v (train_material_params.py:622-626)."""
     n = sc.n_steps if n_steps is None else n_steps
@@ -45,8 +45,10 @@ def run_scene(sim, sc, n_steps=None, step_fn=None):
     for k in range(n):
         kw = {}
         if sc.mesh_vertices is not None:
-            kw["mesh_x"] = (sc.mesh_vertices + np.float32(sc.dt * k) * sc.mesh_v).astype(np.float32)
+            kw["mesh_x"] = (sc.mesh_vertices + np.float32(sc.dt * (k0 + k)) * sc.mesh_v).astype(np.float32)
             kw["mesh_v"] = sc.mesh_v
         if sc.joint_verts_v is not None:
             kw["joint_verts_v"], kw["joint_faces_v"] = sc.joint_verts_v, sc.joint_faces_v
+        if getattr(sc, "joint_t_hold", 0) > 0:  # staged sand release, run_demo.py:524
+            kw["joint_traditional_v"] = np.zeros((sc.joint_t_count(k0 + k), 3), np.float32)
         fn(sc.dt, **kw)

@@ -23,7 +23,7 @@ from mpmavatar_amd import dist as mdist  # noqa: E402
 from mpmavatar_amd import scenes  # noqa: E402
 
 SCENES = {"garment": scenes.small_garment, "sheet": scenes.small_sheet, "cube": scenes.small_cube,
-          "demo": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8))}
+          "demo": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=False)}
 
 
 def main():

@@ -155,3 +155,25 @@ def test_out_of_margin_paths(scene, oracle_lib):
     assert rel(x, o.x) < (1e-4 if scene == "cube" else 1e-3)
     assert rel(v, o.v) < (3e-4 if scene == "cube" else 5e-2)
     assert rel(x, xc) < (2e-5 if scene == "cube" else 2e-4)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_staged_sand_release(mode, oracle_lib):
+    """run_demo.py:524: the mover holds the trailing sand particles at zero velocity and lets go of them in stages
+    (the length of joint_traditional_v shrinks over time).  Single-step and fused driving must agree with the oracle
+    across several release boundaries."""
+    from mpmavatar_amd import harness
+    mk = lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=(20, 7, 60))
+    sc = mk()
+    assert sc.joint_t_count(0) == sc.n_traditional and 0 < sc.joint_t_count(45) < sc.n_traditional
+    o, g, _ = _run_pair(sc, 80, mode)
+    assert rel(g["particle_x"], o.x) < 1e-4
+    assert rel(g["particle_v"], o.v) < 5e-3
+    held = slice(sc.n_elements + sc.n_traditional - sc.joint_t_count(80), sc.n_elements + sc.n_traditional)
+    if sc.joint_t_count(80) > 0:   # still held: has not moved
+        assert np.abs(g["particle_x"][held] - sc.x[held]).max() < 1e-6
+    free = slice(sc.n_elements, sc.n_elements + sc.n_traditional - sc.joint_t_count(30))
+    assert (sc.x[free, 1] - g["particle_x"][free, 1]).max() > 1e-5  # released sand falls
+    b = harness.build_solver(mk(), "cuda:0", mode=mode)
+    harness.run(b, 80, fused=True)
+    assert rel(b.state.particle_x.cpu().numpy(), g["particle_x"]) < 1e-6
