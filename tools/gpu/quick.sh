@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick A/B: fused substep time of the headline scene for a list of environment settings, e.g.
-#   VARIANTS="MPMHIP_P2G_WGS=768 MPMHIP_P2G_WGS=1024" bash scripts_gpu_quick.sh
+#   VARIANTS="MPMHIP_P2G_SCAN=3 MPMHIP_P2G_SCAN=4" bash tools/gpu/quick.sh
 R=$GRAFT_REPO_ROOT; cd $R
 for v in ${VARIANTS:-X=0}; do
   echo "== $v"
