@@ -906,35 +906,12 @@ __device__ __forceinline__ void p2g_escaped(const Bufs &b, const VAdj &va, int c
   }
 }
 
+// ---- pieces shared by the two p2g kernels -------------------------------------------------------------------
+// tile pass of one chunk: margin check (out-of-margin lanes go to the esc list), DPP pre-reduction, LDS atomics
 template <int STEPS>
-__global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *recs, int n_chunks, Dims d, float rpic,
-                                             float dt, GridPtrs g, SplatArgs sa) {
-  __shared__ double tile[4 * TILE_PAD];
-  __shared__ int esc[CHUNK];
-  __shared__ int esc_n;
-  if ((int)blockIdx.x < sa.n_extra) {  // extra workgroups first: they are the long-latency ones
-    int e = blockIdx.x;
-    if (e < sa.n_fbins) col_splat_wg(tile, sa, e, d, g);
-    else if (e < sa.n_fbins + sa.n_mov_wg) mover_splat_wg(b, sa.js, e - sa.n_fbins, d, g);
-    return;
-  }
-  int w = xcd_slice((int)blockIdx.x - sa.n_extra, n_chunks);
-  if (w < 0) return;
-  const ChunkRec cm = recs[w];
-  int blk = cm.blk, chunk = cm.chunk;
-  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
-  int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
-  int cls = 0, s = 0;
-  bool valid = cm.map(chunk * CHUNK + (int)threadIdx.x, cls, s);
-  // issue the particle loads before the tile is cleared so that their latency overlaps
-  bool w_nv = __any(valid && cls != 2), w_v = __any(valid && cls == 2);
-  if (g.dbg & 8) w_v = false;
-  if (g.dbg & 16) w_nv = false;
-  P2GRaw raw = p2g_issue(b, va, valid, cls, s, d, w_nv, w_v);
-  for (int t = threadIdx.x; t < 4 * TILE_PAD; t += TPB) tile[t] = 0.0;
-  if (threadIdx.x == 0) esc_n = 0;
-  P2GParticle q = p2g_finish(raw, va, valid, cls, s, d, rpic, dt, w_v, p2g_zero(ox, oy, oz, d));
-  __syncthreads();
+__device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p, P2GParticle &q, bool valid, int ox, int oy,
+                                            int oz, const Dims &d, const GridPtrs &g) {
+  int &esc_n = *esc_n_p;
   int key = -2 - (int)(threadIdx.x & 63), base = 0;
   if (valid) {
     int lx = q.s.bx - ox, ly = q.s.by - oy, lz = q.s.bz - oz;
@@ -989,20 +966,19 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *re
       }
     }
   }
-  __syncthreads();
-  if (esc_n > 0) {
-    for (int e = threadIdx.x; e < esc_n; e += TPB) {
-      int ec = 0, es = 0;
-      if (cm.map(chunk * CHUNK + esc[e], ec, es)) p2g_escaped(b, va, ec, es, d, rpic, dt, g);
-    }
-  }
-  // flush: skip untouched nodes; every touched node lies in an active block by construction
-  if (g.dbg & 1) return;
+}
+
+// flush: skip untouched nodes; every touched node lies in an active block by construction.  REZERO leaves the tile
+// cleared for the next chunk of a persistent workgroup.
+template <bool REZERO>
+__device__ __forceinline__ void p2g_flush(double *tile, int ox, int oy, int oz, const Dims &d, const GridPtrs &g) {
   for (int t = threadIdx.x; t < TILE3; t += TPB) {
     int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
-    const double *qd = tile + tile_idx(ti, tj, tk);
+    double *qd = tile + tile_idx(ti, tj, tk);
     float m = (float)qd[0], px = (float)qd[TILE_PAD], py = (float)qd[2 * TILE_PAD], pz = (float)qd[3 * TILE_PAD];
     if (m == 0.0f && px == 0.0f && py == 0.0f && pz == 0.0f) continue;
+    if (REZERO) { qd[0] = 0.0; qd[TILE_PAD] = 0.0; qd[2 * TILE_PAD] = 0.0; qd[3 * TILE_PAD] = 0.0; }
+    if (g.dbg & 1) continue;
     int x = ox + ti, y = oy + tj, z = oz + tk;
     if (!in_grid(x, y, z, d.G)) continue;
     int nb = blk_of(x, y, z, d.NB);
@@ -1011,6 +987,46 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *re
     atomicAdd(p, m);
     atomicAdd(p + 64, px); atomicAdd(p + 128, py); atomicAdd(p + 192, pz);
   }
+}
+
+template <int STEPS>
+__global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *recs, int n_chunks, Dims d, float rpic,
+                                             float dt, GridPtrs g, SplatArgs sa) {
+  __shared__ double tile[4 * TILE_PAD];
+  __shared__ int esc[CHUNK];
+  __shared__ int esc_n;
+  if ((int)blockIdx.x < sa.n_extra) {  // extra workgroups first: they are the long-latency ones
+    int e = blockIdx.x;
+    if (e < sa.n_fbins) col_splat_wg(tile, sa, e, d, g);
+    else if (e < sa.n_fbins + sa.n_mov_wg) mover_splat_wg(b, sa.js, e - sa.n_fbins, d, g);
+    return;
+  }
+  int w = xcd_slice((int)blockIdx.x - sa.n_extra, n_chunks);
+  if (w < 0) return;
+  const ChunkRec cm = recs[w];
+  int blk = cm.blk, chunk = cm.chunk;
+  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
+  int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
+  int cls = 0, s = 0;
+  bool valid = cm.map(chunk * CHUNK + (int)threadIdx.x, cls, s);
+  // issue the particle loads before the tile is cleared so that their latency overlaps
+  bool w_nv = __any(valid && cls != 2), w_v = __any(valid && cls == 2);
+  if (g.dbg & 8) w_v = false;
+  if (g.dbg & 16) w_nv = false;
+  P2GRaw raw = p2g_issue(b, va, valid, cls, s, d, w_nv, w_v);
+  for (int t = threadIdx.x; t < 4 * TILE_PAD; t += TPB) tile[t] = 0.0;
+  if (threadIdx.x == 0) esc_n = 0;
+  P2GParticle q = p2g_finish(raw, va, valid, cls, s, d, rpic, dt, w_v, p2g_zero(ox, oy, oz, d));
+  __syncthreads();
+  p2g_scatter<STEPS>(tile, esc, &esc_n, q, valid, ox, oy, oz, d, g);
+  __syncthreads();
+  if (esc_n > 0) {
+    for (int e = threadIdx.x; e < esc_n; e += TPB) {
+      int ec = 0, es = 0;
+      if (cm.map(chunk * CHUNK + esc[e], ec, es)) p2g_escaped(b, va, ec, es, d, rpic, dt, g);
+    }
+  }
+  p2g_flush<false>(tile, ox, oy, oz, d, g);
 }
 
 // ------------------------------------------------------------------------------------------------
