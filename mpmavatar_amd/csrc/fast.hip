@@ -384,36 +384,38 @@ __global__ __launch_bounds__(TPB) void k_grid(const int *alist, int n_A, Dims d,
   }
 }
 
-// Clear the accumulators of one block after a fused substep (what node_update<true> would have cleared).
-__device__ __forceinline__ void zero_block(int blk, int l, const GridPtrs &g, int has_col, int has_mov) {
-  if (g.m_flag[blk]) {  // wave-uniform
-    float *pm = g.mv + ((size_t)blk * GCH_MV) * 64 + l;
+// Clear the accumulators a fused substep left loaded (what node_update<true> would have cleared).  The accumulators
+// are double-buffered: substep n scatters into buffer n & 1, and the clearing of buffer (n - 1) & 1 rides in the p2g
+// launch of substep n as extra workgroups -- it can run concurrently with the scatter because it touches the other
+// buffer.  Stand-alone (k_zero_blocks) only before a re-sort: the active list is about to change.
+struct ZeroArgs {
+  const int *alist;
+  int n_A, n_wg;  // n_wg workgroups clear 4 blocks each (0: nothing to clear)
+  int has_col, has_mov;
+  float *mv, *col, *mov;  // the buffer to clear
+  int *m_flag, *col_flag;
+};
+__device__ __forceinline__ void zero_blocks_wg(const ZeroArgs &z, int wg) {
+  int a = wg * 4 + (int)(threadIdx.x >> 6), l = threadIdx.x & 63;
+  if (a >= z.n_A) return;
+  int blk = z.alist[a];
+  if (z.m_flag[blk]) {  // wave-uniform
+    float *pm = z.mv + ((size_t)blk * GCH_MV) * 64 + l;
     float m = pm[0], px = pm[64], py = pm[128], pz = pm[192];
     if (m != 0.0f || px != 0.0f || py != 0.0f || pz != 0.0f) { pm[0] = 0.0f; pm[64] = 0.0f; pm[128] = 0.0f; pm[192] = 0.0f; }
-    if (l == 0) g.m_flag[blk] = 0;
+    if (l == 0) z.m_flag[blk] = 0;
   }
-  if (has_col && g.col_flag[blk]) {  // wave-uniform
-    float *pc = g.col + ((size_t)blk * GCH_COL) * 64 + l;
+  if (z.has_col && z.col_flag[blk]) {  // wave-uniform
+    float *pc = z.col + ((size_t)blk * GCH_COL) * 64 + l;
     if (pc[0] != 0.0f) { pc[0] = 0.0f; pc[64] = 0.0f; pc[128] = 0.0f; pc[192] = 0.0f; pc[256] = 0.0f; pc[320] = 0.0f; pc[384] = 0.0f; }
-    if (l == 0) g.col_flag[blk] = 0;
+    if (l == 0) z.col_flag[blk] = 0;
   }
-  if (has_mov) {
-    float *pv = g.mov + ((size_t)blk * GCH_MOV) * 64 + l;
+  if (z.has_mov) {
+    float *pv = z.mov + ((size_t)blk * GCH_MOV) * 64 + l;
     if (pv[0] != 0.0f) { pv[0] = 0.0f; pv[64] = 0.0f; pv[128] = 0.0f; pv[192] = 0.0f; }
   }
 }
-// The zeroing rides in the next substep's stress launch as extra workgroups (ZeroArgs); stand-alone only before a
-// re-sort (the active list is about to change) or when no stress kernel runs.
-struct ZeroArgs {
-  const int *alist;
-  int n_A, n_wg;  // n_wg = workgroups [0, n_wg) of the launch that clear 4 blocks each (0: nothing to clear)
-  int has_col, has_mov;
-};
-__device__ __forceinline__ void zero_blocks_wg(const ZeroArgs &z, int wg, const GridPtrs &g) {
-  int a = wg * 4 + (int)(threadIdx.x >> 6);
-  if (a < z.n_A) zero_block(z.alist[a], threadIdx.x & 63, g, z.has_col, z.has_mov);
-}
-__global__ __launch_bounds__(TPB) void k_zero_blocks(ZeroArgs z, GridPtrs g) { zero_blocks_wg(z, blockIdx.x, g); }
+__global__ __launch_bounds__(TPB) void k_zero_blocks(ZeroArgs z) { zero_blocks_wg(z, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------------
 // stress (compute_stress_from_F_trial, mpm_utils.py:1017-1105) on the sorted SoA state
@@ -424,9 +426,7 @@ __global__ __launch_bounds__(TPB) void k_zero_blocks(ZeroArgs z, GridPtrs g) { z
 // finished elements earlier (re-sort, read-back, pre-p2g operations, joint-face splats, multi-GPU ghosts).
 template <bool FINALIZE>
 __global__ void k_stress_elem(Bufs b, F3 *ef, Dims d, float friction_coeff, const int *face_slot,
-                              const unsigned *skeys, int blk_bits, int *counters, ZeroArgs z, GridPtrs g) {
-  const int n_main = (d.n_e + TPB - 1) / TPB;  // the zeroing workgroups come last: they fill the tail of the launch
-  if ((int)blockIdx.x >= n_main) { zero_blocks_wg(z, (int)blockIdx.x - n_main, g); return; }
+                              const unsigned *skeys, int blk_bits, int *counters) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.n_e) return;
   if (b.sel[e] == 1) {  // not simulated (selection == 2 marks a ghost copy: stress yes, transfers no)
@@ -470,9 +470,7 @@ __global__ void k_stress_elem(Bufs b, F3 *ef, Dims d, float friction_coeff, cons
   ef[2 * d.n_e + e] = F3{f3.x, f3.y, f3.z};
 }
 
-__global__ void k_stress_trad(Bufs b, Dims d, mpmhip_model_scalars sc, float dt, ZeroArgs z, GridPtrs g) {
-  const int n_main = (d.n_t + TPB - 1) / TPB;
-  if ((int)blockIdx.x >= n_main) { zero_blocks_wg(z, (int)blockIdx.x - n_main, g); return; }
+__global__ void k_stress_trad(Bufs b, Dims d, mpmhip_model_scalars sc, float dt) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= d.n_t) return;
   int s = t + d.n_e;
@@ -625,6 +623,8 @@ struct SplatArgs {
   JointSplatArgs js;       // workgroups [n_fbins, n_fbins + n_mov_wg): joints
   int n_mov_wg;
   int n_extra;             // n_fbins + n_mov_wg rounded up to a multiple of 8 (keeps the XCD mapping of the chunks)
+  ZeroArgs z;              // workgroups [z_first, z_first + z.n_wg), after the chunk workgroups: clear the other
+  int z_first;             // accumulator buffer
 };
 
 // PASS 0: weight + weight*velocity (collider channels 0..3), PASS 1: weight*normal (channels 4..6); both passes use
@@ -999,6 +999,10 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *re
     int e = blockIdx.x;
     if (e < sa.n_fbins) col_splat_wg(tile, sa, e, d, g);
     else if (e < sa.n_fbins + sa.n_mov_wg) mover_splat_wg(b, sa.js, e - sa.n_fbins, d, g);
+    return;
+  }
+  if ((int)blockIdx.x >= sa.z_first) {  // ... and the clearing workgroups last: they fill the tail of the launch
+    zero_blocks_wg(sa.z, (int)blockIdx.x - sa.z_first);
     return;
   }
   int w = xcd_slice((int)blockIdx.x - sa.n_extra, n_chunks);
@@ -1524,6 +1528,10 @@ struct FastState {
   // they are cleared by the next substep's stress launch (ZeroArgs) or, before a re-sort, by k_zero_blocks
   bool fuse_grid = true, grid_dirty = false;
   int dirty_col = 0, dirty_mov = 0;
+  // accumulator double buffer: g.{mv,col,mov,m_flag,col_flag} point at buffer `par`
+  float *mv2[2] = {nullptr, nullptr}, *col2[2] = {nullptr, nullptr}, *mov2[2] = {nullptr, nullptr};
+  int *mflag2[2] = {nullptr, nullptr}, *cflag2[2] = {nullptr, nullptr};
+  int par = 0;
   GridParams last_gp{};
   BCList last_bcl{};  // false: ignore the drift flag (tests of the out-of-margin paths)
   std::vector<void *> allocs;
@@ -1627,17 +1635,23 @@ int do_import(mpmhip_ctx *c) {
   return MPMHIP_OK;
 }
 
+// what has to be cleared after the last fused substep (the buffer g points at), marking it clean
 static ZeroArgs take_zero(FastState *f) {
-  ZeroArgs z{f->alist, f->n_A, 0, f->dirty_col, f->dirty_mov};
+  ZeroArgs z{f->alist, f->n_A, 0, f->dirty_col, f->dirty_mov, f->g.mv, f->g.col, f->g.mov, f->g.m_flag, f->g.col_flag};
   if (f->grid_dirty && f->n_A) z.n_wg = (f->n_A + 3) / 4;
   f->grid_dirty = false;
   return z;
 }
-// clear the accumulators now (the active list is about to change, or nothing else will do it)
+static void select_buffer(FastState *f, int par) {
+  f->par = par;
+  f->g.mv = f->mv2[par]; f->g.col = f->col2[par]; f->g.mov = f->mov2[par];
+  f->g.m_flag = f->mflag2[par]; f->g.col_flag = f->cflag2[par];
+}
+// clear the accumulators now (the active list is about to change)
 static void flush_grid(mpmhip_ctx *c) {
   FastState *f = c->fast;
   ZeroArgs z = take_zero(f);
-  if (z.n_wg) hipLaunchKernelGGL(k_zero_blocks, (unsigned)z.n_wg, TPB, 0, c->stream, z, f->g);
+  if (z.n_wg) hipLaunchKernelGGL(k_zero_blocks, (unsigned)z.n_wg, TPB, 0, c->stream, z);
 }
 // v_out of the last (fused) substep for export_grid / stats; the accumulators stay as they are
 static void materialize_grid(mpmhip_ctx *c, bool count) {
@@ -1780,10 +1794,13 @@ int fast_init(mpmhip_ctx *c) {
   if ((rc = dalloc(c, &f->adj_cnt, (size_t)d.n_v + 1))) return rc;
   if ((rc = dalloc(c, &f->order, (size_t)d.n_p))) return rc;
   if ((rc = dalloc(c, &f->iota, (size_t)d.n_p))) return rc;
-  if ((rc = dalloc(c, &f->g.mv, f->nblocks * GCH_MV * 64))) return rc;
+  for (int i = 0; i < 2; ++i) {
+    if ((rc = dalloc(c, &f->mv2[i], f->nblocks * GCH_MV * 64))) return rc;
+    if ((rc = dalloc(c, &f->mflag2[i], f->nblocks))) return rc;
+    if ((rc = dalloc(c, &f->cflag2[i], f->nblocks))) return rc;
+  }
+  select_buffer(f, 0);
   if ((rc = dalloc(c, &f->g.vout, f->nblocks * GCH_VOUT * 64))) return rc;
-  if ((rc = dalloc(c, &f->g.col_flag, f->nblocks))) return rc;
-  if ((rc = dalloc(c, &f->g.m_flag, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->g.counters, 8))) return rc;
   if ((rc = dalloc(c, &f->pb_flag, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->pb_index, f->nblocks))) return rc;
@@ -1819,16 +1836,20 @@ int fast_add_collider_storage(mpmhip_ctx *c, MeshCollider &mc) {
   if ((rc = dalloc(c, &f->fiota, (size_t)nf))) return rc;
   if ((rc = dalloc(c, &f->fb_start, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->fb_cnt, f->nblocks))) return rc;
-  if ((rc = dalloc(c, &f->g.col, f->nblocks * GCH_COL * 64))) return rc;
-  mc.weight = f->g.col;
+  for (int i = 0; i < 2; ++i)
+    if ((rc = dalloc(c, &f->col2[i], f->nblocks * GCH_COL * 64))) return rc;
+  select_buffer(f, f->par);
+  mc.weight = f->col2[0];
   return MPMHIP_OK;
 }
 
 int fast_add_mover_storage(mpmhip_ctx *c, Mover &mv) {
   FastState *f = c->fast;
   if (!c->movers.empty()) return fail(c, MPMHIP_ERR_LIMIT, "fast mode supports one particle mover (the reference drivers register one)");
-  int rc = dalloc(c, &f->g.mov, f->nblocks * GCH_MOV * 64);
-  mv.weight = f->g.mov;
+  int rc = MPMHIP_OK;
+  for (int i = 0; i < 2 && !rc; ++i) rc = dalloc(c, &f->mov2[i], f->nblocks * GCH_MOV * 64);
+  select_buffer(f, f->par);
+  mv.weight = f->mov2[0];
   return rc;
 }
 
@@ -1907,6 +1928,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   bool mov_on = a.joint_v_v && a.joint_f_v && !c->movers.empty();
   SplatArgs sa{};
   SplatArgs none{};
+  none.z_first = 1 << 30;
   if (has_col) {
     sa.pts = c->cur_pts; sa.vel = c->cur_vel; sa.adv = c->cur_f; sa.fidx = f->fidx; sa.fbins = f->fbins;
     sa.n_fbins = f->n_fbins;
@@ -1918,25 +1940,31 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     sa.n_mov_wg = (int)nblk((size_t)nj * 32);
     if (nj == 0) sa.n_mov_wg = 0;
   }
+  // accumulators left loaded by the previous (fused) substep: this substep scatters into the other buffer and clears
+  // the loaded one with extra workgroups of the p2g launch
+  sa.z = take_zero(f);
+  if (sa.z.n_wg) {
+    if (c->profiling) {  // profiling runs keep one launch per reference phase: clear now
+      hipLaunchKernelGGL(k_zero_blocks, (unsigned)sa.z.n_wg, TPB, 0, s, sa.z);
+      sa.z.n_wg = 0;
+    } else {
+      select_buffer(f, f->par ^ 1);
+    }
+  }
   sa.n_extra = (sa.n_fbins + sa.n_mov_wg + 7) & ~7;
+  sa.z_first = sa.n_extra + (int)xcd_grid(f->n_chunks);
   {
     ScopedPhase ph(c, "compute_stress_from_F_trial");
-    ZeroArgs z = take_zero(f), z0{f->alist, 0, 0, 0, 0};  // clears what the previous fused substep left loaded
     if (d.n_e) {
       if (f->elem_pending)
-        hipLaunchKernelGGL(k_stress_elem<true>, nblk(d.n_e) + z.n_wg, TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff,
-                           f->face_slot, f->keys[1], f->blk_bits, f->g.counters, z, f->g);
+        hipLaunchKernelGGL(k_stress_elem<true>, nblk(d.n_e), TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff, f->face_slot,
+                           f->keys[1], f->blk_bits, f->g.counters);
       else
-        hipLaunchKernelGGL(k_stress_elem<false>, nblk(d.n_e) + z.n_wg, TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff,
-                           f->face_slot, f->keys[1], f->blk_bits, f->g.counters, z, f->g);
+        hipLaunchKernelGGL(k_stress_elem<false>, nblk(d.n_e), TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff, f->face_slot,
+                           f->keys[1], f->blk_bits, f->g.counters);
       f->elem_pending = false;
-      z = z0;
     }
-    if (d.n_t) {
-      hipLaunchKernelGGL(k_stress_trad, nblk(d.n_t) + z.n_wg, TPB, 0, s, b, d, c->sc, dt, z, f->g);
-      z = z0;
-    }
-    if (z.n_wg) hipLaunchKernelGGL(k_zero_blocks, (unsigned)z.n_wg, TPB, 0, s, z, f->g);
+    if (d.n_t) hipLaunchKernelGGL(k_stress_trad, nblk(d.n_t), TPB, 0, s, b, d, c->sc, dt);
   }
   if (c->profiling && sa.n_extra) {
     {
@@ -1950,6 +1978,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       SplatArgs only = sa;
       only.n_mov_wg = 0;
       only.n_extra = (only.n_fbins + 7) & ~7;
+      only.z_first = 1 << 30;
       P2G_LAUNCH((unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only);
     }
     if (sa.n_mov_wg) {
@@ -1957,12 +1986,13 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       SplatArgs only = sa;
       only.n_fbins = 0;
       only.n_extra = (only.n_mov_wg + 7) & ~7;
+      only.z_first = 1 << 30;
       P2G_LAUNCH((unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only);
     }
   } else {
     ScopedPhase ph(c, "p2g");
-    if (f->n_chunks || sa.n_extra)
-      P2G_LAUNCH(xcd_grid(f->n_chunks) + (unsigned)sa.n_extra, TPB, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
+    if (f->n_chunks || sa.n_extra || sa.z.n_wg)
+      P2G_LAUNCH(xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg), TPB, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
                          c->sc.rpic_damping, dt, f->g, sa);
   }
   return MPMHIP_OK;
