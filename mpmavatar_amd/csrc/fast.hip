@@ -741,9 +741,15 @@ __device__ __forceinline__ P2GParticle p2g_zero(int ox, int oy, int oz, const Di
 struct P2GRaw {
   V3 x, v;
   float mass, vol;
-  M3 C, S;
+  M3 C, S;        // S: stress, or F_trial of a traditional particle when its stress update is fused into p2g (TRAD)
+  float mu, lam, ys;  // TRAD only
   AdjBatch ab;
 };
+// TRAD = true fuses compute_stress_from_F_trial of the traditional particles (mpm_utils.py:1047-1103, k_stress_trad) into
+// the front of p2g: the lane loads F_trial instead of the stress, runs the SVD / return mapping while the rest of its
+// chunk's loads are still in flight, stores F / stress / hardening state exactly as the stand-alone kernel does and
+// scatters with the fresh stress.  Same order of operations as the reference, one launch and one stress round trip less.
+template <bool TRAD>
 __device__ __forceinline__ P2GRaw p2g_issue(const Bufs &b, const VAdj &va, bool valid, int cls, int s, const Dims &d,
                                             bool w_nv, bool w_v) {
   P2GRaw r;
@@ -754,9 +760,21 @@ __device__ __forceinline__ P2GRaw p2g_issue(const Bufs &b, const VAdj &va, bool 
   r.v = ld3(b.all, A_V, sa);
   r.S = m3_zero();
   r.vol = 1.0f;
+  r.mu = r.lam = r.ys = 0.0f;
   if (w_nv) {
     int sn = (valid && cls != 2) ? s : 0;
-    r.S = ld9(b.nv, N_STRESS, sn);
+    if (TRAD) {
+      bool tr = valid && cls == 1;
+      int t = tr ? s - d.n_e : 0;
+      const float *base = tr ? b.tr.p + (size_t)T_FT * b.tr.n + t : b.nv.p + (size_t)N_STRESS * b.nv.n + sn;
+      size_t st = tr ? (size_t)b.tr.n : (size_t)b.nv.n;
+      r.S = M3{base[0], base[st], base[2 * st], base[3 * st], base[4 * st], base[5 * st], base[6 * st], base[7 * st], base[8 * st]};
+      r.mu = b.nv.at(N_MU, sn);
+      r.lam = b.nv.at(N_LAM, sn);
+      if (d.n_t) r.ys = b.tr.at(T_YS, t);
+    } else {
+      r.S = ld9(b.nv, N_STRESS, sn);
+    }
     r.vol = b.nv.at(N_VOL, sn);
   }
 #pragma unroll
@@ -764,8 +782,10 @@ __device__ __forceinline__ P2GRaw p2g_issue(const Bufs &b, const VAdj &va, bool 
   if (w_v) r.ab = adj_load(va, (valid && cls == 2) ? s - d.n_nv : 0, 0);
   return r;
 }
-__device__ __forceinline__ P2GParticle p2g_finish(const P2GRaw &r, const VAdj &va, bool valid, int cls, int s,
-                                                  const Dims &d, float rpic, float dt, bool w_v, const P2GParticle &zero) {
+template <bool TRAD>
+__device__ __forceinline__ P2GParticle p2g_finish(const P2GRaw &r, const Bufs &b, const VAdj &va, bool valid, int cls, int s,
+                                                  const Dims &d, float rpic, float dt, bool w_v, const P2GParticle &zero,
+                                                  const TradParams &tp) {
   V3 vf = v3(0, 0, 0);
   if (w_v) {
     vf = adj_gather(va, r.ab, vf);
@@ -783,16 +803,32 @@ __device__ __forceinline__ P2GParticle p2g_finish(const P2GRaw &r, const VAdj &v
   q.Cdx = d.dx * C;
   q.Sdt = m3_zero();
   q.vfdt = v3(0, 0, 0);
-  if (cls == 0) q.Sdt = (-dt * d.inv_dx) * r.S;
-  else if (cls == 1) q.Sdt = (-dt * d.inv_dx * r.vol) * r.S;
-  else q.vfdt = dt * vf;
+  if (cls == 0) {
+    q.Sdt = (-dt * d.inv_dx) * r.S;
+  } else if (cls == 1) {
+    M3 S = r.S;
+    if (TRAD) {  // r.S holds F_trial: k_stress_trad's body
+      int t = s - d.n_e;
+      M3 F;
+      float mu = r.mu, lam = r.lam, ys = r.ys;
+      traditional_update(r.S, tp, mu, lam, ys, dt, F, S);
+      if (tp.material == 1 || tp.material == 5) b.tr.at(T_YS, t) = ys;
+      if (tp.material == 5) { b.nv.at(N_MU, s) = mu; b.nv.at(N_LAM, s) = lam; }
+      st9(b.tr, T_F, t, F);
+      st9(b.nv, N_STRESS, s, S);
+    }
+    q.Sdt = (-dt * d.inv_dx * r.vol) * S;
+  } else {
+    q.vfdt = dt * vf;
+  }
   return q;
 }
 // slow-path loader (escaped particles)
+template <bool TRAD>
 __device__ __forceinline__ P2GParticle p2g_load(const Bufs &b, const VAdj &va, int cls, int s, const Dims &d, float rpic,
-                                                float dt) {
-  P2GRaw r = p2g_issue(b, va, true, cls, s, d, cls != 2, cls == 2);
-  return p2g_finish(r, va, true, cls, s, d, rpic, dt, cls == 2, P2GParticle{});
+                                                float dt, const TradParams &tp) {
+  P2GRaw r = p2g_issue<TRAD>(b, va, true, cls, s, d, cls != 2, cls == 2);
+  return p2g_finish<TRAD>(r, b, va, true, cls, s, d, rpic, dt, cls == 2, P2GParticle{}, tp);
 }
 
 // ---- wave-level pre-reduction -------------------------------------------------------------------------
@@ -885,9 +921,10 @@ __device__ __forceinline__ void p2g_node_ref(const P2GParticle &q, int i, int j,
 }
 
 // slow path for the (rare) particles that left their tile margin since the last re-sort: global atomics
+template <bool TRAD>
 __device__ __forceinline__ void p2g_escaped(const Bufs &b, const VAdj &va, int cls, int s, const Dims &d, float rpic,
-                                         float dt, GridPtrs g) {
-  P2GParticle q = p2g_load(b, va, cls, s, d, rpic, dt);
+                                         float dt, GridPtrs g, const TradParams &tp) {
+  P2GParticle q = p2g_load<TRAD>(b, va, cls, s, d, rpic, dt, tp);
   atomicAdd(g.counters + 0, 1);
 #pragma unroll 1
   for (int n = 0; n < 27; ++n) {
@@ -989,9 +1026,9 @@ __device__ __forceinline__ void p2g_flush(double *tile, int ox, int oy, int oz, 
   }
 }
 
-template <int STEPS>
+template <int STEPS, bool TRAD>
 __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *recs, int n_chunks, Dims d, float rpic,
-                                             float dt, GridPtrs g, SplatArgs sa) {
+                                             float dt, GridPtrs g, SplatArgs sa, TradParams tp) {
   __shared__ double tile[4 * TILE_PAD];
   __shared__ int esc[CHUNK];
   __shared__ int esc_n;
@@ -1017,17 +1054,17 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *re
   bool w_nv = __any(valid && cls != 2), w_v = __any(valid && cls == 2);
   if (g.dbg & 8) w_v = false;
   if (g.dbg & 16) w_nv = false;
-  P2GRaw raw = p2g_issue(b, va, valid, cls, s, d, w_nv, w_v);
+  P2GRaw raw = p2g_issue<TRAD>(b, va, valid, cls, s, d, w_nv, w_v);
   for (int t = threadIdx.x; t < 4 * TILE_PAD; t += TPB) tile[t] = 0.0;
   if (threadIdx.x == 0) esc_n = 0;
-  P2GParticle q = p2g_finish(raw, va, valid, cls, s, d, rpic, dt, w_v, p2g_zero(ox, oy, oz, d));
+  P2GParticle q = p2g_finish<TRAD>(raw, b, va, valid, cls, s, d, rpic, dt, w_v, p2g_zero(ox, oy, oz, d), tp);
   __syncthreads();
   p2g_scatter<STEPS>(tile, esc, &esc_n, q, valid, ox, oy, oz, d, g);
   __syncthreads();
   if (esc_n > 0) {
     for (int e = threadIdx.x; e < esc_n; e += TPB) {
       int ec = 0, es = 0;
-      if (cm.map(chunk * CHUNK + esc[e], ec, es)) p2g_escaped(b, va, ec, es, d, rpic, dt, g);
+      if (cm.map(chunk * CHUNK + esc[e], ec, es)) p2g_escaped<TRAD>(b, va, ec, es, d, rpic, dt, g, tp);
     }
   }
   p2g_flush<false>(tile, ox, oy, oz, d, g);
@@ -1526,7 +1563,7 @@ struct FastState {
   bool adaptive_rebin = true;
   // fused grid stage: after a substep the accumulators of the active blocks are still loaded (g2p only read them);
   // they are cleared by the next substep's stress launch (ZeroArgs) or, before a re-sort, by k_zero_blocks
-  bool fuse_grid = true, grid_dirty = false;
+  bool fuse_grid = true, grid_dirty = false, fuse_trad = true;
   int dirty_col = 0, dirty_mov = 0;
   // accumulator double buffer: g.{mv,col,mov,m_flag,col_flag} point at buffer `par`
   float *mv2[2] = {nullptr, nullptr}, *col2[2] = {nullptr, nullptr}, *mov2[2] = {nullptr, nullptr};
@@ -1809,6 +1846,7 @@ int fast_init(mpmhip_ctx *c) {
   f->g.ab_flag = f->ab_flag;
   if (const char *e = getenv("MPMHIP_DBG")) f->g.dbg = atoi(e);
   if (const char *e = getenv("MPMHIP_FUSE_GRID")) f->fuse_grid = atoi(e) != 0;
+  if (const char *e = getenv("MPMHIP_FUSE_TRAD")) f->fuse_trad = atoi(e) != 0;
   MPM_HIP_CHECK(c, hipHostMalloc((void **)&f->h_pin, 64 * sizeof(int), hipHostMallocDefault));
   MPM_HIP_CHECK(c, hipEventCreateWithFlags(&f->ev_flag, hipEventDisableTiming));
   return MPMHIP_OK;
@@ -1870,17 +1908,11 @@ int fast_pull(mpmhip_ctx *c) {
 //   A: [re-sort] pre-ops, body/joint splats (side stream), stress, p2g          -> halo exchange of shared blocks
 //   B: grid stage, g2p (+ escaped queue)                                         -> ghost x/v/d3 exchange
 //   C: element finalise, drift-flag bookkeeping
-static int p2g_scan_steps() {
-  static int v = [] { const char *e = getenv("MPMHIP_P2G_SCAN"); int k = e ? atoi(e) : 3; return k < 2 ? 2 : (k > 4 ? 4 : k); }();
-  return v;
-}
-#define P2G_LAUNCH(...)                                                          \
+// P2G_LAUNCH(trad, grid, block, shmem, stream, args...): k_p2g with or without the fused traditional stress update
+#define P2G_LAUNCH(trad, ...)                                                    \
   do {                                                                           \
-    switch (p2g_scan_steps()) {                                                  \
-      case 2: hipLaunchKernelGGL(k_p2g<2>, __VA_ARGS__); break;                  \
-      case 3: hipLaunchKernelGGL(k_p2g<3>, __VA_ARGS__); break;                  \
-      default: hipLaunchKernelGGL(k_p2g<4>, __VA_ARGS__); break;                 \
-    }                                                                            \
+    if (trad) hipLaunchKernelGGL((k_p2g<3, true>), __VA_ARGS__);                 \
+    else hipLaunchKernelGGL((k_p2g<3, false>), __VA_ARGS__);                     \
   } while (0)
 
 static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
@@ -1940,6 +1972,10 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     sa.n_mov_wg = (int)nblk((size_t)nj * 32);
     if (nj == 0) sa.n_mov_wg = 0;
   }
+  // traditional particles: their stress update runs at the front of p2g (k_p2g<.., true>) unless profiling wants the
+  // reference's phases apart
+  const bool trad_fused = d.n_t > 0 && f->fuse_trad && !c->profiling;
+  const TradParams tp{c->sc.material, c->sc.alpha, c->sc.hardening, c->sc.xi, c->sc.plastic_viscosity, c->sc.softening};
   // accumulators left loaded by the previous (fused) substep: this substep scatters into the other buffer and clears
   // the loaded one with extra workgroups of the p2g launch
   sa.z = take_zero(f);
@@ -1964,14 +2000,14 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
                            f->keys[1], f->blk_bits, f->g.counters);
       f->elem_pending = false;
     }
-    if (d.n_t) hipLaunchKernelGGL(k_stress_trad, nblk(d.n_t), TPB, 0, s, b, d, c->sc, dt);
+    if (d.n_t && !trad_fused) hipLaunchKernelGGL(k_stress_trad, nblk(d.n_t), TPB, 0, s, b, d, c->sc, dt);
   }
   if (c->profiling && sa.n_extra) {
     {
       ScopedPhase ph(c, "p2g");
       if (f->n_chunks)
-        P2G_LAUNCH(xcd_grid(f->n_chunks), TPB, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
-                           c->sc.rpic_damping, dt, f->g, none);
+        P2G_LAUNCH(false, xcd_grid(f->n_chunks), TPB, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
+                   c->sc.rpic_damping, dt, f->g, none, tp);
     }
     if (sa.n_fbins) {
       ScopedPhase ph(c, "apply_Mesh_Collision_on_grid");
@@ -1979,7 +2015,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       only.n_mov_wg = 0;
       only.n_extra = (only.n_fbins + 7) & ~7;
       only.z_first = 1 << 30;
-      P2G_LAUNCH((unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only);
+      P2G_LAUNCH(false, (unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only, tp);
     }
     if (sa.n_mov_wg) {
       ScopedPhase ph(c, "apply_Particle_Moving_on_grid");
@@ -1987,13 +2023,13 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       only.n_fbins = 0;
       only.n_extra = (only.n_mov_wg + 7) & ~7;
       only.z_first = 1 << 30;
-      P2G_LAUNCH((unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only);
+      P2G_LAUNCH(false, (unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only, tp);
     }
   } else {
     ScopedPhase ph(c, "p2g");
     if (f->n_chunks || sa.n_extra || sa.z.n_wg)
-      P2G_LAUNCH(xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg), TPB, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
-                         c->sc.rpic_damping, dt, f->g, sa);
+      P2G_LAUNCH(trad_fused, xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg), TPB, 0, s, b, f->va(), f->chunks,
+                 f->n_chunks, d, c->sc.rpic_damping, dt, f->g, sa, tp);
   }
   return MPMHIP_OK;
 }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick A/B: fused substep time of the headline scene for a list of environment settings, e.g.
-#   VARIANTS="MPMHIP_P2G_SCAN=3 MPMHIP_P2G_SCAN=4" bash tools/gpu/quick.sh
+#   VARIANTS="MPMHIP_FUSE_GRID=1 MPMHIP_FUSE_GRID=0" bash tools/gpu/quick.sh
 R=$GRAFT_REPO_ROOT; cd $R
 for v in ${VARIANTS:-X=0}; do
   echo "== $v"
