@@ -585,12 +585,14 @@ struct JointSplatArgs {
   int n_t, n_v, n_f;
   int off_t, off_v;  // caller-order index of the first particle of group 0 / group 1 (group 2 starts at 0)
   const int *inv;    // caller order -> sorted slot
+  const int *perm;   // sorted slot -> caller order
+  int t_in_tile;     // 1: group 0 is splatted by the p2g chunks themselves (second tile pass), not by mover_splat_wg
 };
 __device__ __forceinline__ void mover_splat_wg(const Bufs &b, const JointSplatArgs &js, int wg, const Dims &d,
                                                const GridPtrs &g) {
   const int *inv = js.inv;
   int t = wg * TPB + (int)threadIdx.x;
-  int q = t >> 5, nn = t & 31;
+  int q = (t >> 5) + (js.t_in_tile ? js.n_t : 0), nn = t & 31;
   if (nn >= 27 || q >= js.n_t + js.n_v + js.n_f) return;
   const float *vel;
   int orig;
@@ -1007,7 +1009,7 @@ __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p
 
 // flush: skip untouched nodes; every touched node lies in an active block by construction.  REZERO leaves the tile
 // cleared for the next chunk of a persistent workgroup.
-template <bool REZERO>
+template <bool REZERO, bool TO_MOV = false>
 __device__ __forceinline__ void p2g_flush(double *tile, int ox, int oy, int oz, const Dims &d, const GridPtrs &g) {
   for (int t = threadIdx.x; t < TILE3; t += TPB) {
     int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
@@ -1019,14 +1021,33 @@ __device__ __forceinline__ void p2g_flush(double *tile, int ox, int oy, int oz, 
     int x = ox + ti, y = oy + tj, z = oz + tk;
     if (!in_grid(x, y, z, d.G)) continue;
     int nb = blk_of(x, y, z, d.NB);
-    float *p = g.mv + ((size_t)nb * GCH_MV) * 64 + loc_of(x, y, z);
-    g.m_flag[nb] = 1;
+    float *p = (TO_MOV ? g.mov : g.mv) + ((size_t)nb * 4) * 64 + loc_of(x, y, z);  // GCH_MV == GCH_MOV == 4
+    if (!TO_MOV) g.m_flag[nb] = 1;
     atomicAdd(p, m);
     atomicAdd(p + 64, px); atomicAdd(p + 128, py); atomicAdd(p + 192, pz);
   }
 }
 
-template <int STEPS, bool TRAD>
+// joint splat of one out-of-margin particle (second tile pass of k_p2g<.., JT = true>)
+__device__ __forceinline__ void mover_escaped(V3 x, V3 pv, const Dims &d, const GridPtrs &g) {
+  Stencil s = make_stencil(x, d.inv_dx);
+#pragma unroll 1
+  for (int n = 0; n < 27; ++n) {
+    int i = n / 9, j = (n / 3) % 3, k = n % 3;
+    float w = sel3(i, s.w0.x, s.w1.x, s.w2.x) * sel3(j, s.w0.y, s.w1.y, s.w2.y) * sel3(k, s.w0.z, s.w1.z, s.w2.z);
+    int gx = s.bx + i, gy = s.by + j, gz = s.bz + k;
+    int blk = blk_of(gx, gy, gz, d.NB);
+    if (!g.ab_flag[blk]) { atomicAdd(g.counters + 1, 1); continue; }
+    float *p = g.mov + ((size_t)blk * GCH_MOV) * 64 + loc_of(gx, gy, gz);
+    atomicAdd(p, w);
+    atomicAdd(p + 64, w * pv.x); atomicAdd(p + 128, w * pv.y); atomicAdd(p + 192, w * pv.z);
+  }
+}
+
+// JT = true: the mover holds MANY traditional particles (run_demo.py keeps 100k sand particles frozen for the first
+// frames); their joint splat (weight, weight * joint velocity into the mover channels, mpm_solver.py:677-704) is a
+// second pass through the same LDS tile by the chunk that owns them instead of 27 x 4 scattered global atomics each.
+template <int STEPS, bool TRAD, bool JT>
 __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *recs, int n_chunks, Dims d, float rpic,
                                              float dt, GridPtrs g, SplatArgs sa, TradParams tp) {
   __shared__ double tile[4 * TILE_PAD];
@@ -1067,7 +1088,41 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *re
       if (cm.map(chunk * CHUNK + esc[e], ec, es)) p2g_escaped<TRAD>(b, va, ec, es, d, rpic, dt, g, tp);
     }
   }
-  p2g_flush<false>(tile, ox, oy, oz, d, g);
+  p2g_flush<JT>(tile, ox, oy, oz, d, g);
+  if (JT) {
+    // held = one of the last js.n_t traditional particles in the caller's order, with the reference's range check
+    int jq = -1;
+    if (valid && cls == 1) {
+      int o = sa.js.perm[s] - sa.js.off_t;
+      if (o >= 0 && o < sa.js.n_t) jq = o;
+    }
+    V3 xq = raw.x;
+    asm volatile("" : "+v"(xq.x), "+v"(xq.y), "+v"(xq.z), "+v"(jq));  // keep pass 2 from sharing live values with pass 1
+    if (__syncthreads_or(jq >= 0)) {  // also orders the re-zeroing flush above before the atomics below
+      if (threadIdx.x == 0) esc_n = 0;
+      P2GParticle q2 = p2g_zero(ox, oy, oz, d);
+      bool held = false;
+      V3 pv = v3(0, 0, 0);
+      if (jq >= 0) {
+        Stencil st = make_stencil(xq, d.inv_dx);
+        if (splat_ok(d.G, st)) {  // mpm_solver.py:692
+          held = true;
+          pv = load_v3(sa.js.vel_t + 3 * (size_t)jq);
+          q2.s = st; q2.mass = 1.0f; q2.a0 = pv;  // contribution = (w, w * v): the scatter's mass / momentum channels
+        }
+      }
+      __syncthreads();
+      p2g_scatter<STEPS>(tile, esc, &esc_n, q2, held, ox, oy, oz, d, g);
+      __syncthreads();
+      for (int e = threadIdx.x; e < esc_n; e += TPB) {
+        int ec = 0, es = 0;
+        if (!cm.map(chunk * CHUNK + esc[e], ec, es)) continue;
+        int o = sa.js.perm[es] - sa.js.off_t;
+        mover_escaped(ld3(b.all, A_X, es), load_v3(sa.js.vel_t + 3 * (size_t)o), d, g);
+      }
+      p2g_flush<false, true>(tile, ox, oy, oz, d, g);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1908,11 +1963,13 @@ int fast_pull(mpmhip_ctx *c) {
 //   A: [re-sort] pre-ops, body/joint splats (side stream), stress, p2g          -> halo exchange of shared blocks
 //   B: grid stage, g2p (+ escaped queue)                                         -> ghost x/v/d3 exchange
 //   C: element finalise, drift-flag bookkeeping
-// P2G_LAUNCH(trad, grid, block, shmem, stream, args...): k_p2g with or without the fused traditional stress update
-#define P2G_LAUNCH(trad, ...)                                                    \
+// P2G_LAUNCH(trad, jt, grid, block, shmem, stream, args...): k_p2g with / without the fused traditional stress update
+// and the in-tile joint splat of held traditional particles
+#define P2G_LAUNCH(trad, jt, ...)                                                \
   do {                                                                           \
-    if (trad) hipLaunchKernelGGL((k_p2g<3, true>), __VA_ARGS__);                 \
-    else hipLaunchKernelGGL((k_p2g<3, false>), __VA_ARGS__);                     \
+    if ((trad) && (jt)) hipLaunchKernelGGL((k_p2g<3, true, true>), __VA_ARGS__); \
+    else if (trad) hipLaunchKernelGGL((k_p2g<3, true, false>), __VA_ARGS__);     \
+    else hipLaunchKernelGGL((k_p2g<3, false, false>), __VA_ARGS__);              \
   } while (0)
 
 static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
@@ -1958,6 +2015,11 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   // phase names: the same kernel with no particle chunks.
   bool has_col = !c->colliders.empty() && c->num_mesh_f && f->n_fbins;
   bool mov_on = a.joint_v_v && a.joint_f_v && !c->movers.empty();
+  // traditional particles: their stress update runs at the front of p2g (k_p2g<.., true, ..>) unless profiling wants
+  // the reference's phases apart
+  const bool trad_fused = d.n_t > 0 && f->fuse_trad && !c->profiling;
+  const TradParams tp{c->sc.material, c->sc.alpha, c->sc.hardening, c->sc.xi, c->sc.plastic_viscosity, c->sc.softening};
+  bool jt_tile = false;
   SplatArgs sa{};
   SplatArgs none{};
   none.z_first = 1 << 30;
@@ -1967,15 +2029,14 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   }
   if (mov_on) {
     sa.js = JointSplatArgs{a.joint_t_v, a.joint_v_v, a.joint_f_v, (a.joint_t_v ? a.n_joint_t : 0), c->cfg.num_joint_v,
-                           c->cfg.num_joint_f, d.n_nv - a.n_joint_t, d.n_nv, f->inv};
-    int nj = sa.js.n_t + sa.js.n_v + sa.js.n_f;
+                           c->cfg.num_joint_f, d.n_nv - a.n_joint_t, d.n_nv, f->inv, f->perm[f->cur], 0};
+    // many held traditional particles: splatted through the p2g tiles (needs the fused-stress kernel variant)
+    jt_tile = trad_fused && sa.js.n_t >= 2048;
+    sa.js.t_in_tile = jt_tile ? 1 : 0;
+    int nj = (jt_tile ? 0 : sa.js.n_t) + sa.js.n_v + sa.js.n_f;
     sa.n_mov_wg = (int)nblk((size_t)nj * 32);
     if (nj == 0) sa.n_mov_wg = 0;
   }
-  // traditional particles: their stress update runs at the front of p2g (k_p2g<.., true>) unless profiling wants the
-  // reference's phases apart
-  const bool trad_fused = d.n_t > 0 && f->fuse_trad && !c->profiling;
-  const TradParams tp{c->sc.material, c->sc.alpha, c->sc.hardening, c->sc.xi, c->sc.plastic_viscosity, c->sc.softening};
   // accumulators left loaded by the previous (fused) substep: this substep scatters into the other buffer and clears
   // the loaded one with extra workgroups of the p2g launch
   sa.z = take_zero(f);
@@ -2006,7 +2067,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     {
       ScopedPhase ph(c, "p2g");
       if (f->n_chunks)
-        P2G_LAUNCH(false, xcd_grid(f->n_chunks), TPB, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
+        P2G_LAUNCH(false, false, xcd_grid(f->n_chunks), TPB, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
                    c->sc.rpic_damping, dt, f->g, none, tp);
     }
     if (sa.n_fbins) {
@@ -2015,7 +2076,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       only.n_mov_wg = 0;
       only.n_extra = (only.n_fbins + 7) & ~7;
       only.z_first = 1 << 30;
-      P2G_LAUNCH(false, (unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only, tp);
+      P2G_LAUNCH(false, false, (unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only, tp);
     }
     if (sa.n_mov_wg) {
       ScopedPhase ph(c, "apply_Particle_Moving_on_grid");
@@ -2023,12 +2084,12 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       only.n_fbins = 0;
       only.n_extra = (only.n_mov_wg + 7) & ~7;
       only.z_first = 1 << 30;
-      P2G_LAUNCH(false, (unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only, tp);
+      P2G_LAUNCH(false, false, (unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only, tp);
     }
   } else {
     ScopedPhase ph(c, "p2g");
     if (f->n_chunks || sa.n_extra || sa.z.n_wg)
-      P2G_LAUNCH(trad_fused, xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg), TPB, 0, s, b, f->va(), f->chunks,
+      P2G_LAUNCH(trad_fused, jt_tile, xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg), TPB, 0, s, b, f->va(), f->chunks,
                  f->n_chunks, d, c->sc.rpic_damping, dt, f->g, sa, tp);
   }
   return MPMHIP_OK;

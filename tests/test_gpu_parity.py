@@ -157,13 +157,15 @@ def test_out_of_margin_paths(scene, oracle_lib):
     assert rel(x, xc) < (2e-5 if scene == "cube" else 2e-4)
 
 
+@pytest.mark.parametrize("sand", [(16, 3, 8), (32, 4, 16)])  # 384: joint workgroups; 2048: second tile pass of p2g
 @pytest.mark.parametrize("mode", MODES)
-def test_staged_sand_release(mode, oracle_lib):
+def test_staged_sand_release(mode, sand, oracle_lib):
     """run_demo.py:524: the mover holds the trailing sand particles at zero velocity and lets go of them in stages
     (the length of joint_traditional_v shrinks over time).  Single-step and fused driving must agree with the oracle
     across several release boundaries."""
     from mpmavatar_amd import harness
-    mk = lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=(20, 7, 60))
+    n_sand = sand[0] * sand[1] * sand[2]
+    mk = lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=sand, hold=(20, 7, n_sand // 6))
     sc = mk()
     assert sc.joint_t_count(0) == sc.n_traditional and 0 < sc.joint_t_count(45) < sc.n_traditional
     o, g, _ = _run_pair(sc, 80, mode)
