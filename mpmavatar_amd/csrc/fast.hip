@@ -202,21 +202,23 @@ __global__ void k_export(mpmhip_state_ptrs st, mpmhip_model_ptrs md, Bufs b, VAd
 // ------------------------------------------------------------------------------------------------
 // rebin: keys, permutation, block tables
 // ------------------------------------------------------------------------------------------------
-// key = class | inactive | block | cell-in-block ; the low 6 bits order particles of a block by cell
-__device__ __forceinline__ unsigned make_key(V3 x, int cls, int inactive, const Dims &d, int blk_bits) {
+// key = class | state | block | cell-in-block ; the low 6 bits order particles of a block by cell.
+// state: 0 = simulated, 1 = ghost copy that gathers for itself (multi-GPU: g2p yes, p2g no), 2 = not transferred
+__device__ __forceinline__ unsigned make_key(V3 x, int cls, int state, const Dims &d, int blk_bits) {
   int bx = (int)(x.x * d.inv_dx - 0.5f), by = (int)(x.y * d.inv_dx - 0.5f), bz = (int)(x.z * d.inv_dx - 0.5f);
   bx = min(max(bx, 0), d.G - 3); by = min(max(by, 0), d.G - 3); bz = min(max(bz, 0), d.G - 3);
   unsigned blk = (unsigned)blk_of(bx, by, bz, d.NB);
   unsigned cell = (unsigned)loc_of(bx, by, bz);
-  return ((unsigned)cls << (blk_bits + 7)) | ((unsigned)inactive << (blk_bits + 6)) | (blk << 6) | cell;
+  return ((unsigned)cls << (blk_bits + 8)) | ((unsigned)state << (blk_bits + 6)) | (blk << 6) | cell;
 }
 
-__global__ void k_keys(Bufs b, Dims d, int blk_bits, unsigned *keys, int *iota) {
+__global__ void k_keys(Bufs b, Dims d, int blk_bits, int ghost_g2p, unsigned *keys, int *iota) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= d.n_p) return;
   int cls = s < d.n_e ? 0 : (s < d.n_nv ? 1 : 2);
   V3 x = ld3(b.all, A_X, s);
-  keys[s] = make_key(x, cls, b.sel[s] != 0 ? 1 : 0, d, blk_bits);
+  int sel = b.sel[s];
+  keys[s] = make_key(x, cls, sel == 0 ? 0 : ((sel == 2 && ghost_g2p && cls != 1) ? 1 : 2), d, blk_bits);
   iota[s] = s;
 }
 
@@ -248,7 +250,8 @@ __global__ void k_face_slots(Bufs b, const int *inv, int *face_slot, Dims d) {
 }
 
 __device__ __forceinline__ int key_block(unsigned k, int blk_bits) { return (int)((k >> 6) & ((1u << blk_bits) - 1u)); }
-__device__ __forceinline__ bool key_inactive(unsigned k, int blk_bits) { return (k >> (blk_bits + 6)) & 1u; }
+__device__ __forceinline__ int key_state(unsigned k, int blk_bits) { return (int)((k >> (blk_bits + 6)) & 3u); }
+__device__ __forceinline__ bool key_inactive(unsigned k, int blk_bits) { return key_state(k, blk_bits) >= 2; }
 
 __global__ void k_mark_blocks(const unsigned *keys, int n, int blk_bits, int *pb_flag) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,8 +274,9 @@ __global__ void k_ranges(const unsigned *keys, Dims d, int blk_bits, const int *
   int cls = s < d.n_e ? 0 : (s < d.n_nv ? 1 : 2);
   int c0 = cls == 0 ? 0 : (cls == 1 ? d.n_e : d.n_nv), c1 = cls == 0 ? d.n_e : (cls == 1 ? d.n_nv : d.n_p);
   int slot = pb_index[key_block(k, blk_bits)];
-  if (s == c0 || (keys[s - 1] >> 6) != (k >> 6)) ranges[(cls * 2 + 0) * n_P + slot] = s;
-  if (s == c1 - 1 || (keys[s + 1] >> 6) != (k >> 6)) ranges[(cls * 2 + 1) * n_P + slot] = s + 1;
+  int row = key_state(k, blk_bits) == 0 ? cls * 2 : (cls == 0 ? 6 : 8);  // ghosts: elements, vertices only
+  if (s == c0 || (keys[s - 1] >> 6) != (k >> 6)) ranges[(row + 0) * n_P + slot] = s;
+  if (s == c1 - 1 || (keys[s + 1] >> 6) != (k >> 6)) ranges[(row + 1) * n_P + slot] = s + 1;
 }
 
 __global__ void k_dilate(const int *plist, int n_P, int NB, int *ab_flag) {
@@ -498,16 +502,21 @@ __device__ __forceinline__ int tile_idx(int i, int j, int k) { return i * TS_I +
 
 // One chunk = up to 256 particles of ONE particle block, all three classes packed back to back (elements, then
 // traditional, then vertices) so that lanes stay filled; lane t of chunk k takes combined index k*256 + t.
-// The record is self-contained (32 bytes, one scalar load): a chunks -> plist -> ranges chain of three dependent
+// The record is self-contained (48 bytes, one scalar load): a chunks -> plist -> ranges chain of three dependent
 // loads in front of every particle load was a measurable part of p2g / g2p (both start with nothing else to do).
 struct ChunkRec {
   int blk, chunk, e0, ne, t0, nt, v0, nv;
+  int ge0, gne, gv0, gnv;  // ghost copies of the block (multi-GPU; only in the g2p list, empty in the p2g list)
   __device__ __forceinline__ bool map(int ci, int &cls, int &s) const {
     if (ci < ne) { cls = 0; s = e0 + ci; return true; }
     ci -= ne;
     if (ci < nt) { cls = 1; s = t0 + ci; return true; }
     ci -= nt;
     if (ci < nv) { cls = 2; s = v0 + ci; return true; }
+    ci -= nv;
+    if (ci < gne) { cls = 0; s = ge0 + ci; return true; }
+    ci -= gne;
+    if (ci < gnv) { cls = 2; s = gv0 + ci; return true; }
     return false;
   }
 };
@@ -1601,13 +1610,15 @@ struct FastState {
   GridPtrs g{};
   int *pb_flag = nullptr, *pb_index = nullptr, *ab_flag = nullptr, *ab_index = nullptr;
   int *plist = nullptr, *alist = nullptr, *ranges = nullptr;
-  ChunkRec *chunks = nullptr;
+  ChunkRec *chunks = nullptr, *chunks_g = nullptr;  // p2g list, g2p list (= p2g list unless there are ghost copies)
+  int n_chunks_g = 0;
+  bool ghost_g2p = false;  // multi-GPU: ghost copies (selection == 2) gather for themselves
   int cap_P = 0, cap_A = 0, cap_chunks = 0, cap_R = 0;
   int64_t stat_steps = 0;
   int n_P = 0, n_A = 0, n_chunks = 0;
   int *h_pin = nullptr;  // pinned host scratch
   std::vector<int> h_ranges, h_plist;
-  std::vector<ChunkRec> h_chunks;
+  std::vector<ChunkRec> h_chunks, h_chunks_g;
   bool elem_pending = false;  // element finalise of the last substep still to be done (fused into the next stress)
   int steps_since_rebin = 0;
   hipEvent_t ev_flag = nullptr;
@@ -1760,9 +1771,9 @@ int rebin(mpmhip_ctx *c) {
   hipStream_t s = c->stream;
   int cur = f->cur, alt = 1 - cur;
   flush_grid(c);
-  if (d.n_p == 0) { f->n_P = f->n_A = f->n_chunks = 0; f->steps_since_rebin = 0; return MPMHIP_OK; }
+  if (d.n_p == 0) { f->n_P = f->n_A = f->n_chunks = f->n_chunks_g = 0; f->steps_since_rebin = 0; return MPMHIP_OK; }
   flush_elements(c);
-  hipLaunchKernelGGL(k_keys, nblk(d.n_p), TPB, 0, s, f->buf[cur], d, f->blk_bits, f->keys[0], f->iota);
+  hipLaunchKernelGGL(k_keys, nblk(d.n_p), TPB, 0, s, f->buf[cur], d, f->blk_bits, f->ghost_g2p ? 1 : 0, f->keys[0], f->iota);
   size_t need = 0;
   MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(nullptr, need, f->keys[0], f->keys[1], f->iota, f->order, (size_t)d.n_p, 0u,
                                              (unsigned)f->key_bits, s));
@@ -1787,8 +1798,8 @@ int rebin(mpmhip_ctx *c) {
   int rc = scan_flags(c, f->pb_flag, f->pb_index, nb, &f->n_P);
   if (rc) return rc;
   if ((rc = ensure_cap(c, &f->plist, &f->cap_P, f->n_P, 1))) return rc;
-  if ((rc = ensure_cap(c, &f->ranges, &f->cap_R, f->n_P, 6))) return rc;
-  MPM_HIP_CHECK(c, hipMemsetAsync(f->ranges, 0, (size_t)f->n_P * 6 * sizeof(int), s));
+  if ((rc = ensure_cap(c, &f->ranges, &f->cap_R, f->n_P, 10))) return rc;
+  MPM_HIP_CHECK(c, hipMemsetAsync(f->ranges, 0, (size_t)f->n_P * 10 * sizeof(int), s));
   hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, f->pb_flag, f->pb_index, nb, f->plist);
   hipLaunchKernelGGL(k_ranges, nblk(d.n_p), TPB, 0, s, skeys, d, f->blk_bits, f->pb_index, f->n_P, f->ranges);
   hipLaunchKernelGGL(k_dilate, nblk((size_t)f->n_P * 27), TPB, 0, s, f->plist, f->n_P, d.NB, f->ab_flag);
@@ -1796,27 +1807,40 @@ int rebin(mpmhip_ctx *c) {
   if ((rc = ensure_cap(c, &f->alist, &f->cap_A, f->n_A, 1))) return rc;
   hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, f->ab_flag, f->ab_index, nb, f->alist);
   // chunk records on the host from the compact ranges
-  f->h_ranges.resize((size_t)f->n_P * 6);
+  f->h_ranges.resize((size_t)f->n_P * 10);
   f->h_plist.resize((size_t)f->n_P);
-  MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_ranges.data(), f->ranges, (size_t)f->n_P * 6 * sizeof(int), hipMemcpyDeviceToHost, s));
+  MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_ranges.data(), f->ranges, (size_t)f->n_P * 10 * sizeof(int), hipMemcpyDeviceToHost, s));
   MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_plist.data(), f->plist, (size_t)f->n_P * sizeof(int), hipMemcpyDeviceToHost, s));
   MPM_HIP_CHECK(c, hipStreamSynchronize(s));
+  // two lists: p2g walks the simulated particles of a block, g2p those plus the ghost copies (identical without ghosts)
   f->h_chunks.clear();
+  f->h_chunks_g.clear();
+  bool any_ghost = false;
   for (int p = 0; p < f->n_P; ++p) {
     auto R = [&](int k) { return f->h_ranges[(size_t)k * f->n_P + p]; };
-    ChunkRec r{f->h_plist[p], 0, R(0), R(1) - R(0), R(2), R(3) - R(2), R(4), R(5) - R(4)};
-    int tot = r.ne + r.nt + r.nv;  // the three classes of a block are packed back to back
+    ChunkRec r{f->h_plist[p], 0, R(0), R(1) - R(0), R(2), R(3) - R(2), R(4), R(5) - R(4), 0, 0, 0, 0};
+    int tot = r.ne + r.nt + r.nv;  // the classes of a block are packed back to back
     for (int k = 0; k * CHUNK < tot; ++k) { r.chunk = k; f->h_chunks.push_back(r); }
+    r.ge0 = R(6); r.gne = R(7) - R(6); r.gv0 = R(8); r.gnv = R(9) - R(8);
+    any_ghost = any_ghost || r.gne + r.gnv > 0;
+    tot += r.gne + r.gnv;
+    for (int k = 0; k * CHUNK < tot; ++k) { r.chunk = k; f->h_chunks_g.push_back(r); }
   }
   f->n_chunks = (int)f->h_chunks.size();
-  if (f->n_chunks > f->cap_chunks) {
-    int cap = f->n_chunks + f->n_chunks / 4 + 64;
+  f->n_chunks_g = any_ghost ? (int)f->h_chunks_g.size() : f->n_chunks;
+  int need_recs = f->n_chunks + (any_ghost ? f->n_chunks_g : 0);
+  if (need_recs > f->cap_chunks) {
+    int cap = need_recs + need_recs / 4 + 64;
     if ((rc = dalloc(c, &f->chunks, (size_t)cap, false))) return rc;
     f->cap_chunks = cap;
   }
+  f->chunks_g = any_ghost ? f->chunks + f->n_chunks : f->chunks;
   if (f->n_chunks)
     MPM_HIP_CHECK(c, hipMemcpyAsync(f->chunks, f->h_chunks.data(), f->h_chunks.size() * sizeof(ChunkRec), hipMemcpyHostToDevice, s));
-  MPM_HIP_CHECK(c, hipStreamSynchronize(s));  // h_chunks is pageable: the copy must finish before it is reused
+  if (any_ghost)
+    MPM_HIP_CHECK(c, hipMemcpyAsync(f->chunks + f->n_chunks, f->h_chunks_g.data(), f->h_chunks_g.size() * sizeof(ChunkRec),
+                                    hipMemcpyHostToDevice, s));
+  MPM_HIP_CHECK(c, hipStreamSynchronize(s));  // the host vectors are pageable: the copies must finish before reuse
   if (!c->colliders.empty() && c->num_mesh_f) {
     int nf = c->num_mesh_f;
     hipLaunchKernelGGL(k_face_keys, nblk(nf), TPB, 0, s, c->cur_pts, c->cur_vel, c->cur_f, c->mesh_idx, nf, d, f->fkeys[0], f->fiota);
@@ -1869,7 +1893,7 @@ int fast_init(mpmhip_ctx *c) {
   f->nblocks = (size_t)d.NB * d.NB * d.NB;
   f->blk_bits = 1;
   while ((1ull << f->blk_bits) < f->nblocks) ++f->blk_bits;
-  f->key_bits = f->blk_bits + 6 + 1 + 2;
+  f->key_bits = f->blk_bits + 6 + 2 + 2;
   if (f->key_bits > 32) return fail(c, MPMHIP_ERR_INVALID, "grid too large for 32-bit sort keys");
   // upper bound between re-sorts; the drift flag normally triggers one earlier (or never, for slow scenes)
   f->rebin_interval = cfg.rebin_interval > 0 ? cfg.rebin_interval : (cfg.rebin_interval < 0 ? -cfg.rebin_interval : 256);
@@ -2121,11 +2145,11 @@ static int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
   for (auto &bc : c->bcs) bc_host_modify(bc, (float)c->time, dt);
   {
     ScopedPhase ph(c, "g2p_v");
-    if (f->n_chunks) {
+    if (f->n_chunks_g) {
       if (fused)
-        hipLaunchKernelGGL(k_g2p<true>, xcd_grid(f->n_chunks), TPB, 0, s, b, f->chunks, f->n_chunks, d, dt, f->g, gp, bcl);
+        hipLaunchKernelGGL(k_g2p<true>, xcd_grid(f->n_chunks_g), TPB, 0, s, b, f->chunks_g, f->n_chunks_g, d, dt, f->g, gp, bcl);
       else
-        hipLaunchKernelGGL(k_g2p<false>, xcd_grid(f->n_chunks), TPB, 0, s, b, f->chunks, f->n_chunks, d, dt, f->g, gp, bcl);
+        hipLaunchKernelGGL(k_g2p<false>, xcd_grid(f->n_chunks_g), TPB, 0, s, b, f->chunks_g, f->n_chunks_g, d, dt, f->g, gp, bcl);
     }
   }
   if (fused) {
