@@ -191,7 +191,11 @@ int mpmhip_set_time(mpmhip_ctx *ctx, double t);
  *   begin: [stress, p2g] + pack halo_send      -> exchange halo   (sum of the grid blocks both ranks touch)
  *   mid  : add halo_recv, [grid, g2p] + pack ghost_send -> exchange ghosts (x, v of vertices; d3 of elements)
  *   end  : unpack ghost_recv, [element finalise]
- * All ranks must re-sort at the same substep: mpmhip_dist_rebin() replaces the context's own re-sort policy. */
+ * All ranks must re-sort at the same substep: mpmhip_dist_rebin() replaces the context's own re-sort policy.
+ * With mpmhip_dist_set_ghost_mode(ctx, 1) the ghost copies gather for themselves (g2p yes, p2g no): their grid
+ * neighbourhood is on both ranks' active lists and therefore complete after the halo sum, so the per-substep ghost
+ * exchange disappears (mid / end no longer pack / unpack); owners and copies differ only by the rounding order of the
+ * halo sums, and mpmhip_dist_ghost_pack / _unpack re-synchronise them around an exchange at each collective re-sort. */
 typedef struct {
   int32_t n_blocks;          /* grid blocks on both ranks' active lists */
   const int32_t *blocks;     /* [dev] their ids in ascending order (identical on both ranks) */
@@ -202,6 +206,11 @@ typedef struct {
   float *ghost_send, *ghost_recv; /* [dev] 6*n_p + 3*n_e floats */
 } mpmhip_dist_peer;
 int mpmhip_dist_enable(mpmhip_ctx *ctx);
+/* 0 (default): ghost copies are overwritten by their owners' values every substep; 1: they gather for themselves.
+ * Call before the first mpmhip_dist_rebin. */
+int mpmhip_dist_set_ghost_mode(mpmhip_ctx *ctx, int32_t ghosts_gather);
+int mpmhip_dist_ghost_pack(mpmhip_ctx *ctx);   /* fill every peer's ghost_send */
+int mpmhip_dist_ghost_unpack(mpmhip_ctx *ctx); /* apply every peer's ghost_recv */
 int mpmhip_dist_num_blocks(const mpmhip_ctx *ctx); /* size of the active-block byte map */
 /* import the bound state if needed, re-sort, and write this rank's active-block map (1 byte per block) [dev] */
 int mpmhip_dist_rebin(mpmhip_ctx *ctx, uint8_t *active_map);
@@ -223,8 +232,9 @@ int mpmhip_rccl_set_ghosts(mpmhip_ctx *ctx, int32_t n_peers, const int32_t *peer
                            const int32_t *n_send_e, const int32_t *const *send_e, const int32_t *n_recv_e,
                            const int32_t *const *recv_e);
 /* n substeps (collective): re-sort + shared-block lists every rebin_interval substeps (counted from step_index),
- * halo and ghost exchanges with ncclSend/ncclRecv groups on the context's stream; mesh advection factor of substep
- * k is (step_index + k) * dt */
+ * halo (and, in ghost mode 0, ghost) exchanges with ncclSend/ncclRecv groups on the context's stream; in ghost mode 1
+ * the ghosts are re-synchronised before every re-sort instead.  Mesh advection factor of substep k is
+ * (step_index + k) * dt */
 int mpmhip_rccl_steps(mpmhip_ctx *ctx, float dt, int32_t n, int64_t step_index, int32_t rebin_interval,
                       const float *mesh_x, const float *mesh_v, const float *joint_verts_v, const float *joint_faces_v);
 

@@ -89,6 +89,9 @@ SIGNATURES = {
     "mpmhip_step": (C.c_int, [vp, C.c_float, vp, vp, vp, C.c_int32, vp, vp]),
     "mpmhip_steps": (C.c_int, [vp, C.c_float, C.c_int32, vp, vp, vp, C.c_int32, vp, vp]),
     "mpmhip_dist_enable": (C.c_int, [vp]),
+    "mpmhip_dist_set_ghost_mode": (C.c_int, [vp, C.c_int32]),
+    "mpmhip_dist_ghost_pack": (C.c_int, [vp]),
+    "mpmhip_dist_ghost_unpack": (C.c_int, [vp]),
     "mpmhip_dist_num_blocks": (C.c_int, [vp]),
     "mpmhip_dist_rebin": (C.c_int, [vp, vp]),
     "mpmhip_dist_set_peers": (C.c_int, [vp, C.c_int32, C.POINTER(DistPeer)]),

@@ -384,6 +384,21 @@ int mpmhip_dist_enable(mpmhip_ctx *c) {
   if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
   return fast_dist_enable(c);
 }
+int mpmhip_dist_set_ghost_mode(mpmhip_ctx *c, int32_t ghosts_gather) {
+  CHECK_CTX(c);
+  if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
+  return fast_dist_set_ghost_mode(c, ghosts_gather);
+}
+int mpmhip_dist_ghost_pack(mpmhip_ctx *c) {
+  CHECK_CTX(c);
+  if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
+  return fast_dist_ghosts(c, 1);
+}
+int mpmhip_dist_ghost_unpack(mpmhip_ctx *c) {
+  CHECK_CTX(c);
+  if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
+  return fast_dist_ghosts(c, 0);
+}
 int mpmhip_dist_num_blocks(const mpmhip_ctx *c) { return (c && c->fast) ? fast_dist_num_blocks(c) : 0; }
 int mpmhip_dist_rebin(mpmhip_ctx *c, uint8_t *active_map) {
   CHECK_CTX(c);

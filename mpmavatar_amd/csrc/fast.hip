@@ -2200,6 +2200,11 @@ int fast_dist_enable(mpmhip_ctx *c) {
   c->fast->dist = true;
   return MPMHIP_OK;
 }
+int fast_dist_set_ghost_mode(mpmhip_ctx *c, int ghosts_gather) {
+  c->fast->ghost_g2p = ghosts_gather != 0;
+  c->fast->steps_since_rebin = 1 << 30;
+  return MPMHIP_OK;
+}
 int fast_dist_num_blocks(const mpmhip_ctx *c) { return (int)c->fast->nblocks; }
 
 int fast_dist_rebin(mpmhip_ctx *c, unsigned char *active_map) {
@@ -2283,11 +2288,19 @@ int fast_dist_phase(mpmhip_ctx *c, int phase, const StepArgs &a) {
   } else if (phase == 1) {
     launch_halo(c, false);
     if ((rc = step_phase_b(c, f->dist_args))) return rc;
-    launch_ghosts(c, true);
+    if (!f->ghost_g2p) launch_ghosts(c, true);
   } else {
-    launch_ghosts(c, false);
+    if (!f->ghost_g2p) launch_ghosts(c, false);
     if ((rc = step_phase_c(c, f->dist_args))) return rc;
   }
+  MPM_HIP_CHECK(c, hipGetLastError());
+  return MPMHIP_OK;
+}
+// re-synchronisation of the ghost copies around an exchange (ghost mode 1: at every collective re-sort)
+int fast_dist_ghosts(mpmhip_ctx *c, int send) {
+  if (!c->fast->have_order) return MPMHIP_OK;  // nothing sorted yet: the copies are still the caller's exact values
+  if (!send) flush_elements(c);                // finished elements first: the unpack overwrites their d3
+  launch_ghosts(c, send != 0);
   MPM_HIP_CHECK(c, hipGetLastError());
   return MPMHIP_OK;
 }
@@ -2425,6 +2438,11 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
     c->cur_vel = a.mesh_v ? a.mesh_v : c->mesh_vel;
     c->cur_f = (a.mesh_x && a.mesh_v) ? a.mesh_f : 0.0f;
     if (idx % rebin_interval == 0 || c->caller_dirty) {
+      if (f->ghost_g2p && f->have_order && !c->caller_dirty && !f->peers.empty()) {  // owners -> copies, then re-sort
+        if ((rc = fast_dist_ghosts(c, 1))) return rc;
+        if ((rc = rccl_exchange(c, false))) return rc;
+        if ((rc = fast_dist_ghosts(c, 0))) return rc;
+      }
       f->dist_keep_cur = true;
       rc = rccl_rebin(c);
       f->dist_keep_cur = false;
@@ -2433,7 +2451,7 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
     if ((rc = fast_dist_phase(c, 0, a))) return rc;
     if ((rc = rccl_exchange(c, true))) return rc;
     if ((rc = fast_dist_phase(c, 1, a))) return rc;
-    if ((rc = rccl_exchange(c, false))) return rc;
+    if (!f->ghost_g2p && (rc = rccl_exchange(c, false))) return rc;
     if ((rc = fast_dist_phase(c, 2, a))) return rc;
     c->time = c->time + (double)dt;
     c->substeps += 1;

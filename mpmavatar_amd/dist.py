@@ -8,10 +8,12 @@ Decomposition
   * ghosts: a rank also holds (a) every element that touches one of its vertices (so vertex forces are complete
     without an exchange) and (b) every vertex of its local elements.  Ghost copies carry particle_selection == 2:
     stress / element finalise run on them, p2g / g2p do not.
-  * per substep two neighbour exchanges, RCCL send/recv through torch.distributed on the solver's stream:
-      1. after p2g : the (m, momentum[, mover]) channels of the grid blocks that both ranks have on their active
-         lists are summed (both then run the identical grid update there, so g2p needs no second exchange);
-      2. after g2p : owners send x, v of their boundary vertices and d3 of their boundary elements to the ghosts.
+  * per substep ONE neighbour exchange: after p2g the (m, momentum[, mover]) channels of the grid blocks that both
+    ranks have on their active lists are summed; both ranks then evaluate the identical grid stage there.  Ghost
+    copies gather for themselves (g2p yes, p2g no): their grid neighbourhood is on both active lists, hence complete
+    after the sum.  Owner and copy differ only by the rounding order of those sums; at every collective re-sort the
+    owners overwrite the copies (x, v of vertices, d3 of elements) to keep that from accumulating.
+    (MPMHIP_DIST_GHOST_G2P=0 selects the older scheme: copies do not gather, owners send them every substep.)
     The body-face splat is replicated (each rank splats the faces that touch its active blocks).
   * all ranks re-sort at the same substep (every ``rebin_interval`` substeps); the shared-block lists are rebuilt
     there from an all_gather of the per-rank active-block maps.
@@ -127,6 +129,7 @@ class ShardedSim:
     backend: str
     rebin_interval: int
     transport: str = "torch"           # "rccl": loop inside libmpmhip.so; "torch": phases driven from Python
+    ghost_g2p: bool = True             # ghost copies gather for themselves (one exchange per substep)
     steps_done: int = 0
     peers: list = field(default_factory=list)
     keep: list = field(default_factory=list)
@@ -145,7 +148,10 @@ def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int 
     sv = sim.solver
     sv._bind(sim.model, sim.state)
     sv._call("mpmhip_dist_enable")
-    ss = ShardedSim(shard, sim, dist.get_backend(), rebin_interval or 32)
+    import os
+    ghost_g2p = os.environ.get("MPMHIP_DIST_GHOST_G2P", "1") != "0"
+    sv._call("mpmhip_dist_set_ghost_mode", 1 if ghost_g2p else 0)
+    ss = ShardedSim(shard, sim, dist.get_backend(), rebin_interval or 32, ghost_g2p=ghost_g2p)
     dev = torch.device(device)
     i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.int32), device=dev)
     for q in sorted(set(shard.send_p) | set(shard.recv_p)):
@@ -301,6 +307,10 @@ def run(ss: ShardedSim, n_steps: int):
         return
     for _ in range(n_steps):
         if ss.steps_done % ss.rebin_interval == 0:
+            if ss.ghost_g2p and ss.steps_done > 0 and ss.peers:  # owners -> copies before the re-sort
+                sv._call("mpmhip_dist_ghost_pack")
+                _exchange(ss, "ghost")
+                sv._call("mpmhip_dist_ghost_unpack")
             rebin_all(ss)
         adv = float(np.float32(sc.dt * ss.steps_done))
         jvp = None if jv is None else (dp(jv) or dummy)
@@ -308,7 +318,8 @@ def run(ss: ShardedSim, n_steps: int):
         sv._call("mpmhip_dist_step_begin", float(sc.dt), dp(sim.mesh_x0), dp(sim.mesh_v), adv, None, 0, jvp, jfp)
         _exchange(ss, "halo")
         sv._call("mpmhip_dist_step_mid")
-        _exchange(ss, "ghost")
+        if not ss.ghost_g2p:
+            _exchange(ss, "ghost")
         sv._call("mpmhip_dist_step_end")
         ss.steps_done += 1
 

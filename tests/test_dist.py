@@ -21,11 +21,11 @@ def _free_port():
     return p
 
 
-def _launch(nproc, *args, timeout=600):
+def _launch(nproc, *args, timeout=600, extra_env=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"),
            *map(str, args)]
-    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return r.stdout
@@ -38,9 +38,18 @@ def test_partition_and_halo_sum_cpu(world, scene, oracle_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ghost_g2p", ["1", "0"])  # 1: copies gather for themselves; 0: owners send every substep
 @pytest.mark.parametrize("scene,steps", [("garment", 40), ("sheet", 40), ("demo", 30), ("cube", 30)])
-def test_sharded_matches_single_context(scene, steps):
-    out = _launch(2, "gpu", scene, steps)
+def test_sharded_matches_single_context(scene, steps, ghost_g2p):
+    out = _launch(2, "gpu", scene, steps, extra_env={"MPMHIP_DIST_GHOST_G2P": ghost_g2p})
+    assert "max rel dx" in out
+
+
+@pytest.mark.gpu
+def test_sharded_ghost_resync_at_resort():
+    """More substeps than the collective re-sort interval (8 in the worker): the copies are overwritten by their
+    owners' values before each re-sort and keep gathering for themselves in between."""
+    out = _launch(2, "gpu", "sheet", 100)
     assert "max rel dx" in out
 
 
