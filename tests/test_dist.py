@@ -46,6 +46,15 @@ def test_sharded_matches_single_context(scene, steps, ghost_g2p):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["sheet", "demo"])
+def test_sharded_three_ranks(scene):
+    """Three ranks (interior rank with two peers: multi-peer pack / add tables; halo sums are no longer a single
+    commutative pair, so owner and ghost copy may differ in the last bit until the next re-synchronisation)."""
+    out = _launch(3, "gpu", scene, 60)
+    assert "max rel dx" in out
+
+
+@pytest.mark.gpu
 def test_sharded_ghost_resync_at_resort():
     """More substeps than the collective re-sort interval (8 in the worker): the copies are overwritten by their
     owners' values before each re-sort and keep gathering for themselves in between."""
