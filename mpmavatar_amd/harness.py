@@ -75,7 +75,7 @@ def run(sim: Sim, n_steps: int, fused: bool = False):
     on the torch side like the reference loop; fused=True hands runs of substeps to ``mpmhip_steps`` (split where the
     scene's staged sand release changes the length of ``joint_traditional_v``)."""
     sc, sv = sim.scene, sim.solver
-    dev = sim.state.particle_x.device
+    dev = sv.device  # (not via sim.state.particle_x: reading a state field pulls it back and forces a re-import)
 
     def kwargs(step):
         n_jt = sc.joint_t_count(step)
