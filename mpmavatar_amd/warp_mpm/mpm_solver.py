@@ -86,6 +86,7 @@ class MPMWARP(object):
         self._keep = None
         self._masks = []
         self._profiling = False
+        self._read_snaps = {}
         # bookkeeping lists kept for API familiarity (mpm_solver.py:30-43)
         self.grid_postprocess, self.collider_params, self.modify_bc = [], [], []
         self.mesh_colliders, self.mesh_collider_params = [], []
@@ -176,7 +177,23 @@ class MPMWARP(object):
     def _before_caller_read(self, obj):
         if self._ctx and (obj is self._bound_state or obj is self._bound_model):
             self._call("mpmhip_pull_state")
-            # the caller may modify what it reads: re-import before the next substep (cheap, once per frame)
+            # The caller may modify what it reads (the reference hands out zero-copy views).  torch counts in-place
+            # modifications per tensor (Tensor._version): remember the counters and re-import before the next substep
+            # only if one of them moved -- a plain read-back (clone / .cpu(), once per frame in the drivers) then costs
+            # no re-import and no re-sort.  Writes that bypass torch need state._touch().
+            snap = {}
+            for name in type(obj)._fields:
+                t = obj._t.get(name)
+                if isinstance(t, torch.Tensor):
+                    snap[name] = (t, t._version)
+            self._read_snaps[id(obj)] = snap
+
+    def _push_if_modified(self):
+        if not self._read_snaps:
+            return
+        dirty = any(t._version != v for snap in self._read_snaps.values() for t, v in snap.values())
+        self._read_snaps.clear()
+        if dirty:
             self._call("mpmhip_push_state")
 
     def _before_caller_write(self, obj):
@@ -250,6 +267,7 @@ class MPMWARP(object):
                    fused=True)
 
     def _step(self, mpm_model, mpm_state, dt, n, mesh_x, mesh_v, jt, jv, jf, fused=False):
+        self._push_if_modified()
         self._bind(mpm_model, mpm_state)
         has_mesh = hasattr(self, "mesh")
         mx = self._ptr(mesh_x, self.num_mesh_v if has_mesh else None, "mesh_x")

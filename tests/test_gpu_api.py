@@ -43,6 +43,23 @@ def test_read_modify_continue(mode, oracle_lib):
     assert rel(sim.state.particle_v.cpu().numpy(), o.v) < 2e-2
 
 
+def test_plain_read_back_costs_no_reimport():
+    """The drivers read particle_x once per frame (run_demo.py:532).  A read that does not modify the tensors must not
+    make the next substep re-import the state and re-sort (torch's per-tensor version counters tell)."""
+    sc = scenes.small_sheet()
+    sim = harness.build_solver(sc, "cuda:0", mode="fast", rebin_interval=-1000000)  # fixed interval: only imports re-sort
+    ref = harness.build_solver(sc, "cuda:0", mode="fast", rebin_interval=-1000000)
+    for _ in range(5):
+        harness.run(sim, 8, fused=True)
+        _ = sim.state.particle_x.clone(), sim.state.particle_v.cpu()
+    harness.run(ref, 40, fused=True)
+    assert sim.solver.stats()["rebins"] == 1
+    assert rel(sim.state.particle_x.cpu().numpy(), ref.state.particle_x.cpu().numpy()) < 1e-7
+    sim.state.particle_v.mul_(1.0)  # an in-place op, even a no-op, counts as a modification
+    harness.run(sim, 1, fused=True)
+    assert sim.solver.stats()["rebins"] == 2
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_reset_state_gives_a_fresh_run(mode):
     sc = scenes.small_sheet()
