@@ -43,8 +43,9 @@ def phase_bytes(sc, n_active, n_coll, n_mov):
     }
 
 
-# kernels of the fused substep loop per reference phase (rocprofv3 names; k_g2p<true> also does the grid stage)
-PHASE_KERNELS = {"p2g": ["k_p2g<3, false>", "k_p2g<3, true>", "k_p2g<3>"], "g2p_v": ["k_g2p<true>"], "grid_update": ["k_grid<true>"],
+# kernels of the fused substep loop per reference phase (rocprofv3 names without template arguments, except where the
+# argument selects the fused form; k_g2p<true> also does the grid stage)
+PHASE_KERNELS = {"p2g": ["k_p2g"], "g2p_v": ["k_g2p<true>"], "grid_update": ["k_grid<true>"],
                  "compute_stress_from_F_trial": ["k_stress_elem<true>", "k_stress_trad"], "g2p_e": ["k_elem_finalize"]}
 
 
@@ -59,10 +60,10 @@ def pmc_traffic(phase, workload):
         return None, None
     prof = json.load(open(files[-1]))
     tot = 0.0
-    for k in PHASE_KERNELS.get(phase, []):
-        e = prof["kernels"].get(k)
-        if e:
-            tot += e["hbm_read_bytes"] + e["hbm_write_bytes"]
+    for want in PHASE_KERNELS.get(phase, []):
+        for k, e in prof["kernels"].items():
+            if k == want or ("<" not in want and k.split("<")[0] == want):
+                tot += e["hbm_read_bytes"] + e["hbm_write_bytes"]
     return (tot or None), os.path.relpath(files[-1], ROOT)
 
 
