@@ -14,7 +14,7 @@ namespace mpm {
 namespace {
 
 constexpr int TPB = 256;
-inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+inline unsigned nblk(size_t n) { return n ? (unsigned)((n + TPB - 1) / TPB) : 1u; }  // never an empty grid: kernels bound-check
 
 struct GridDesc {
   int G;

@@ -7,7 +7,7 @@ namespace mpm {
 
 namespace {
 constexpr int TPB = 256;
-inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+inline unsigned nblk(size_t n) { return n ? (unsigned)((n + TPB - 1) / TPB) : 1u; }  // never an empty grid: kernels bound-check
 
 // v / x / mass are AoS [n*3], [n*3], [n] in the caller's particle order
 __global__ void k_pre(PreOp op, float *v, const float *x, const float *mass, int n, float dt) {

@@ -41,7 +41,7 @@ constexpr int TPB = 256;
 constexpr int CHUNK = 256;     // particles per class handled by one workgroup of p2g / g2p
 constexpr int TILE = 8;        // tile edge in nodes: block (4) + 1 below + 3 above
 constexpr int TILE3 = TILE * TILE * TILE;
-inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+inline unsigned nblk(size_t n) { return n ? (unsigned)((n + TPB - 1) / TPB) : 1u; }  // never an empty grid: kernels bound-check
 
 // component-major array view: comp c of item i at p[c*n + i]
 struct Soa {
@@ -864,11 +864,19 @@ struct SegMask {
   bool tail;             // last lane of its segment
 };
 __device__ __forceinline__ SegMask seg_masks(int key) {
+  // m_d(l) = 1 iff lanes l-d .. l all carry the same key (one unbroken run).  Comparing key(l-d) with key(l) alone is
+  // only equivalent while equal keys are contiguous, i.e. right after a re-sort: once particles have moved to other
+  // cells of their block the lane order is no longer monotone (A B A ...), and the scan would jump over the B and add a
+  // lane that also issues its own atomic.
   SegMask sm;
-  sm.m1 = dpp_shr_i(key, ~key, 1) == key ? 1.0f : 0.0f;
-  sm.m2 = dpp_shr_i(key, ~key, 2) == key ? 1.0f : 0.0f;
-  sm.m4 = dpp_shr_i(key, ~key, 4) == key ? 1.0f : 0.0f;
-  sm.m8 = dpp_shr_i(key, ~key, 8) == key ? 1.0f : 0.0f;
+  int c1 = dpp_shr_i(key, ~key, 1) == key ? 1 : 0;
+  int c2 = c1 & dpp_shr_i(c1, 0, 1);
+  int c4 = c2 & dpp_shr_i(c2, 0, 2);
+  int c8 = c4 & dpp_shr_i(c4, 0, 4);
+  sm.m1 = c1 ? 1.0f : 0.0f;
+  sm.m2 = c2 ? 1.0f : 0.0f;
+  sm.m4 = c4 ? 1.0f : 0.0f;
+  sm.m8 = c8 ? 1.0f : 0.0f;
   int next = __builtin_amdgcn_update_dpp(~key, key, 0x101, 0xf, 0xf, false);  // row_shl:1 -> lane l+1
   sm.tail = next != key;
   return sm;

@@ -21,6 +21,8 @@ def oracle_from_scene(sc, omp=False, n_threads=1) -> OracleMPM:
     o.faces[:] = sc.faces.astype(np.float32)  # float-encoded indices, mpm_data_structure.py:211-215
     o.d[:] = sc.d
     o.R_inv[:] = sc.R_inv
+    if getattr(sc, "selection", None) is not None:
+        o.selection[:] = np.where(np.asarray(sc.selection) == 0, 0, 1)  # only selection == 0 is simulated (mpm_data_structure.py:39)
     o.set_parameters_dict(sc.params)
     o.reset_state()
     o.density[:] = sc.density
