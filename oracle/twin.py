@@ -76,6 +76,8 @@ class TwinMPM:
         p = sc.params
         self.material = MATERIALS[p.get("material", "jelly")]
         self.g = f8(p.get("g", [0, 0, 0]))
+        self.rpic_damping = float(np.float32(p.get("rpic_damping", 0.0)))
+        self.grid_v_damping_scale = float(np.float32(p.get("grid_v_damping_scale", 1.1)))
         self.density = np.full(self.n_p, float(sc.density))
         self.mass = f8((self.density.astype(np.float32) * sc.vol.astype(np.float32)))
         E, nu = np.float32(sc.E), np.float32(sc.nu)
@@ -217,7 +219,12 @@ class TwinMPM:
         dW = self._dw27(w, dw)
         nodes = self._nodes(base)
         dpos = (_IJK[None].astype(np.float64) - fx[:, None, :]) * self.dx
-        mv = self.v[:, None, :] + np.einsum("nij,nkj->nki", self.C, dpos)
+        # mpm_utils.py:528-540: C <- (1 - rpic) C + rpic/2 (C - C^T); C = 0 if rpic < -0.001
+        r = self.rpic_damping
+        Ca = (1.0 - r) * self.C + 0.5 * r * (self.C - np.transpose(self.C, (0, 2, 1)))
+        if r < -0.001:
+            Ca = np.zeros_like(Ca)
+        mv = self.v[:, None, :] + np.einsum("nij,nkj->nki", Ca, dpos)
         mom = (W * self.mass[:, None])[..., None] * mv
         force = np.zeros((self.n_p, 27, 3))
         S = self.stress.copy()
@@ -233,6 +240,8 @@ class TwinMPM:
     def grid_update(self, dt):
         act = self.grid_m > 1e-15
         self.grid_v_out[act] = self.grid_v_in[act] / self.grid_m[act, None] + dt * self.g
+        if self.grid_v_damping_scale < 1.0:  # add_damping_via_grid, mpm_solver.py:373, mpm_utils.py:1162-1174
+            self.grid_v_out -= (1.0 - self.grid_v_damping_scale) * self.grid_v_out
 
     def _splat(self, pts, vals_list):
         G = self.G

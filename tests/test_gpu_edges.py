@@ -106,3 +106,67 @@ def test_no_particles(mode):
     harness.run(sim, 2, fused=False)
     assert sim.state.particle_x.shape == (0, 3)
     assert sim.solver.stats()["n_active_nodes"] == 0
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("params", [{"rpic_damping": 0.3}, {"rpic_damping": -1.0}, {"grid_v_damping_scale": 0.9},
+                                    {"rpic_damping": 0.5, "grid_v_damping_scale": 0.97}])
+def test_rpic_and_grid_damping(mode, params, oracle_lib):
+    """rpic_damping blends / drops the APIC matrix in p2g (mpm_utils.py:528-534); grid_v_damping_scale < 1 switches on
+    add_damping_via_grid (mpm_solver.py:373, mpm_utils.py:1162-1174).  The drivers leave both at their defaults."""
+    sc = scenes.small_cube(n=6, params=params)
+    o, sim = _pair(sc, 60, mode)
+    assert rel(sim.state.particle_x.cpu().numpy(), o.x) < 1e-5
+    assert rel(sim.state.particle_v.cpu().numpy(), o.v) < 1e-4
+    # absolute bound: C is tiny once the grid is damped, the fp32 cancellation noise of 4/dx (M - v fx) is not
+    assert np.abs(sim.state.particle_C.cpu().numpy() - o.C).max() < 1e-4
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("surface", ["sticky", "slip", "cut"])
+def test_surface_collider_kinds_and_grid_mask(mode, surface, oracle_lib):
+    """Plane colliders of every kind (incl. quirk Q1: slip / frictional planes also end in a zero write) plus a
+    grid-node mask that pins a slab of nodes (enforce_grid_velocity_by_mask, mpm_solver.py:1330-1355)."""
+    from oracle.scene_adapter import oracle_from_scene
+    sc = scenes.small_cube(n=6)
+    sc.bcs = []
+    G = sc.n_grid
+    mask = np.zeros((G, G, G), np.int32)
+    mask[:, :, : G // 2 - 2] = 1   # nodes with small z are pinned: the cube's low-z side hangs on them
+    o = oracle_from_scene(sc)
+    sim = harness.build_solver(sc, "cuda:0", mode=mode)
+    y0 = float(sc.x[:, 1].min()) - 0.01
+    kw = dict(point=[0.0, y0, 0.0], normal=[0.0, 2.0, 0.0], surface=surface, friction=0.0 if surface == "sticky" else 0.3)
+    sim.solver.add_surface_collider(**kw)
+    o.add_surface_collider(**kw)
+    sim.solver.enforce_grid_velocity_by_mask(torch.as_tensor(mask.reshape(-1)))
+    o.enforce_grid_velocity_by_mask(mask)
+    for _ in range(60):
+        sim.solver.p2g2p(sim.model, sim.state, sc.dt)
+        o.p2g2p(sc.dt)
+    assert rel(sim.state.particle_x.cpu().numpy(), o.x) < 1e-5
+    assert rel(sim.state.particle_v.cpu().numpy(), o.v) < 1e-4
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_high_valence_vertex(mode, oracle_lib):
+    """A triangle fan: one vertex shared by 20 elements (the vertex-force gather walks its adjacency in batches of 8,
+    the garment meshes of the other tests never exceed 6-8)."""
+    from mpmavatar_amd.scenes import _cloth_scene
+    n = 20
+    ang = np.linspace(0.0, 2.0 * np.pi, n, endpoint=False)
+    ring = np.stack([1.0 + 0.12 * np.cos(ang), np.full(n, 1.2), 1.0 + 0.12 * np.sin(ang)], 1)
+    ring2 = np.stack([1.0 + 0.24 * np.cos(ang + 0.1), np.full(n, 1.2), 1.0 + 0.24 * np.sin(ang + 0.1)], 1)
+    verts = np.concatenate([[[1.0, 1.2, 1.0]], ring, ring2]).astype(np.float32)
+    faces = [[0, 1 + i, 1 + (i + 1) % n] for i in range(n)]
+    faces += [[1 + i, 1 + n + i, 1 + (i + 1) % n] for i in range(n)]
+    faces += [[1 + (i + 1) % n, 1 + n + i, 1 + n + (i + 1) % n] for i in range(n)]
+    faces = np.asarray(faces, np.int32)
+    sc = _cloth_scene("fan", verts, faces, 32, n_steps=60)
+    sc.v[:] = np.array([0.0, 0.0, 0.0], np.float32)
+    sc.v[sc.n_elements + sc.n_traditional] = [0.0, 0.6, 0.0]   # pluck the hub vertex
+    o, sim = _pair(sc, 60, mode)
+    assert rel(sim.state.particle_x.cpu().numpy(), o.x) < 1e-5
+    assert rel(sim.state.particle_v.cpu().numpy(), o.v) < 5e-2   # cloth branch flips (test_gpu_parity docstring)
+    o1, sim1 = _pair(sc, 1, mode)
+    assert rel(sim1.state.particle_v.cpu().numpy(), o1.v) < 1e-4

@@ -31,6 +31,15 @@ def test_cube_100_substeps(material, params, oracle_lib):
     assert rel(o.x, t.x) < 1e-5 and rel(o.v, t.v) < 2e-4 and rel(o.F_trial, t.F_trial) < 1e-5
 
 
+@pytest.mark.parametrize("params", [{"rpic_damping": 0.3}, {"rpic_damping": -1.0}, {"grid_v_damping_scale": 0.9},
+                                    {"rpic_damping": 0.5, "grid_v_damping_scale": 0.97}])
+def test_rpic_and_grid_damping(params, oracle_lib):
+    """p2g's RPIC blend / PIC switch (mpm_utils.py:528-540) and add_damping_via_grid (:1162-1174, mpm_solver.py:373)."""
+    o, t = pair(scenes.small_cube(n=6, params=params), 60)
+    assert rel(o.x, t.x) < 1e-5 and rel(o.v, t.v) < 2e-4
+    assert np.abs(o.C - t.C).max() < 1e-4   # absolute: C is tiny under damping, fp32 cancellation noise is not
+
+
 def test_sheet_first_substep_strict(oracle_lib):
     o, t = pair(scenes.small_sheet(), 1)
     assert rel(o.x, t.x) < 1e-6 and rel(o.v, t.v) < 2e-5 and rel(o.C, t.C) < 5e-5 and rel(o.d, t.d) < 1e-6
