@@ -170,3 +170,38 @@ def test_high_valence_vertex(mode, oracle_lib):
     assert rel(sim.state.particle_v.cpu().numpy(), o.v) < 5e-2   # cloth branch flips (test_gpu_parity docstring)
     o1, sim1 = _pair(sc, 1, mode)
     assert rel(sim1.state.particle_v.cpu().numpy(), o1.v) < 1e-4
+
+
+@pytest.mark.parametrize("rebin_interval", [0, -1000000])
+def test_particles_shuffling_between_cells(rebin_interval, oracle_lib):
+    """A spinning, shearing blob: over the run every particle crosses several cells (and blocks), neighbours at
+    different times.  rebin_interval = 0: adaptive re-sorts keep up; negative: ONE sort at the start, so the lane order
+    inside a block becomes arbitrary (runs of equal cells break up, particles sit far outside their tile) -- the
+    segmented scan, the margin checks and the global-memory fallbacks all have to cope.  Baseline kernels and oracle as
+    references."""
+    from oracle.scene_adapter import oracle_from_scene, run_scene
+    rng = np.random.default_rng(5)
+    dx = 2.0 / 32
+    pts = (np.array([0.75, 0.75, 0.75]) + rng.uniform(0, 0.5, (3000, 3))).astype(np.float32)
+    r = pts - pts.mean(0)
+    vel = (np.cross(np.array([0.0, 0.0, 9.0]), r) + np.stack([5.0 * r[:, 1], 0 * r[:, 0], 2.0 * r[:, 0]], 1)).astype(np.float32)
+    sc = _trad_scene("whirl", pts, (dx / 2) ** 3, 32, v=vel, E=20.0, bcs=[("bounding_box", {})], n_steps=80)
+    sc.dt = 1e-3
+    sc.params["g"] = [0.0, 0.0, 0.0]
+    n = 80
+    o = oracle_from_scene(sc)
+    run_scene(o, sc, n)
+    assert np.abs(o.x - sc.x).max() > 1.2 * dx   # they do travel across cells
+    fast = harness.build_solver(sc, "cuda:0", mode="fast", rebin_interval=rebin_interval)
+    harness.run(fast, n, fused=True)
+    base = harness.build_solver(sc, "cuda:0", mode="baseline")
+    harness.run(base, n, fused=True)
+    xf, xb = fast.state.particle_x.cpu().numpy(), base.state.particle_x.cpu().numpy()
+    vf, vb = fast.state.particle_v.cpu().numpy(), base.state.particle_v.cpu().numpy()
+    assert np.isfinite(xf).all()
+    assert rel(xf, o.x) < 1e-4 and rel(vf, o.v) < 1e-3
+    assert rel(xf, xb) < 2e-5 and rel(vf, vb) < 5e-4
+    st = fast.solver.stats()
+    assert st.get("reserved", 0) == 0
+    if rebin_interval < 0:
+        assert st["rebins"] == 1 and st["n_fallback_particles"] > 1000
