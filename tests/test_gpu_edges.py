@@ -205,3 +205,25 @@ def test_particles_shuffling_between_cells(rebin_interval, oracle_lib):
     assert st.get("reserved", 0) == 0
     if rebin_interval < 0:
         assert st["rebins"] == 1 and st["n_fallback_particles"] > 1000
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("n_grid", [30, 34, 45])
+def test_grid_size_not_a_multiple_of_the_block(mode, n_grid, oracle_lib):
+    """run_demo.py uses a 250^3 grid: the 4x4x4-node blocks of the fast back end overhang the grid there.  Small
+    versions with material pressed into the far corner, where the overhanging blocks are."""
+    dx = 2.0 / n_grid
+    rng = np.random.default_rng(3)
+    hi = 2.0 - 2.2 * dx
+    pts = (hi - rng.uniform(0, 5 * dx, (600, 3))).astype(np.float32)
+    vel = np.tile([1.5, 1.0, 2.0], (600, 1)).astype(np.float32)
+    sc = _trad_scene("corner", pts, (dx / 2) ** 3, n_grid, v=vel, E=50.0, bcs=[("bounding_box", {})], n_steps=60)
+    o, sim = _pair(sc, 60, mode)
+    x = sim.state.particle_x.cpu().numpy()
+    assert np.isfinite(x).all() and x.max() <= 2.0 - 2 * dx + 1e-6
+    assert rel(x, o.x) < 1e-5
+    assert rel(sim.state.particle_v.cpu().numpy(), o.v) < 2e-4
+    sc2 = scenes.sheet(n=20, n_grid=n_grid, collider_subdiv=2, n_steps=40, span=(0.7, 1.3), y=1.2, sphere_r=0.18,
+                       sphere_c=(1.0, 0.99, 1.0), name=f"sheet-{n_grid}")
+    o2, sim2 = _pair(sc2, 40, mode)
+    assert rel(sim2.state.particle_x.cpu().numpy(), o2.x) < 1e-4
