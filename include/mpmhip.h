@@ -238,6 +238,22 @@ int mpmhip_rccl_set_ghosts(mpmhip_ctx *ctx, int32_t n_peers, const int32_t *peer
 int mpmhip_rccl_steps(mpmhip_ctx *ctx, float dt, int32_t n, int64_t step_index, int32_t rebin_interval,
                       const float *mesh_x, const float *mesh_v, const float *joint_verts_v, const float *joint_faces_v);
 
+/* ---- after the solver: per-face frames and bound Gaussians --------------------------------
+ * Stand-alone maps on [dev] arrays (no solver context; `stream` is a hipStream_t, NULL = default stream).
+ * mpmhip_face_frames = MeshGaussianModel.set_mesh_by_verts (scene/mesh_gaussian_model.py:137-146) with
+ * compute_face_orientation(return_scale=True) (utils/graphics_utils.py:88-106):
+ *   face_center [n_f*3] = mean of the three vertices, face_orien_mat [n_f*9] row-major with columns a0 a1 a2,
+ *   face_orien_quat [n_f*4] WXYZ = quat_xyzw_to_wxyz(rotmat_to_unitquat(mat)) (roma), face_scaling [n_f]. */
+int mpmhip_face_frames(int32_t device, void *stream, const float *verts, const int32_t *faces, int32_t n_faces,
+                       float *face_center, float *face_orien_mat, float *face_orien_quat, float *face_scaling);
+/* GaussianModel.get_xyz / get_rotation / get_scaling with a face binding (scene/gaussian_model.py:112-151):
+ *   xyz [n_g*3] = mat[b] xyz_local * scaling[b] + center[b];  rotation [n_g*4] WXYZ = normalize(quat[b]) (x)
+ *   normalize(rotation_raw);  scaling [n_g*3] = exp(scaling_raw) * face_scaling[b].  Any output may be NULL. */
+int mpmhip_bind_gaussians(int32_t device, void *stream, int32_t n_gaussians, const int32_t *binding, const float *xyz_local,
+                          const float *rotation_raw, const float *scaling_raw, const float *face_center,
+                          const float *face_orien_mat, const float *face_orien_quat, const float *face_scaling, float *xyz,
+                          float *rotation, float *scaling);
+
 /* ---- introspection ---------------------------------------------------------------------- */
 /* dense reference-layout copies of grid_m [G^3], grid_v_in [G^3*3], grid_v_out [G^3*3] as they
  * stand after the last substep's grid stage ([dev] outputs, any may be NULL).  Synchronous. */
