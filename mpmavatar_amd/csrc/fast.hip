@@ -202,23 +202,46 @@ __global__ void k_export(mpmhip_state_ptrs st, mpmhip_model_ptrs md, Bufs b, VAd
 // ------------------------------------------------------------------------------------------------
 // rebin: keys, permutation, block tables
 // ------------------------------------------------------------------------------------------------
-// key = class | state | block | cell-in-block ; the low 6 bits order particles of a block by cell.
-// state: 0 = simulated, 1 = ghost copy that gathers for itself (multi-GPU: g2p yes, p2g no), 2 = not transferred
-__device__ __forceinline__ unsigned make_key(V3 x, int cls, int state, const Dims &d, int blk_bits) {
-  int bx = (int)(x.x * d.inv_dx - 0.5f), by = (int)(x.y * d.inv_dx - 0.5f), bz = (int)(x.z * d.inv_dx - 0.5f);
+// key = class | state | block | cell ; `kf` packs the field widths (blk_bits | cell_bits << 8).
+// state: 0 = simulated, 1 = ghost copy that gathers for itself (multi-GPU: g2p yes, p2g no), 2 = not transferred.
+// PREDICTIVE SORT (cell_bits == 8): the block is the one the particle is expected to be in half a re-sort interval
+// from now (x + lead * v, the shift clamped to one cell per axis), so that a coherently moving particle starts in the
+// margin on one side of its block's tile and ends in the margin on the other: twice the travel before a re-sort is
+// due.  The low bits then order by the CURRENT cell relative to that block's tile (6x6x6 positions), which is what
+// the DPP pre-reduction of p2g wants to see in neighbouring lanes.  cell_bits == 6 (very large grids whose keys would
+// not fit 32 bits otherwise): no prediction, cell = position inside the block.
+__device__ __forceinline__ int kf_blk(int kf) { return kf & 255; }
+__device__ __forceinline__ int kf_cell(int kf) { return kf >> 8; }
+__device__ __forceinline__ unsigned make_key(V3 x, V3 v, float lead, int cls, int state, const Dims &d, int kf) {
+  int bb = kf_blk(kf), cb = kf_cell(kf);
+  int cx = (int)(x.x * d.inv_dx - 0.5f), cy = (int)(x.y * d.inv_dx - 0.5f), cz = (int)(x.z * d.inv_dx - 0.5f);
+  int bx = cx, by = cy, bz = cz;
+  if (cb == 8) {
+    float lim = d.dx;  // at most one cell: the current cell must stay inside the predicted block's tile margin
+    V3 xp = v3(x.x + fminf(fmaxf(lead * v.x, -lim), lim), x.y + fminf(fmaxf(lead * v.y, -lim), lim),
+               x.z + fminf(fmaxf(lead * v.z, -lim), lim));
+    int px = (int)(xp.x * d.inv_dx - 0.5f), py = (int)(xp.y * d.inv_dx - 0.5f), pz = (int)(xp.z * d.inv_dx - 0.5f);
+    bx = min(max(px, cx - 1), cx + 1); by = min(max(py, cy - 1), cy + 1); bz = min(max(pz, cz - 1), cz + 1);
+  }
   bx = min(max(bx, 0), d.G - 3); by = min(max(by, 0), d.G - 3); bz = min(max(bz, 0), d.G - 3);
   unsigned blk = (unsigned)blk_of(bx, by, bz, d.NB);
-  unsigned cell = (unsigned)loc_of(bx, by, bz);
-  return ((unsigned)cls << (blk_bits + 8)) | ((unsigned)state << (blk_bits + 6)) | (blk << 6) | cell;
+  unsigned cell;
+  if (cb == 8) {  // current cell in the predicted block's tile: 0..5 per axis when inside the margin (clamped otherwise)
+    int lx = min(max(cx - (4 * (bx >> 2) - 1), 0), 5), ly = min(max(cy - (4 * (by >> 2) - 1), 0), 5), lz = min(max(cz - (4 * (bz >> 2) - 1), 0), 5);
+    cell = (unsigned)((lx * 6 + ly) * 6 + lz);
+  } else {
+    cell = (unsigned)loc_of(bx, by, bz);
+  }
+  return ((unsigned)cls << (bb + cb + 2)) | ((unsigned)state << (bb + cb)) | (blk << cb) | cell;
 }
 
-__global__ void k_keys(Bufs b, Dims d, int blk_bits, int ghost_g2p, unsigned *keys, int *iota) {
+__global__ void k_keys(Bufs b, Dims d, int kf, float lead, int ghost_g2p, unsigned *keys, int *iota) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= d.n_p) return;
   int cls = s < d.n_e ? 0 : (s < d.n_nv ? 1 : 2);
-  V3 x = ld3(b.all, A_X, s);
+  V3 x = ld3(b.all, A_X, s), v = ld3(b.all, A_V, s);
   int sel = b.sel[s];
-  keys[s] = make_key(x, cls, sel == 0 ? 0 : ((sel == 2 && ghost_g2p && cls != 1) ? 1 : 2), d, blk_bits);
+  keys[s] = make_key(x, v, lead, cls, sel == 0 ? 0 : ((sel == 2 && ghost_g2p && cls != 1) ? 1 : 2), d, kf);
   iota[s] = s;
 }
 
@@ -249,8 +272,9 @@ __global__ void k_face_slots(Bufs b, const int *inv, int *face_slot, Dims d) {
   for (int c = 0; c < 3; ++c) face_slot[c * d.n_e + e] = inv[d.n_nv + b.face_orig[c * d.n_e + e]] - d.n_nv;
 }
 
-__device__ __forceinline__ int key_block(unsigned k, int blk_bits) { return (int)((k >> 6) & ((1u << blk_bits) - 1u)); }
-__device__ __forceinline__ int key_state(unsigned k, int blk_bits) { return (int)((k >> (blk_bits + 6)) & 3u); }
+// (the parameter named blk_bits below is the packed key format kf)
+__device__ __forceinline__ int key_block(unsigned k, int kf) { return (int)((k >> kf_cell(kf)) & ((1u << kf_blk(kf)) - 1u)); }
+__device__ __forceinline__ int key_state(unsigned k, int kf) { return (int)((k >> (kf_blk(kf) + kf_cell(kf))) & 3u); }
 __device__ __forceinline__ bool key_inactive(unsigned k, int blk_bits) { return key_state(k, blk_bits) >= 2; }
 
 __global__ void k_mark_blocks(const unsigned *keys, int n, int blk_bits, int *pb_flag) {
@@ -275,8 +299,9 @@ __global__ void k_ranges(const unsigned *keys, Dims d, int blk_bits, const int *
   int c0 = cls == 0 ? 0 : (cls == 1 ? d.n_e : d.n_nv), c1 = cls == 0 ? d.n_e : (cls == 1 ? d.n_nv : d.n_p);
   int slot = pb_index[key_block(k, blk_bits)];
   int row = key_state(k, blk_bits) == 0 ? cls * 2 : (cls == 0 ? 6 : 8);  // ghosts: elements, vertices only
-  if (s == c0 || (keys[s - 1] >> 6) != (k >> 6)) ranges[(row + 0) * n_P + slot] = s;
-  if (s == c1 - 1 || (keys[s + 1] >> 6) != (k >> 6)) ranges[(row + 1) * n_P + slot] = s + 1;
+  int cb = kf_cell(blk_bits);
+  if (s == c0 || (keys[s - 1] >> cb) != (k >> cb)) ranges[(row + 0) * n_P + slot] = s;
+  if (s == c1 - 1 || (keys[s + 1] >> cb) != (k >> cb)) ranges[(row + 1) * n_P + slot] = s + 1;
 }
 
 __global__ void k_dilate(const int *plist, int n_P, int NB, int *ab_flag) {
@@ -448,6 +473,7 @@ __global__ void k_stress_elem(Bufs b, F3 *ef, Dims d, float friction_coeff, cons
     {  // drift check against the block this element was sorted into
       int blk = key_block(skeys[e], blk_bits);
       int oz = 4 * (blk % d.NB) - 1, oy = 4 * ((blk / d.NB) % d.NB) - 1, ox = 4 * (blk / (d.NB * d.NB)) - 1;
+      // (no look-ahead here: an element follows its three vertices, whose g2p raises the flag early, see g2p_write)
       int nbx = (int)(xe.x * d.inv_dx - 0.5f) - ox, nby = (int)(xe.y * d.inv_dx - 0.5f) - oy, nbz = (int)(xe.z * d.inv_dx - 0.5f) - oz;
       if (b.sel[e] == 0 && ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u)) counters[6] = 1;
     }
@@ -749,6 +775,7 @@ __device__ __forceinline__ P2GParticle p2g_zero(int ox, int oy, int oz, const Di
 // when the wavefront holds any element or traditional particle, the first ADJ_BATCH adjacency entries when it holds
 // any vertex (wave-uniform branches; lanes of the other class read slot 0 and are masked afterwards).  The
 // per-class `if` ladder this replaces serialised stress -> adjacency -> corner-force latencies.
+constexpr float DRIFT_LOOKAHEAD = 20.0f;  // substeps
 struct P2GRaw {
   V3 x, v;
   float mass, vol;
@@ -1095,6 +1122,14 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *re
   P2GRaw raw = p2g_issue<TRAD>(b, va, valid, cls, s, d, w_nv, w_v);
   for (int t = threadIdx.x; t < 4 * TILE_PAD; t += TPB) tile[t] = 0.0;
   if (threadIdx.x == 0) esc_n = 0;
+  if (valid) {  // early warning for the adaptive re-sort: will this particle still fit the tile DRIFT_LOOKAHEAD substeps
+                // from now (the host reads the flag with a lag of up to 16 substeps)?  The out-of-margin paths work
+                // but cost ~100 scattered global atomics per particle and substep.
+    float la = DRIFT_LOOKAHEAD * dt;
+    int fx = (int)((raw.x.x + la * raw.v.x) * d.inv_dx - 0.5f) - ox, fy = (int)((raw.x.y + la * raw.v.y) * d.inv_dx - 0.5f) - oy,
+        fz = (int)((raw.x.z + la * raw.v.z) * d.inv_dx - 0.5f) - oz;
+    if ((unsigned)fx > 5u || (unsigned)fy > 5u || (unsigned)fz > 5u) g.counters[6] = 1;
+  }
   P2GParticle q = p2g_finish<TRAD>(raw, b, va, valid, cls, s, d, rpic, dt, w_v, p2g_zero(ox, oy, oz, d), tp);
   __syncthreads();
   p2g_scatter<STEPS>(tile, esc, &esc_n, q, valid, ox, oy, oz, d, g);
@@ -1250,7 +1285,9 @@ __device__ __forceinline__ void g2p_write(const Bufs &b, int cls, int s, V3 x, V
   V3 nx = x + dt * r.v;
   nx = v3(fminf(fmaxf(nx.x, a_min), a_max), fminf(fmaxf(nx.y, a_min), a_max), fminf(fmaxf(nx.z, a_min), a_max));
   st3(b.all, A_X, s, nx);
-  {  // will this particle still fit its block's tile at the next p2g?  If not, ask the host for a re-sort.
+  {  // already outside the tile margin of its block?  Ask the host for a re-sort.  (The early warning -- will it still
+     // fit DRIFT_LOOKAHEAD substeps from now -- is raised by the next p2g, where x and v are in registers anyway; here
+     // it cost hipcc 18-50 more VGPRs and an occupancy step.)
     int nbx = (int)(nx.x * d.inv_dx - 0.5f) - ox, nby = (int)(nx.y * d.inv_dx - 0.5f) - oy, nbz = (int)(nx.z * d.inv_dx - 0.5f) - oz;
     if ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u) g.counters[6] = 1;
   }
@@ -1595,7 +1632,11 @@ struct FastState {
   bool dist_keep_cur = false;  // re-sort inside mpmhip_rccl_steps: the caller's mesh pointers are valid
   std::vector<DistPeer> peers;
   StepArgs dist_args{};
-  int blk_bits = 0, key_bits = 0;
+  int blk_bits = 0, key_bits = 0;  // blk_bits: packed key format kf (field widths) as the kernels take it
+  int blk_bits_plain = 0;          // bits of a block id (face-bin sort)
+  float lead_steps = 12.0f;        // predictive sort: look this many substeps ahead (half the expected re-sort interval)
+  float last_dt = 0.0f;
+  int true_since_rebin = 0;        // substeps since the last re-sort (steps_since_rebin is overwritten to force one)
   size_t nblocks = 0;
   Bufs buf[2]{};
   int cur = 0;
@@ -1781,7 +1822,8 @@ int rebin(mpmhip_ctx *c) {
   flush_grid(c);
   if (d.n_p == 0) { f->n_P = f->n_A = f->n_chunks = f->n_chunks_g = 0; f->steps_since_rebin = 0; return MPMHIP_OK; }
   flush_elements(c);
-  hipLaunchKernelGGL(k_keys, nblk(d.n_p), TPB, 0, s, f->buf[cur], d, f->blk_bits, f->ghost_g2p ? 1 : 0, f->keys[0], f->iota);
+  hipLaunchKernelGGL(k_keys, nblk(d.n_p), TPB, 0, s, f->buf[cur], d, f->blk_bits, f->lead_steps * f->last_dt,
+                     f->ghost_g2p ? 1 : 0, f->keys[0], f->iota);
   size_t need = 0;
   MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(nullptr, need, f->keys[0], f->keys[1], f->iota, f->order, (size_t)d.n_p, 0u,
                                              (unsigned)f->key_bits, s));
@@ -1854,14 +1896,14 @@ int rebin(mpmhip_ctx *c) {
     hipLaunchKernelGGL(k_face_keys, nblk(nf), TPB, 0, s, c->cur_pts, c->cur_vel, c->cur_f, c->mesh_idx, nf, d, f->fkeys[0], f->fiota);
     size_t need2 = 0;
     MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(nullptr, need2, f->fkeys[0], f->fkeys[1], f->fiota, f->forder, (size_t)nf, 0u,
-                                               (unsigned)f->blk_bits, s));
+                                               (unsigned)f->blk_bits_plain, s));
     if (need2 > f->sort_tmp_bytes) {
       MPM_HIP_CHECK(c, hipMalloc(&f->sort_tmp, need2));
       f->allocs.push_back(f->sort_tmp);
       f->sort_tmp_bytes = need2;
     }
     MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(f->sort_tmp, need2, f->fkeys[0], f->fkeys[1], f->fiota, f->forder, (size_t)nf,
-                                               0u, (unsigned)f->blk_bits, s));
+                                               0u, (unsigned)f->blk_bits_plain, s));
     MPM_HIP_CHECK(c, hipMemsetAsync(f->fb_cnt, 0, f->nblocks * sizeof(int), s));
     hipLaunchKernelGGL(k_face_bins, nblk(nf), TPB, 0, s, f->fkeys[1], nf, f->fb_start, f->fb_cnt);
     if (std::min(nf, f->n_A) > f->cap_fbins) {
@@ -1899,10 +1941,13 @@ int fast_init(mpmhip_ctx *c) {
   d.G = cfg.n_grid; d.NB = (cfg.n_grid + 3) / 4;
   d.dx = c->dx; d.inv_dx = c->inv_dx; d.grid_lim = cfg.grid_lim;
   f->nblocks = (size_t)d.NB * d.NB * d.NB;
-  f->blk_bits = 1;
-  while ((1ull << f->blk_bits) < f->nblocks) ++f->blk_bits;
-  f->key_bits = f->blk_bits + 6 + 2 + 2;
+  f->blk_bits_plain = 1;
+  while ((1ull << f->blk_bits_plain) < f->nblocks) ++f->blk_bits_plain;
+  int cell_bits = f->blk_bits_plain + 8 + 2 + 2 <= 32 ? 8 : 6;  // 8: predictive sort (see make_key)
+  if (const char *e = getenv("MPMHIP_PREDICTIVE_SORT")) if (atoi(e) == 0) cell_bits = 6;
+  f->key_bits = f->blk_bits_plain + cell_bits + 2 + 2;
   if (f->key_bits > 32) return fail(c, MPMHIP_ERR_INVALID, "grid too large for 32-bit sort keys");
+  f->blk_bits = f->blk_bits_plain | (cell_bits << 8);
   // upper bound between re-sorts; the drift flag normally triggers one earlier (or never, for slow scenes)
   f->rebin_interval = cfg.rebin_interval > 0 ? cfg.rebin_interval : (cfg.rebin_interval < 0 ? -cfg.rebin_interval : 256);
   f->adaptive_rebin = cfg.rebin_interval >= 0;
@@ -2038,9 +2083,15 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     }
     if (f->steps_since_rebin >= f->rebin_interval) {
       ScopedPhase ph(c, "rebin");
+      // predictive sort: aim at the middle of the next interval, estimated from the one that just ended
+      if (f->true_since_rebin > 0) f->lead_steps = std::min(std::max(0.5f * (float)f->true_since_rebin, 4.0f), 48.0f);
+      f->last_dt = dt;
       if ((rc = rebin(c))) return rc;
+      f->true_since_rebin = 0;
     }
   }
+  f->last_dt = dt;
+  f->true_since_rebin += 1;
   Bufs &b = f->buf[f->cur];
   // The body-face and joint splats ride along in the p2g launch as extra workgroups (SplatArgs).  With profiling on
   // (one sync per phase, like the reference's ScopedTimer) they get a launch of their own under the reference's
