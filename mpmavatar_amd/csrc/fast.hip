@@ -38,7 +38,9 @@ namespace mpm {
 namespace {
 
 constexpr int TPB = 256;
-constexpr int CHUNK = 256;     // particles per class handled by one workgroup of p2g / g2p
+constexpr int CHUNK = 256;     // particles of one block handled by one workgroup of p2g / g2p (192 measured: no gain on
+                               // the sheet, 8-10 % slower on the dense scenes)
+constexpr int PT = CHUNK;      // threads of those workgroups (and of the extra workgroups riding in their launches)
 constexpr int TILE = 8;        // tile edge in nodes: block (4) + 1 below + 3 above
 constexpr int TILE3 = TILE * TILE * TILE;
 inline unsigned nblk(size_t n) { return n ? (unsigned)((n + TPB - 1) / TPB) : 1u; }  // never an empty grid: kernels bound-check
@@ -425,7 +427,7 @@ struct ZeroArgs {
   int *m_flag, *col_flag;
 };
 __device__ __forceinline__ void zero_blocks_wg(const ZeroArgs &z, int wg) {
-  int a = wg * 4 + (int)(threadIdx.x >> 6), l = threadIdx.x & 63;
+  int a = wg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6), l = threadIdx.x & 63;  // one block per wavefront
   if (a >= z.n_A) return;
   int blk = z.alist[a];
   if (z.m_flag[blk]) {  // wave-uniform
@@ -626,7 +628,7 @@ struct JointSplatArgs {
 __device__ __forceinline__ void mover_splat_wg(const Bufs &b, const JointSplatArgs &js, int wg, const Dims &d,
                                                const GridPtrs &g) {
   const int *inv = js.inv;
-  int t = wg * TPB + (int)threadIdx.x;
+  int t = wg * PT + (int)threadIdx.x;
   int q = (t >> 5) + (js.t_in_tile ? js.n_t : 0), nn = t & 31;
   if (nn >= 27 || q >= js.n_t + js.n_v + js.n_f) return;
   const float *vel;
@@ -672,9 +674,9 @@ __device__ __forceinline__ void col_splat_pass(double *tile, const FaceBin &fb, 
                                                const GridPtrs &g) {
   constexpr int NCH = PASS == 0 ? 4 : 3;
   const int l = threadIdx.x;
-  for (int t = l; t < NCH * TILE_PAD; t += TPB) tile[t] = 0.0;
+  for (int t = l; t < NCH * TILE_PAD; t += PT) tile[t] = 0.0;
   __syncthreads();
-  for (int jj = fb.start + l; jj < fb.start + fb.cnt; jj += TPB) {
+  for (int jj = fb.start + l; jj < fb.start + fb.cnt; jj += PT) {
     int i0 = sa.fidx[3 * jj], i1 = sa.fidx[3 * jj + 1], i2 = sa.fidx[3 * jj + 2];
     V3 p0 = mesh_point(sa.pts, sa.vel, sa.adv, i0), p1 = mesh_point(sa.pts, sa.vel, sa.adv, i1), p2 = mesh_point(sa.pts, sa.vel, sa.adv, i2);
     V3 fp = v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
@@ -719,7 +721,7 @@ __device__ __forceinline__ void col_splat_pass(double *tile, const FaceBin &fb, 
     }
   }
   __syncthreads();
-  for (int t = l; t < TILE3; t += TPB) {
+  for (int t = l; t < TILE3; t += PT) {
     int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
     const double *q = tile + tile_idx(ti, tj, tk);
     float c0 = (float)q[0], c1 = (float)q[TILE_PAD], c2 = (float)q[2 * TILE_PAD];
@@ -1055,7 +1057,7 @@ __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p
 // cleared for the next chunk of a persistent workgroup.
 template <bool REZERO, bool TO_MOV = false>
 __device__ __forceinline__ void p2g_flush(double *tile, int ox, int oy, int oz, const Dims &d, const GridPtrs &g) {
-  for (int t = threadIdx.x; t < TILE3; t += TPB) {
+  for (int t = threadIdx.x; t < TILE3; t += PT) {
     int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
     double *qd = tile + tile_idx(ti, tj, tk);
     float m = (float)qd[0], px = (float)qd[TILE_PAD], py = (float)qd[2 * TILE_PAD], pz = (float)qd[3 * TILE_PAD];
@@ -1092,7 +1094,7 @@ __device__ __forceinline__ void mover_escaped(V3 x, V3 pv, const Dims &d, const 
 // frames); their joint splat (weight, weight * joint velocity into the mover channels, mpm_solver.py:677-704) is a
 // second pass through the same LDS tile by the chunk that owns them instead of 27 x 4 scattered global atomics each.
 template <int STEPS, bool TRAD, bool JT>
-__global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *recs, int n_chunks, Dims d, float rpic,
+__global__ __launch_bounds__(PT) void k_p2g(Bufs b, VAdj va, const ChunkRec *recs, int n_chunks, Dims d, float rpic,
                                              float dt, GridPtrs g, SplatArgs sa, TradParams tp) {
   __shared__ double tile[4 * TILE_PAD];
   __shared__ int esc[CHUNK];
@@ -1120,7 +1122,7 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *re
   if (g.dbg & 8) w_v = false;
   if (g.dbg & 16) w_nv = false;
   P2GRaw raw = p2g_issue<TRAD>(b, va, valid, cls, s, d, w_nv, w_v);
-  for (int t = threadIdx.x; t < 4 * TILE_PAD; t += TPB) tile[t] = 0.0;
+  for (int t = threadIdx.x; t < 4 * TILE_PAD; t += PT) tile[t] = 0.0;
   if (threadIdx.x == 0) esc_n = 0;
   if (valid) {  // early warning for the adaptive re-sort: will this particle still fit the tile DRIFT_LOOKAHEAD substeps
                 // from now (the host reads the flag with a lag of up to 16 substeps)?  The out-of-margin paths work
@@ -1135,7 +1137,7 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *re
   p2g_scatter<STEPS>(tile, esc, &esc_n, q, valid, ox, oy, oz, d, g);
   __syncthreads();
   if (esc_n > 0) {
-    for (int e = threadIdx.x; e < esc_n; e += TPB) {
+    for (int e = threadIdx.x; e < esc_n; e += PT) {
       int ec = 0, es = 0;
       if (cm.map(chunk * CHUNK + esc[e], ec, es)) p2g_escaped<TRAD>(b, va, ec, es, d, rpic, dt, g, tp);
     }
@@ -1166,7 +1168,7 @@ __global__ __launch_bounds__(TPB) void k_p2g(Bufs b, VAdj va, const ChunkRec *re
       __syncthreads();
       p2g_scatter<STEPS>(tile, esc, &esc_n, q2, held, ox, oy, oz, d, g);
       __syncthreads();
-      for (int e = threadIdx.x; e < esc_n; e += TPB) {
+      for (int e = threadIdx.x; e < esc_n; e += PT) {
         int ec = 0, es = 0;
         if (!cm.map(chunk * CHUNK + esc[e], ec, es)) continue;
         int o = sa.js.perm[es] - sa.js.off_t;
@@ -1299,7 +1301,7 @@ __device__ __forceinline__ void g2p_write(const Bufs &b, int cls, int s, V3 x, V
 // tiles are evaluated once per tile (about 2x redundant arithmetic, ~50 VALU instructions per node) in exchange for
 // one launch, one v_out round trip through HBM and one grid-wide dependency less per substep.
 template <bool FUSED>
-__global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const ChunkRec *recs, int n_chunks, Dims d, float dt, GridPtrs g,
+__global__ __launch_bounds__(PT) void k_g2p(Bufs b, const ChunkRec *recs, int n_chunks, Dims d, float dt, GridPtrs g,
                                              GridParams gp, BCList bcl) {
   __shared__ float tile[3 * TILE_PAD];
   int w = xcd_slice(blockIdx.x, n_chunks);
@@ -1338,7 +1340,7 @@ __global__ __launch_bounds__(TPB) void k_g2p(Bufs b, const ChunkRec *recs, int n
       if (bc_may_touch(bcl.bc[k], ox, oy, oz, ox + 7, oy + 7, oz + 7, d.G, d.dx, gp.time, gp.dt)) bc_mask |= 1u << k;
   }
 #pragma unroll
-  for (int t = threadIdx.x; t < TILE3; t += TPB) {
+  for (int t = threadIdx.x; t < TILE3; t += PT) {
     int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
     int gx = ox + ti, gy = oy + tj, gz = oz + tk;
     V3 v = v3(0, 0, 0);
@@ -1790,7 +1792,7 @@ int do_import(mpmhip_ctx *c) {
 // what has to be cleared after the last fused substep (the buffer g points at), marking it clean
 static ZeroArgs take_zero(FastState *f) {
   ZeroArgs z{f->alist, f->n_A, 0, f->dirty_col, f->dirty_mov, f->g.mv, f->g.col, f->g.mov, f->g.m_flag, f->g.col_flag};
-  if (f->grid_dirty && f->n_A) z.n_wg = (f->n_A + 3) / 4;
+  if (f->grid_dirty && f->n_A) z.n_wg = (f->n_A + PT / 64 - 1) / (PT / 64);
   f->grid_dirty = false;
   return z;
 }
@@ -1803,7 +1805,7 @@ static void select_buffer(FastState *f, int par) {
 static void flush_grid(mpmhip_ctx *c) {
   FastState *f = c->fast;
   ZeroArgs z = take_zero(f);
-  if (z.n_wg) hipLaunchKernelGGL(k_zero_blocks, (unsigned)z.n_wg, TPB, 0, c->stream, z);
+  if (z.n_wg) hipLaunchKernelGGL(k_zero_blocks, (unsigned)z.n_wg, PT, 0, c->stream, z);
 }
 // v_out of the last (fused) substep for export_grid / stats; the accumulators stay as they are
 static void materialize_grid(mpmhip_ctx *c, bool count) {
@@ -2126,7 +2128,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     jt_tile = trad_fused && sa.js.n_t >= 2048;
     sa.js.t_in_tile = jt_tile ? 1 : 0;
     int nj = (jt_tile ? 0 : sa.js.n_t) + sa.js.n_v + sa.js.n_f;
-    sa.n_mov_wg = (int)nblk((size_t)nj * 32);
+    sa.n_mov_wg = (int)(((size_t)nj * 32 + PT - 1) / PT);
     if (nj == 0) sa.n_mov_wg = 0;
   }
   // accumulators left loaded by the previous (fused) substep: this substep scatters into the other buffer and clears
@@ -2134,7 +2136,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   sa.z = take_zero(f);
   if (sa.z.n_wg) {
     if (c->profiling) {  // profiling runs keep one launch per reference phase: clear now
-      hipLaunchKernelGGL(k_zero_blocks, (unsigned)sa.z.n_wg, TPB, 0, s, sa.z);
+      hipLaunchKernelGGL(k_zero_blocks, (unsigned)sa.z.n_wg, PT, 0, s, sa.z);
       sa.z.n_wg = 0;
     } else {
       select_buffer(f, f->par ^ 1);
@@ -2159,7 +2161,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     {
       ScopedPhase ph(c, "p2g");
       if (f->n_chunks)
-        P2G_LAUNCH(false, false, xcd_grid(f->n_chunks), TPB, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
+        P2G_LAUNCH(false, false, xcd_grid(f->n_chunks), PT, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
                    c->sc.rpic_damping, dt, f->g, none, tp);
     }
     if (sa.n_fbins) {
@@ -2168,7 +2170,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       only.n_mov_wg = 0;
       only.n_extra = (only.n_fbins + 7) & ~7;
       only.z_first = 1 << 30;
-      P2G_LAUNCH(false, false, (unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only, tp);
+      P2G_LAUNCH(false, false, (unsigned)only.n_extra, PT, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only, tp);
     }
     if (sa.n_mov_wg) {
       ScopedPhase ph(c, "apply_Particle_Moving_on_grid");
@@ -2176,12 +2178,12 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       only.n_fbins = 0;
       only.n_extra = (only.n_mov_wg + 7) & ~7;
       only.z_first = 1 << 30;
-      P2G_LAUNCH(false, false, (unsigned)only.n_extra, TPB, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only, tp);
+      P2G_LAUNCH(false, false, (unsigned)only.n_extra, PT, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only, tp);
     }
   } else {
     ScopedPhase ph(c, "p2g");
     if (f->n_chunks || sa.n_extra || sa.z.n_wg)
-      P2G_LAUNCH(trad_fused, jt_tile, xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg), TPB, 0, s, b, f->va(), f->chunks,
+      P2G_LAUNCH(trad_fused, jt_tile, xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg), PT, 0, s, b, f->va(), f->chunks,
                  f->n_chunks, d, c->sc.rpic_damping, dt, f->g, sa, tp);
   }
   return MPMHIP_OK;
@@ -2215,9 +2217,9 @@ static int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
     ScopedPhase ph(c, "g2p_v");
     if (f->n_chunks_g) {
       if (fused)
-        hipLaunchKernelGGL(k_g2p<true>, xcd_grid(f->n_chunks_g), TPB, 0, s, b, f->chunks_g, f->n_chunks_g, d, dt, f->g, gp, bcl);
+        hipLaunchKernelGGL(k_g2p<true>, xcd_grid(f->n_chunks_g), PT, 0, s, b, f->chunks_g, f->n_chunks_g, d, dt, f->g, gp, bcl);
       else
-        hipLaunchKernelGGL(k_g2p<false>, xcd_grid(f->n_chunks_g), TPB, 0, s, b, f->chunks_g, f->n_chunks_g, d, dt, f->g, gp, bcl);
+        hipLaunchKernelGGL(k_g2p<false>, xcd_grid(f->n_chunks_g), PT, 0, s, b, f->chunks_g, f->n_chunks_g, d, dt, f->g, gp, bcl);
     }
   }
   if (fused) {
