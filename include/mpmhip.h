@@ -101,7 +101,9 @@ typedef struct {
   int32_t n_collider_nodes;
   int32_t n_mover_nodes;
   int32_t n_fallback_particles; /* particles that left their tile margin since the last re-sort */
-  int32_t reserved;
+  int32_t n_dropped;            /* fast mode: scatter contributions that fell outside the active blocks (cumulative).
+                                   Must stay 0: non-zero means particles outran the re-sorts (fixed-interval mode
+                                   with an interval too long for their speed) and the results are not valid */
 } mpmhip_stats;
 
 /* ---- lifetime ----------------------------------------------------------------- */

@@ -1139,7 +1139,9 @@ __global__ __launch_bounds__(PT) void k_p2g(Bufs b, VAdj va, const ChunkRec *rec
   if (esc_n > 0) {
     for (int e = threadIdx.x; e < esc_n; e += PT) {
       int ec = 0, es = 0;
-      if (cm.map(chunk * CHUNK + esc[e], ec, es)) p2g_escaped<TRAD>(b, va, ec, es, d, rpic, dt, g, tp);
+      // <false>: the fused stress update of this particle already ran (p2g_finish above) and stored its stress; running
+      // it again would harden / soften the material twice
+      if (cm.map(chunk * CHUNK + esc[e], ec, es)) p2g_escaped<false>(b, va, ec, es, d, rpic, dt, g, tp);
     }
   }
   p2g_flush<JT>(tile, ox, oy, oz, d, g);
@@ -1638,6 +1640,7 @@ struct FastState {
   int blk_bits_plain = 0;          // bits of a block id (face-bin sort)
   float lead_steps = 12.0f;        // predictive sort: look this many substeps ahead (half the expected re-sort interval)
   float last_dt = 0.0f;
+  int poll_mask = 7;               // the drift flag is read back every poll_mask + 1 substeps (host lag <= twice that)
   int true_since_rebin = 0;        // substeps since the last re-sort (steps_since_rebin is overwritten to force one)
   size_t nblocks = 0;
   Bufs buf[2]{};
@@ -2087,7 +2090,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     // the next copy is issued the host waits for the previous one, which also bounds how far the host may run
     // ahead of the GPU (<= 16 substeps) -- otherwise a fused mpmhip_steps(n) would have enqueued all n substeps
     // long before the first flag arrives.
-    if (f->flag_pending && (f->steps_since_rebin & 7) == 0) {
+    if (f->flag_pending && (f->steps_since_rebin & f->poll_mask) == 0) {
       MPM_HIP_CHECK(c, hipEventSynchronize(f->ev_flag));
       f->flag_pending = false;
       if (f->h_pin[24] && f->adaptive_rebin) f->steps_since_rebin = 1 << 30;
@@ -2095,7 +2098,12 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     if (f->steps_since_rebin >= f->rebin_interval) {
       ScopedPhase ph(c, "rebin");
       // predictive sort: aim at the middle of the next interval, estimated from the one that just ended
-      if (f->true_since_rebin > 0) f->lead_steps = std::min(std::max(0.5f * (float)f->true_since_rebin, 4.0f), 48.0f);
+      if (f->true_since_rebin > 0) {
+        f->lead_steps = std::min(std::max(0.5f * (float)f->true_since_rebin, 4.0f), 48.0f);
+        // fast material (short intervals): look at the flag more often, so that the host's lag stays well inside the
+        // 20-substep early warning and nothing outruns the active blocks
+        f->poll_mask = f->true_since_rebin <= 24 ? 1 : (f->true_since_rebin <= 48 ? 3 : 7);
+      }
       f->last_dt = dt;
       if ((rc = rebin(c))) return rc;
       f->true_since_rebin = 0;
@@ -2247,7 +2255,7 @@ static int step_phase_c(mpmhip_ctx *c, const StepArgs &a) {
     if (c->profiling) flush_elements(c);
   }
   f->steps_since_rebin += 1;
-  if (!f->dist && !f->flag_pending && (f->steps_since_rebin & 7) == 0) {
+  if (!f->dist && !f->flag_pending && (f->steps_since_rebin & f->poll_mask) == 0) {
     MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 24, f->g.counters + 6, sizeof(int), hipMemcpyDeviceToHost, s));
     MPM_HIP_CHECK(c, hipEventRecord(f->ev_flag, s));
     f->flag_pending = true;
@@ -2557,7 +2565,7 @@ int fast_stats(mpmhip_ctx *c, mpmhip_stats *out) {
   MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 8, f->g.counters, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
   out->n_fallback_particles = f->h_pin[8];
-  out->reserved = f->h_pin[9];  // dropped contributions (must stay 0)
+  out->n_dropped = f->h_pin[9];  // contributions outside the active blocks (must stay 0)
   out->n_active_nodes = f->h_pin[12];
   if (f->stat_steps > 0) {  // per-substep averages since the previous call
     out->n_collider_nodes = (int)(f->h_pin[10] / f->stat_steps);

@@ -326,7 +326,7 @@ class MPMWARP(object):
     def stats(self):
         s = L.Stats()
         self._call("mpmhip_get_stats", C.byref(s))
-        return {k: getattr(s, k) for k, _ in L.Stats._fields_ if k != "reserved"}
+        return {k: getattr(s, k) for k, _ in L.Stats._fields_}
 
     # ------------------------------------------------------------------ colliders / BCs
     # mpm_solver.py:564-658
