@@ -19,7 +19,7 @@ LIB = os.path.join(LIBDIR, "libmpmhip.so")
 SOURCES = ["api.hip", "common.hip", "baseline.hip", "fast.hip", "frames.hip"]
 HEADERS = ["ctx.hpp", "mpm_math.hpp", "bc.hpp", os.path.join("..", "..", "include", "mpmhip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast-honor-pragmas",
          "-Wall", "-Wno-unused-function"]
 
 

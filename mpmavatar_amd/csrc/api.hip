@@ -16,9 +16,14 @@ std::string g_create_error;
 // kernel that also applies the caller's advection mesh_x + (k*dt)*mesh_v (train_material_params.py:623; mul then
 // add, not fused, like the torch expression)
 __global__ void k_mesh_store(float *pts, float *vel, const float *x, const float *v, float f, size_t n) {
+#pragma clang fp contract(off)
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (x) pts[i] = (v && f != 0.0f) ? __fadd_rn(x[i], __fmul_rn(f, v[i])) : x[i];
+  if (x) {
+    float p = x[i];
+    if (v && f != 0.0f) { float a = f * v[i]; p = p + a; }
+    pts[i] = p;
+  }
   if (v) vel[i] = v[i];
 }
 

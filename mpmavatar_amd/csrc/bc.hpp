@@ -8,6 +8,22 @@
 
 namespace mpm {
 
+// node position minus a BC's reference point, with the product and the difference rounded separately: a node exactly on
+// the face of a cuboid / on a plane must be classified the same way by both kernel back ends and by the CPU oracle
+// (built with -ffp-contract=off), whatever the surrounding code lets the compiler fuse.  HIP's __fmul_rn / __fsub_rn
+// are plain operators and do get contracted, hence the pragma (the `contract` flag is per instruction and survives
+// inlining).
+__device__ __forceinline__ float node_off(int g, float dx, float p) {
+#pragma clang fp contract(off)
+  float pos = (float)g * dx;
+  return pos - p;
+}
+__device__ __forceinline__ float plane_side(V3 off, const float *n) {
+#pragma clang fp contract(off)
+  float a = off.x * n[0], b = off.y * n[1], c = off.z * n[2];
+  return (a + b) + c;
+}
+
 // returns true when v was (re)written
 __device__ __forceinline__ bool apply_bc(const BC &bc, V3 &v, int gx, int gy, int gz, int G, float dx, float time,
                                          float dt, size_t dense_index) {
@@ -18,11 +34,11 @@ __device__ __forceinline__ bool apply_bc(const BC &bc, V3 &v, int gx, int gy, in
   bool in_window = time >= bc.start_time && time < bc.end_time;
   if (bc.type == BC_SURFACE) {
     if (!in_window) return false;
-    V3 off = v3((float)gx * dx - bc.point[0], (float)gy * dx - bc.point[1], (float)gz * dx - bc.point[2]);
-    float dp = off.x * bc.normal[0] + off.y * bc.normal[1] + off.z * bc.normal[2];
+    V3 off = v3(node_off(gx, dx, bc.point[0]), node_off(gy, dx, bc.point[1]), node_off(gz, dx, bc.point[2]));
+    float dp = plane_side(off, bc.normal);
     if (!(dp < 0.0f)) return false;
     if (bc.surface_type == 11) {
-      float z = (float)gz * dx;
+      float z = node_off(gz, dx, 0.0f);
       if (z < 0.4f || z > 0.53f) v = v3(0, 0, 0);
       else v = v3(v.x * 0.3f, 0.0f, v.z * 0.3f);
     } else {
@@ -33,7 +49,7 @@ __device__ __forceinline__ bool apply_bc(const BC &bc, V3 &v, int gx, int gy, in
   }
   if (bc.type == BC_CUBOID) {
     if (in_window) {
-      V3 off = v3((float)gx * dx - bc.point[0], (float)gy * dx - bc.point[1], (float)gz * dx - bc.point[2]);
+      V3 off = v3(node_off(gx, dx, bc.point[0]), node_off(gy, dx, bc.point[1]), node_off(gz, dx, bc.point[2]));
       if (fabsf(off.x) < bc.size[0] && fabsf(off.y) < bc.size[1] && fabsf(off.z) < bc.size[2]) {
         v = v3(bc.velocity[0], bc.velocity[1], bc.velocity[2]);
         return true;
@@ -67,8 +83,8 @@ __device__ __forceinline__ bool bc_may_touch(const BC &bc, int lox, int loy, int
   if (bc.type == BC_SURFACE) {
     if (!in_window) return false;
     // dp is affine in the node index: its minimum over the box is taken at a corner (same float ops as apply_bc)
-    float lo[3] = {(float)lox * dx - bc.point[0], (float)loy * dx - bc.point[1], (float)loz * dx - bc.point[2]};
-    float hi[3] = {(float)hix * dx - bc.point[0], (float)hiy * dx - bc.point[1], (float)hiz * dx - bc.point[2]};
+    float lo[3] = {node_off(lox, dx, bc.point[0]), node_off(loy, dx, bc.point[1]), node_off(loz, dx, bc.point[2])};
+    float hi[3] = {node_off(hix, dx, bc.point[0]), node_off(hiy, dx, bc.point[1]), node_off(hiz, dx, bc.point[2])};
     float dpmin = 0.0f, mag = 0.0f;
     for (int a = 0; a < 3; ++a) {
       dpmin += fminf(lo[a] * bc.normal[a], hi[a] * bc.normal[a]);
@@ -79,9 +95,9 @@ __device__ __forceinline__ bool bc_may_touch(const BC &bc, int lox, int loy, int
   if (bc.type == BC_CUBOID) {
     if (!in_window) return bc.reset == 1 && time < bc.end_time + 15.0f * dt;
     // |g dx - p| < size somewhere in [lo, hi]: g dx - p is monotone in g
-    return ((float)lox * dx - bc.point[0] < bc.size[0]) && ((float)hix * dx - bc.point[0] > -bc.size[0]) &&
-           ((float)loy * dx - bc.point[1] < bc.size[1]) && ((float)hiy * dx - bc.point[1] > -bc.size[1]) &&
-           ((float)loz * dx - bc.point[2] < bc.size[2]) && ((float)hiz * dx - bc.point[2] > -bc.size[2]);
+    return (node_off(lox, dx, bc.point[0]) < bc.size[0]) && (node_off(hix, dx, bc.point[0]) > -bc.size[0]) &&
+           (node_off(loy, dx, bc.point[1]) < bc.size[1]) && (node_off(hiy, dx, bc.point[1]) > -bc.size[1]) &&
+           (node_off(loz, dx, bc.point[2]) < bc.size[2]) && (node_off(hiz, dx, bc.point[2]) > -bc.size[2]);
   }
   if (bc.type == BC_BBOX) {
     const int padding = 3;

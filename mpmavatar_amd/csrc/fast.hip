@@ -1887,8 +1887,8 @@ int rebin(mpmhip_ctx *c) {
       int tot = r.ne + r.nt + r.nv, n = std::min(CHUNK, tot - r.chunk * CHUNK);
       hist[n <= 32 ? 0 : n <= 64 ? 1 : n <= 128 ? 2 : n < 256 ? 3 : 4]++;
     }
-    fprintf(stderr, "[mpmhip] re-sort %d: %d particle blocks, %d active blocks, %zu chunks (<=32: %d, <=64: %d, <=128: %d, <256: %d, full: %d), lead %.1f\n",
-            f->rebins, f->n_P, f->n_A, f->h_chunks.size(), hist[0], hist[1], hist[2], hist[3], hist[4], f->lead_steps);
+    fprintf(stderr, "[mpmhip] re-sort %ld: %d particle blocks, %d active blocks, %zu chunks (<=32: %d, <=64: %d, <=128: %d, <256: %d, full: %d), lead %.1f\n",
+            (long)f->rebins, f->n_P, f->n_A, f->h_chunks.size(), hist[0], hist[1], hist[2], hist[3], hist[4], f->lead_steps);
   }
   f->n_chunks = (int)f->h_chunks.size();
   f->n_chunks_g = any_ghost ? (int)f->h_chunks_g.size() : f->n_chunks;

@@ -404,10 +404,12 @@ __device__ __forceinline__ float sel3(int i, float a, float b, float c) { return
 // body-mesh vertex i at this substep: x + adv*v with the multiply and the add rounded separately (the caller's
 // torch expression mesh_x + f*mesh_v, train_material_params.py:623)
 __device__ __forceinline__ V3 mesh_point(const float *pts, const float *vel, float adv, int i) {
+#pragma clang fp contract(off)
   V3 p = load_v3(pts + 3 * i);
   if (adv == 0.0f) return p;
   V3 u = load_v3(vel + 3 * i);
-  return v3(__fadd_rn(p.x, __fmul_rn(adv, u.x)), __fadd_rn(p.y, __fmul_rn(adv, u.y)), __fadd_rn(p.z, __fmul_rn(adv, u.z)));
+  float ax = adv * u.x, ay = adv * u.y, az = adv * u.z;
+  return v3(p.x + ax, p.y + ay, p.z + az);
 }
 
 // collider response on one node (mpm_solver.py:898-917): v is grid_v_out, vm the splatted body

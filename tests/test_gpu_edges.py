@@ -254,3 +254,27 @@ def test_out_of_margin_traditional_particles_with_hardening(material, oracle_lib
     assert rel(sim.state.particle_x.cpu().numpy(), o.x) < 2e-5
     assert rel(sim.state.particle_v.cpu().numpy(), o.v) < 2e-4
     assert rel(sim.state.particle_F_trial.cpu().numpy(), o.F_trial) < 2e-4
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("fuse_grid", ["0", "1"])
+def test_nodes_exactly_on_a_cuboid_face(mode, fuse_grid, oracle_lib, monkeypatch):
+    """A velocity cuboid (set_velocity_on_cuboid, mpm_solver.py:950-981) whose faces coincide with grid-node planes:
+    14 * 0.05f - 1.0f is -0.3f when the product is rounded and -0.29999999 under an FMA, so `|offset| < size` flips with
+    the compiler's contraction choice.  Both back ends round the product (like the oracle): every node must be
+    classified identically, then the release window (reset=1: 15 substeps of zero grid velocity) and free motion."""
+    monkeypatch.setenv("MPMHIP_FUSE_GRID", fuse_grid)
+    sc = scenes.sheet(n=10, n_grid=40, collider_subdiv=1, span=(0.6, 1.4), y=1.2, sphere_r=0.2, sphere_c=(1.0, 0.97, 1.0), name="edge")
+    sc.bcs = list(sc.bcs) + [("velocity_cuboid", {"point": [1.1, 1.2, 1.0], "size": [0.05, 0.3, 0.3], "velocity": [-0.8, 0.0, 0.0],
+                                                   "start_time": 0.0, "end_time": 0.0011, "reset": 1})]
+    sc.dt = 1e-4
+    for n in (1, 8, 20):   # inside the window; across its end; inside the reset window
+        o, sim = _pair(sc, n, mode, fused=False)
+        G = sc.n_grid
+        og = np.asarray(o.grid_v_out).reshape(G, G, G, 3)
+        live = np.asarray(o.grid_m).reshape(G, G, G) > 0
+        _, _, vo = sim.solver.export_grid()
+        d = np.abs(vo.cpu().numpy() - og).max(-1) * live
+        assert (d > 1e-4).sum() == 0, f"{(d > 1e-4).sum()} nodes classified differently after {n} substeps"
+        assert rel(sim.state.particle_x.cpu().numpy(), o.x) < 1e-5
+        assert np.abs(sim.state.particle_v.cpu().numpy() - o.v).max() < 1e-4 * max(np.abs(o.v).max(), 0.1)
