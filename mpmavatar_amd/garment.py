@@ -67,6 +67,24 @@ def world_to_sim(verts: np.ndarray):
     return scale, shift.astype(np.float32)
 
 
+def get_sand(center=(-0.4, 1.8, -0.1), length=(0.8, 0.04, 0.2), res=(200, 10, 50), noise=0.01, rng=None):
+    """Sand block of run_demo.py (utils/demo_utils.py:6-24): a res[0] x res[1] x res[2] lattice spanning `length` from
+    `center` (its min corner), enumerated with res[0] (x) fastest, then res[2] (z), then res[1] (y) -- the order matters,
+    run_demo.py:524 releases the sand by slicing this list -- plus Gaussian jitter; volume = box volume / count each.
+    Returns (points [n,3] float32, volumes [n] float32)."""
+    res = np.asarray(res, np.int64)
+    idx = np.stack(np.meshgrid(np.arange(res[1]), np.arange(res[2]), np.arange(res[0]), indexing="ij"), -1)
+    pts = idx.reshape(-1, 3).astype(np.float32)[:, [2, 0, 1]]
+    pts = pts / np.array([res[0] - 1, res[1] - 1, res[2] - 1], np.float32)
+    pts = pts * np.asarray(length, np.float32) + np.asarray(center, np.float32)
+    if noise:
+        rng = rng or np.random.default_rng(0)
+        pts = pts + rng.normal(size=pts.shape).astype(np.float32) * np.float32(noise)
+    n = int(res.prod())
+    vol = np.full(n, (length[0] * length[1] * length[2]) / n, np.float32)
+    return pts.astype(np.float32), vol
+
+
 # ------------------------------------------------------------------ synthetic surface meshes
 def grid_sheet(nx: int, nz: int, x0: float, x1: float, z0: float, z1: float, y: float):
     """nx x nz vertex lattice in the x-z plane, two triangles per quad. Vertex id = ix*nz + iz."""

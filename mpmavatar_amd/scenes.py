@@ -176,13 +176,9 @@ def demo_mix(n_grid=64, n_sheet=24, sand=(24, 4, 12), n_steps=200, seed=3, hold=
     verts, faces = garment.grid_sheet(n_sheet, n_sheet, 0.7, 1.3, 0.7, 1.3, 1.25)
     init_dir, rest_dir, e_vol, v_vol = garment.compute_dir_vol(verts, faces, thickness=1e-5)
     R_inv = garment.compute_rest_dir_inv(rest_dir)
-    length = np.array([0.5, 0.04, 0.25])
-    res = np.array(sand)
-    rng = np.random.default_rng(seed)
-    idx = np.stack(np.meshgrid(np.arange(res[1]), np.arange(res[2]), np.arange(res[0]), indexing="ij"), -1)
-    pts = idx.reshape(-1, 3).astype(np.float64)[:, [2, 0, 1]] / (res - 1) * length  # utils/demo_utils.py:6-19
-    pts = pts + np.array([0.75, 1.45, 0.875]) + rng.normal(size=pts.shape) * 0.002
-    t_vol = float(np.prod(length) / np.prod(res))
+    pts, t_vols = garment.get_sand(center=(0.75, 1.45, 0.875), length=(0.5, 0.04, 0.25), res=sand, noise=0.002,
+                                   rng=np.random.default_rng(seed))  # utils/demo_utils.py:6-24
+    t_vol = float(t_vols[0])
     elts = verts[faces].mean(1)
     x = np.concatenate([elts, pts, verts], 0).astype(np.float32)
     vol = np.concatenate([e_vol, np.full(pts.shape[0], t_vol, np.float32), v_vol], 0).astype(np.float32)
