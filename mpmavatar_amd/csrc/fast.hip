@@ -1017,8 +1017,7 @@ __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p
     bool do_add = valid && (dist & ((1 << STEPS) - 1)) == 0;
     if (g.dbg & 128) do_add = false;
     const Stencil &st = q.s;
-    // factored stencil: add_ijk = wm (B_ij + k Cz) + wz_k P_ij + dwz_k Q_ij, wm = wxy_ij (wz_k m)
-    float wzm0 = st.w0.z * q.mass, wzm1 = st.w1.z * q.mass, wzm2 = st.w2.z * q.mass;
+    // factored stencil: add_ijk = wz_k (wxym_ij (B_ij + k Cz) + P_ij) + dwz_k Q_ij,  wm = wxym_ij wz_k,  wxym = wx wy m
     V3 Cx = col0(q.Cdx), Cy = col1(q.Cdx), Cz = col2(q.Cdx);
     V3 S0 = col0(q.Sdt), S1 = col1(q.Sdt), S2 = col2(q.Sdt);
 #pragma unroll
@@ -1028,16 +1027,17 @@ __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         float wy = sel3(j, st.w0.y, st.w1.y, st.w2.y), dwy = sel3(j, st.dw0.y, st.dw1.y, st.dw2.y);
-        float wxy = wx * wy;
+        float wxy = wx * wy, wxym = wxy * q.mass;
         V3 Bij = Bi + (float)j * Cy;
-        V3 P = (dwx * wy) * S0 + (wx * dwy) * S1 + wxy * q.vfdt;
+        V3 T = wxym * Bij + ((dwx * wy) * S0 + (wx * dwy) * S1 + wxy * q.vfdt);
+        V3 dT = wxym * Cz;
         V3 Q = wxy * S2;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           float wzk = sel3(k, st.w0.z, st.w1.z, st.w2.z), dwzk = sel3(k, st.dw0.z, st.dw1.z, st.dw2.z);
-          float wm = wxy * sel3(k, wzm0, wzm1, wzm2);
-          V3 vel = Bij + (float)k * Cz;
-          V3 add = wm * vel + wzk * P + dwzk * Q;
+          float wm = wxym * wzk;
+          if (k > 0) T = T + dT;
+          V3 add = wzk * T + dwzk * Q;
           float r0 = wm, r1 = add.x, r2 = add.y, r3 = add.z;
           seg_scan4<STEPS>(r0, r1, r2, r3, sm);
           if (do_add) {
@@ -1990,7 +1990,7 @@ int fast_init(mpmhip_ctx *c) {
   if ((rc = dalloc(c, &f->ab_flag, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->ab_index, f->nblocks))) return rc;
   f->g.ab_flag = f->ab_flag;
-  if (const char *e = getenv("MPMHIP_DBG")) f->g.dbg = atoi(e);
+  if (const char *e = getenv("MPMHIP_DBG")) f->g.dbg = (int)strtoul(e, nullptr, 0);
   if (const char *e = getenv("MPMHIP_FUSE_GRID")) f->fuse_grid = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_FUSE_TRAD")) f->fuse_trad = atoi(e) != 0;
   MPM_HIP_CHECK(c, hipHostMalloc((void **)&f->h_pin, 64 * sizeof(int), hipHostMallocDefault));
