@@ -1,0 +1,198 @@
+"""Finite-difference material fitting over the solver.
+
+Restates the training step of the reference's physics driver, ``Trainer.train_one_step``
+(/root/reference/train_material_params.py:575-671): the garment is simulated four times per step -- at the current
+parameters (density D, Young's modulus 100*E, rest-pose height scale H) and with D, E, H nudged by 0.05 / 0.05 / 0.005
+-- the loss of each run is the mean over frames of the MSE between simulated and captured cloth vertices in world space,
+the three difference quotients are written into ``.grad`` and Adam + cosine annealing + clamping update the parameters
+(:657-670).  Checkpoints are the reference's ``best_param_*.npz`` / ``last_param_*.npz`` (:725-728, io_formats).
+
+What is MI355X-specific: the four runs are independent, and a garment-sized substep (~120k particles) leaves most of the
+GPU idle (two or three launches of ~10 us each, far below one round of workgroups).  With ``concurrent=True`` every
+variant owns a solver context on its own HIP stream and a host thread (ctypes releases the GIL inside the library), so
+the four simulations share the GPU instead of queueing behind each other; ``concurrent=False`` is the reference's
+sequential order on one context.  Both give the same losses.  Across GPUs the variants are the natural shard: no
+exchange at all (``variant_slice``).
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from concurrent.futures import ThreadPoolExecutor
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import garment, harness
+from .scenes import Scene
+
+# (dD, dE, dH) of the four simulations, train_material_params.py:583
+DELTAS = ((0.0, 0.0, 0.0), (0.05, 0.0, 0.0), (0.0, 0.05, 0.0), (0.0, 0.0, 0.005))
+
+
+@dataclasses.dataclass
+class Frame:
+    """One captured frame in simulation space: body mesh at the frame start and its velocity (advected inside the frame
+    as mesh_x + k*dt*mesh_v, :622), velocities of the attached garment vertices / faces, and the captured cloth
+    vertices of the NEXT frame in world space (the loss target, :631)."""
+    mesh_x: np.ndarray
+    mesh_v: np.ndarray
+    joint_verts_v: Optional[np.ndarray]
+    joint_faces_v: Optional[np.ndarray]
+    target: np.ndarray
+
+
+def variant_slice(rank: int, world: int, n: int = len(DELTAS)) -> range:
+    """Variants simulated by ``rank`` when the FD runs are spread over ``world`` processes (contiguous, balanced)."""
+    lo, hi = (rank * n) // world, ((rank + 1) * n) // world
+    return range(lo, hi)
+
+
+class MaterialFD:
+    """train_material_params.py:575-728 on top of the shim.  ``scene`` supplies the garment (vertices, faces, collider
+    mesh, joints, fixed nu / gamma / kappa); ``frames`` the driving motion and targets."""
+
+    def __init__(self, scene: Scene, frames: Sequence[Frame], *, init=(1.0, 1.0, 1.0), ranges=((0.1, 10.0), (0.1, 10.0), (0.5, 1.5)),
+                 lrs=(0.05, 0.05, 0.005), iterations=100, frame_dt=1.0 / 25, substeps=400, scale=1.0, shift=(0.0, 0.0, 0.0),
+                 device="cuda:0", concurrent=True, mode=None, variants: Optional[Sequence[int]] = None, build=True):
+        self.sc, self.frames = scene, list(frames)
+        self.device = torch.device(device)
+        self.iterations = int(iterations)
+        self.substeps = int(substeps)
+        self.substep_size = frame_dt / substeps                       # :579-581
+        self.scale = float(scale)
+        self.shift = torch.tensor(np.asarray(shift, np.float32).reshape(1, 3), device=self.device if build else "cpu")
+        self.param_ranges = {"D": list(ranges[0]), "E": list(ranges[1]), "H": list(ranges[2])}
+        self.torch_param = {k: torch.tensor(float(v), dtype=torch.float32, requires_grad=True) for k, v in zip("DEH", init)}
+        # :190-191
+        self.optimizer = torch.optim.Adam([{"params": [self.torch_param[k]], "lr": lr} for k, lr in zip("DEH", lrs)], lr=lrs[0])
+        self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, self.iterations * 0.5 * np.pi / np.arccos(0.4), eta_min=0.0)
+        self.best_params = {"D": float(init[0]), "E": float(init[1]) * 100, "H": float(init[2]), "loss": 1.0, "step": -1}
+        self.last_params = dict(self.best_params)
+        self.step = 0
+        self.variants = list(range(len(DELTAS))) if variants is None else list(variants)
+        self.substeps_done = 0
+        if not build:   # optimiser / bookkeeping only (host-side tests)
+            self.concurrent, self.sims, self.pool = False, [], None
+            return
+        self.concurrent = bool(concurrent) and len(self.variants) > 1
+        n_ctx = len(self.variants) if self.concurrent else 1
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(n_ctx)] if self.concurrent else [None]
+        self.sims = []
+        for s in self.streams:
+            with torch.cuda.stream(s) if s is not None else _null():
+                self.sims.append(harness.build_solver(scene, str(self.device), mode=mode))
+        self.pool = ThreadPoolExecutor(max_workers=n_ctx) if self.concurrent else None
+        t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=self.device)
+        self._frames = [dict(mesh_x=t(f.mesh_x), mesh_v=t(f.mesh_v), jv=t(f.joint_verts_v), jf=t(f.joint_faces_v), target=t(f.target))
+                        for f in self.frames]
+        self._x0, self._d0, self._v0 = t(scene.x), t(scene.d), t(scene.v)
+        self._verts0 = scene.x[scene.n_elements + scene.n_traditional:].astype(np.float32)
+
+    # ---- one simulation ------------------------------------------------------------------------------------------
+    def sim2wld(self, p):
+        return (p - self.shift) / self.scale   # :372-373
+
+    def simulate(self, sim, D: float, E: float, H: float, record: Optional[List[np.ndarray]] = None) -> float:
+        """Reset the state to the first frame, set density / stiffness / rest pose, run every frame's substeps as one
+        fused call and accumulate the vertex loss (:584-641).  E is the trained parameter: Young's modulus is 100*E."""
+        sc, dev = self.sc, self.device
+        st, md, sv = sim.state, sim.model, sim.solver
+        n_p = sc.n_particles
+        scaled = self._verts0 * np.array([[1.0, H, 1.0]], np.float32)                       # :587
+        R_inv = torch.as_tensor(garment.compute_rest_dir_inv_from_vf(scaled, sc.faces), device=dev)
+        st.reset_state(sc.n_vertices, self._x0.clone(), self._d0.clone(), None, self._v0.clone(), tensor_R_inv=R_inv, device=dev,
+                       requires_grad=True)
+        st.set_require_grad(True)
+        ones = torch.ones(n_p, dtype=torch.float32, device=dev)
+        st.reset_density(ones * D, None, dev, update_mass=True)                               # :603-605
+        sv.set_E_nu_from_torch(md, ones * (E * 100.0), ones * sc.nu, ones * sc.gamma, ones * sc.kappa, dev)  # :607-609
+        sv.prepare_mu_lam(md, st, dev)
+        loss = torch.zeros((), dtype=torch.float32, device=dev)
+        for f in self._frames:
+            sv.p2g2p_n(md, st, self.substep_size, self.substeps, mesh_x=f["mesh_x"], mesh_v=f["mesh_v"], joint_traditional_v=None,
+                       joint_verts_v=f["jv"], joint_faces_v=f["jf"])                          # :621-626 as one call
+            cloth = self.sim2wld(st.particle_x[sc.n_elements:])
+            loss = loss + torch.nn.functional.mse_loss(cloth, f["target"])                    # :630-631
+            if record is not None:
+                record.append(cloth.detach().cpu().numpy().copy())
+        return float((loss / len(self._frames)).item())
+
+    def losses(self, D: float, E: float, H: float) -> List[float]:
+        """Losses of this process's variants at (D, E, H) + DELTAS[i]."""
+        jobs = [(D + DELTAS[i][0], E + DELTAS[i][1], H + DELTAS[i][2]) for i in self.variants]
+        if not self.concurrent:
+            out = [self.simulate(self.sims[0], *p) for p in jobs]
+        else:
+            def work(k):
+                with torch.cuda.stream(self.streams[k]):
+                    return self.simulate(self.sims[k], *jobs[k])
+            out = list(self.pool.map(work, range(len(jobs))))
+        self.substeps_done += len(jobs) * len(self._frames) * self.substeps
+        return out
+
+    # ---- the training step ---------------------------------------------------------------------------------------
+    def apply_losses(self, geo_losses: Sequence[float]) -> dict:
+        """:650-712: difference quotients -> .grad -> Adam, cosine schedule, clamp, best/last bookkeeping."""
+        g = {"D": (geo_losses[1] - geo_losses[0]) / 0.05, "E": (geo_losses[2] - geo_losses[0]) / 0.05,
+             "H": (geo_losses[3] - geo_losses[0]) / 0.005}
+        self.optimizer.zero_grad()
+        for k in "DEH":
+            self.torch_param[k].grad = torch.tensor(g[k]).float()
+        self.optimizer.step()
+        self.scheduler.step()
+        with torch.no_grad():
+            for k in "DEH":
+                self.torch_param[k].clamp_(min=float(self.param_ranges[k][0]), max=float(self.param_ranges[k][-1]))
+        self.last_params = {"D": self.torch_param["D"].item(), "E": self.torch_param["E"].item() * 100, "H": self.torch_param["H"].item(),
+                            "loss": geo_losses[0], "step": self.step}
+        if geo_losses[0] < self.best_params["loss"]:
+            self.best_params = dict(self.last_params)
+        self.step += 1
+        return {"loss": geo_losses[0], "grad": g, **{k: self.last_params[k] for k in "DEH"}}
+
+    def train_one_step(self) -> dict:
+        if len(self.variants) != len(DELTAS):
+            raise RuntimeError("train_one_step needs all four variants here; with variant_slice() gather the losses "
+                               "of the other ranks and call apply_losses()")
+        p = self.torch_param
+        return self.apply_losses(self.losses(p["D"].item(), p["E"].item(), p["H"].item()))
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.shutdown()
+
+
+class _null:
+    def __enter__(self): return None
+    def __exit__(self, *a): return False
+
+
+# ---- synthetic captured sequence ------------------------------------------------------------------------------------
+def synthetic_problem(scene: Scene, n_frames=4, frame_dt=1.0 / 25, sway=0.4, period=0.5):
+    """Driving motion for ``scene`` (a garment_cylinder-like scene with a body mesh and attached rows): the body sways
+    along x with velocity sway*sin(2 pi t / period), constant inside a frame like the captured SMPL-X velocities
+    (:617-620).  Targets are filled in by ``capture``."""
+    frames, x = [], scene.mesh_vertices.astype(np.float32).copy()
+    njv, njf = scene.num_joint_v, scene.num_joint_f
+    for i in range(n_frames):
+        vel = np.float32(sway * math.sin(2 * math.pi * (i + 0.5) * frame_dt / period))
+        mesh_v = np.tile(np.array([[vel, 0.0, 0.0]], np.float32), (x.shape[0], 1))
+        jv = np.tile(np.array([[vel, 0.0, 0.0]], np.float32), (njv, 1)) if njv else None
+        jf = np.tile(np.array([[vel, 0.0, 0.0]], np.float32), (njf, 1)) if njv else None
+        frames.append(Frame(x.copy(), mesh_v, jv, jf, np.zeros((scene.n_vertices + scene.n_traditional, 3), np.float32)))
+        x = x + np.float32(frame_dt) * mesh_v
+    return frames
+
+
+def capture(fd: MaterialFD, D: float, E: float, H: float):
+    """Simulate once at the 'true' parameters and store the cloth vertices as the frames' targets."""
+    rec: List[np.ndarray] = []
+    stream = fd.streams[0]
+    with torch.cuda.stream(stream) if stream is not None else _null():
+        fd.simulate(fd.sims[0], D, E, H, record=rec)
+    for f, fr, r in zip(fd._frames, fd.frames, rec):
+        fr.target = r
+        f["target"] = torch.as_tensor(r, device=fd.device)
+    torch.cuda.synchronize(fd.device)
