@@ -214,6 +214,10 @@ int mpmhip_dist_set_ghost_mode(mpmhip_ctx *ctx, int32_t ghosts_gather);
 int mpmhip_dist_ghost_pack(mpmhip_ctx *ctx);   /* fill every peer's ghost_send */
 int mpmhip_dist_ghost_unpack(mpmhip_ctx *ctx); /* apply every peer's ghost_recv */
 int mpmhip_dist_num_blocks(const mpmhip_ctx *ctx); /* size of the active-block byte map */
+/* this rank's early-warning drift flag (1: some particle is about to leave the tile margin of the block it was sorted
+ * into; cleared by the next re-sort).  Synchronous.  A sharded driver max-reduces it over the ranks to decide on a
+ * collective re-sort -- the single-GPU adaptive policy (mpmhip_config.rebin_interval = 0) made collective. */
+int mpmhip_dist_drift_flag(mpmhip_ctx *ctx, int32_t *flag);
 /* import the bound state if needed, re-sort, and write this rank's active-block map (1 byte per block) [dev] */
 int mpmhip_dist_rebin(mpmhip_ctx *ctx, uint8_t *active_map);
 int mpmhip_dist_set_peers(mpmhip_ctx *ctx, int32_t n_peers, const mpmhip_dist_peer *peers);
@@ -233,8 +237,10 @@ int mpmhip_rccl_set_ghosts(mpmhip_ctx *ctx, int32_t n_peers, const int32_t *peer
                            const int32_t *const *send_p, const int32_t *n_recv_p, const int32_t *const *recv_p,
                            const int32_t *n_send_e, const int32_t *const *send_e, const int32_t *n_recv_e,
                            const int32_t *const *recv_e);
-/* n substeps (collective): re-sort + shared-block lists every rebin_interval substeps (counted from step_index),
- * halo (and, in ghost mode 0, ghost) exchanges with ncclSend/ncclRecv groups on the context's stream; in ghost mode 1
+/* n substeps (collective): re-sort + shared-block lists every rebin_interval substeps (counted from step_index) if
+ * rebin_interval > 0; if <= 0, when the max-reduced drift flag of the ranks (ncclAllReduce of one int every 16
+ * substeps, read 4 substeps later so that all ranks act at the same substep) asks for it, at the latest every 256
+ * (or -rebin_interval) substeps.  Halo (and, in ghost mode 0, ghost) exchanges with ncclSend/ncclRecv groups on the context's stream; in ghost mode 1
  * the ghosts are re-synchronised before every re-sort instead.  Mesh advection factor of substep k is
  * (step_index + k) * dt */
 int mpmhip_rccl_steps(mpmhip_ctx *ctx, float dt, int32_t n, int64_t step_index, int32_t rebin_interval,

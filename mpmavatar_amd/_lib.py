@@ -95,6 +95,7 @@ SIGNATURES = {
     "mpmhip_dist_ghost_pack": (C.c_int, [vp]),
     "mpmhip_dist_ghost_unpack": (C.c_int, [vp]),
     "mpmhip_dist_num_blocks": (C.c_int, [vp]),
+    "mpmhip_dist_drift_flag": (C.c_int, [vp, C.POINTER(C.c_int32)]),
     "mpmhip_dist_rebin": (C.c_int, [vp, vp]),
     "mpmhip_dist_set_peers": (C.c_int, [vp, C.c_int32, C.POINTER(DistPeer)]),
     "mpmhip_dist_step_begin": (C.c_int, [vp, C.c_float, vp, vp, C.c_float, vp, C.c_int32, vp, vp]),

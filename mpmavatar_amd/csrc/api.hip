@@ -405,6 +405,12 @@ int mpmhip_dist_ghost_unpack(mpmhip_ctx *c) {
   return fast_dist_ghosts(c, 0);
 }
 int mpmhip_dist_num_blocks(const mpmhip_ctx *c) { return (c && c->fast) ? fast_dist_num_blocks(c) : 0; }
+int mpmhip_dist_drift_flag(mpmhip_ctx *c, int32_t *flag) {
+  CHECK_CTX(c);
+  if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
+  if (!flag) return fail(c, MPMHIP_ERR_INVALID, "dist_drift_flag: null output");
+  return fast_dist_drift_flag(c, flag);
+}
 int mpmhip_dist_rebin(mpmhip_ctx *c, uint8_t *active_map) {
   CHECK_CTX(c);
   if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");

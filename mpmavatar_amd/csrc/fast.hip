@@ -1600,6 +1600,7 @@ struct Rccl {  // entry points resolved with dlsym: libmpmhip.so itself does not
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
@@ -1613,7 +1614,9 @@ struct Rccl {  // entry points resolved with dlsym: libmpmhip.so itself does not
     *(void **)&CommDestroy = sym("ncclCommDestroy"); *(void **)&GroupStart = sym("ncclGroupStart");
     *(void **)&GroupEnd = sym("ncclGroupEnd"); *(void **)&Send = sym("ncclSend"); *(void **)&Recv = sym("ncclRecv");
     *(void **)&AllGather = sym("ncclAllGather"); *(void **)&GetErrorString = sym("ncclGetErrorString");
-    return GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllGather && GetErrorString;
+    *(void **)&AllReduce = sym("ncclAllReduce");
+    return GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllGather && AllReduce &&
+           GetErrorString;
   }
 };
 
@@ -1634,6 +1637,11 @@ struct FastState {
   Dims d{};
   bool dist = false;  // multi-GPU: re-sorts only on request (all ranks re-sort together)
   bool dist_keep_cur = false;  // re-sort inside mpmhip_rccl_steps: the caller's mesh pointers are valid
+  // adaptive collective re-sorts (mpmhip_rccl_steps with rebin_interval <= 0): the ranks' drift flags are max-reduced
+  // every DIST_POLL substeps and read DIST_LAG substeps later, so every rank takes the same decision at the same substep
+  int dist_since = 0;
+  bool dist_resort = false, dflag_pending = false, rccl_sorted = false;
+  int64_t dflag_check_at = 0;
   std::vector<DistPeer> peers;
   StepArgs dist_args{};
   int blk_bits = 0, key_bits = 0;  // blk_bits: packed key format kf (field widths) as the kernels take it
@@ -2507,7 +2515,11 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
                     const float *mesh_v, const float *jv, const float *jf) {
   FastState *f = c->fast;
   if (!f->rccl.comm) return fail(c, MPMHIP_ERR_STATE, "rccl_steps: call mpmhip_rccl_init first");
-  if (rebin_interval <= 0) rebin_interval = 32;
+  // rebin_interval > 0: every rank re-sorts at substeps that are multiples of it.  <= 0: when any rank's early-warning
+  // drift flag is up (the single-GPU policy made collective), at the latest every 256 (or -rebin_interval) substeps.
+  const bool adaptive = rebin_interval <= 0;
+  const int cap = rebin_interval < 0 ? -rebin_interval : (rebin_interval == 0 ? 256 : rebin_interval);
+  constexpr int DIST_POLL = 16, DIST_LAG = 4;
   int rc;
   for (int k = 0; k < n; ++k) {
     int64_t idx = step_index + k;
@@ -2515,16 +2527,32 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
     c->cur_pts = a.mesh_x ? a.mesh_x : c->mesh_points;
     c->cur_vel = a.mesh_v ? a.mesh_v : c->mesh_vel;
     c->cur_f = (a.mesh_x && a.mesh_v) ? a.mesh_f : 0.0f;
-    if (idx % rebin_interval == 0 || c->caller_dirty) {
+    if (adaptive && f->dflag_pending && idx >= f->dflag_check_at) {
+      MPM_HIP_CHECK(c, hipEventSynchronize(f->ev_flag));
+      f->dflag_pending = false;
+      if (f->h_pin[26]) f->dist_resort = true;
+    }
+    bool due = adaptive ? (f->dist_resort || f->dist_since >= cap || !f->rccl_sorted) : (idx % cap == 0);
+    if (due || c->caller_dirty) {
       if (f->ghost_g2p && f->have_order && !c->caller_dirty && !f->peers.empty()) {  // owners -> copies, then re-sort
         if ((rc = fast_dist_ghosts(c, 1))) return rc;
         if ((rc = rccl_exchange(c, false))) return rc;
         if ((rc = fast_dist_ghosts(c, 0))) return rc;
       }
+      if (adaptive && f->true_since_rebin > 0)  // predictive sort: aim at the middle of the next interval
+        f->lead_steps = std::min(std::max(0.5f * (float)f->true_since_rebin, 4.0f), 48.0f);
       f->dist_keep_cur = true;
       rc = rccl_rebin(c);
       f->dist_keep_cur = false;
       if (rc) return rc;
+      f->true_since_rebin = 0;
+      f->dist_since = 0;
+      f->dist_resort = false;
+      f->rccl_sorted = true;
+      if (f->dflag_pending) {  // a reduction issued before this re-sort speaks about the old order: drop it (every rank does)
+        MPM_HIP_CHECK(c, hipEventSynchronize(f->ev_flag));
+        f->dflag_pending = false;
+      }
     }
     if ((rc = fast_dist_phase(c, 0, a))) return rc;
     if ((rc = rccl_exchange(c, true))) return rc;
@@ -2533,7 +2561,24 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
     if ((rc = fast_dist_phase(c, 2, a))) return rc;
     c->time = c->time + (double)dt;
     c->substeps += 1;
+    f->dist_since += 1;
+    if (adaptive && !f->dflag_pending && f->dist_since % DIST_POLL == 0) {
+      MPM_NCCL_CHECK(c, f->rccl, f->rccl.AllReduce(f->g.counters + 6, f->g.counters + 7, 1, ncclInt32, ncclMax, f->rccl.comm, c->stream));
+      MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 26, f->g.counters + 7, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      MPM_HIP_CHECK(c, hipEventRecord(f->ev_flag, c->stream));
+      f->dflag_pending = true;
+      f->dflag_check_at = idx + 1 + DIST_LAG;
+    }
   }
+  return MPMHIP_OK;
+}
+
+// the drift flag of this rank (set by the kernels when a particle is about to leave its tile margin); synchronous
+int fast_dist_drift_flag(mpmhip_ctx *c, int32_t *out) {
+  FastState *f = c->fast;
+  MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 27, f->g.counters + 6, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  *out = f->h_pin[27];
   return MPMHIP_OK;
 }
 

@@ -15,7 +15,9 @@ Decomposition
     owners overwrite the copies (x, v of vertices, d3 of elements) to keep that from accumulating.
     (MPMHIP_DIST_GHOST_G2P=0 selects the older scheme: copies do not gather, owners send them every substep.)
     The body-face splat is replicated (each rank splats the faces that touch its active blocks).
-  * all ranks re-sort at the same substep (every ``rebin_interval`` substeps); the shared-block lists are rebuilt
+  * all ranks re-sort at the same substep: every ``rebin_interval`` substeps if that is > 0, otherwise (default) when the
+    max over the ranks of the library's early-warning drift flag asks for it (polled every 16 substeps, at the latest
+    every 256) -- the single-GPU adaptive policy made collective; the shared-block lists are rebuilt
     there from an all_gather of the per-rank active-block maps.
 Transports: "rccl" (default with the nccl backend) runs the whole substep loop inside libmpmhip.so with its own
 RCCL communicator (ncclSend/ncclRecv groups on the solver stream, ncclAllGather of the block maps; no Python per
@@ -131,6 +133,10 @@ class ShardedSim:
     transport: str = "torch"           # "rccl": loop inside libmpmhip.so; "torch": phases driven from Python
     ghost_g2p: bool = True             # ghost copies gather for themselves (one exchange per substep)
     steps_done: int = 0
+    since: int = 0                     # substeps since the last collective re-sort
+    resort_now: bool = False           # some rank's drift flag was up at the last poll
+    sorted_once: bool = False
+    resorts: int = 0
     peers: list = field(default_factory=list)
     keep: list = field(default_factory=list)
     static: dict = field(default_factory=dict)
@@ -151,7 +157,7 @@ def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int 
     import os
     ghost_g2p = os.environ.get("MPMHIP_DIST_GHOST_G2P", "1") != "0"
     sv._call("mpmhip_dist_set_ghost_mode", 1 if ghost_g2p else 0)
-    ss = ShardedSim(shard, sim, dist.get_backend(), rebin_interval or 32, ghost_g2p=ghost_g2p)
+    ss = ShardedSim(shard, sim, dist.get_backend(), int(rebin_interval), ghost_g2p=ghost_g2p)
     dev = torch.device(device)
     i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.int32), device=dev)
     for q in sorted(set(shard.send_p) | set(shard.recv_p)):
@@ -292,6 +298,19 @@ def _exchange(ss: ShardedSim, kind: str):
         rbuf[:nr].copy_(tmp)
 
 
+def _any_rank_drifting(ss: ShardedSim) -> bool:
+    """Collective: max over the ranks of the library's early-warning drift flag."""
+    import torch
+    import torch.distributed as dist
+    sv = ss.sim.solver
+    flag = C.c_int32(0)
+    sv._call("mpmhip_dist_drift_flag", C.byref(flag))
+    t = torch.tensor([flag.value], dtype=torch.int32, device="cpu" if ss.backend == "gloo" else sv.device)
+    if ss.shard.world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
 def run(ss: ShardedSim, n_steps: int):
     """Advance n substeps on every rank (collective)."""
     sim, sv, sc = ss.sim, ss.sim.solver, ss.sim.scene
@@ -305,13 +324,18 @@ def run(ss: ShardedSim, n_steps: int):
                  dp(sim.mesh_x0), dp(sim.mesh_v), jvp, jfp)
         ss.steps_done += n_steps
         return
+    adaptive = ss.rebin_interval <= 0   # re-sort when any rank's drift flag asks for it (polled every 16 substeps)
+    cap = -ss.rebin_interval if ss.rebin_interval < 0 else (256 if ss.rebin_interval == 0 else ss.rebin_interval)
     for _ in range(n_steps):
-        if ss.steps_done % ss.rebin_interval == 0:
+        due = (ss.resort_now or ss.since >= cap or not ss.sorted_once) if adaptive else ss.steps_done % cap == 0
+        if due:
             if ss.ghost_g2p and ss.steps_done > 0 and ss.peers:  # owners -> copies before the re-sort
                 sv._call("mpmhip_dist_ghost_pack")
                 _exchange(ss, "ghost")
                 sv._call("mpmhip_dist_ghost_unpack")
             rebin_all(ss)
+            ss.since, ss.resort_now, ss.sorted_once = 0, False, True
+            ss.resorts += 1
         adv = float(np.float32(sc.dt * ss.steps_done))
         jvp = None if jv is None else (dp(jv) or dummy)
         jfp = None if jf is None else (dp(jf) or dummy)
@@ -322,6 +346,9 @@ def run(ss: ShardedSim, n_steps: int):
             _exchange(ss, "ghost")
         sv._call("mpmhip_dist_step_end")
         ss.steps_done += 1
+        ss.since += 1
+        if adaptive and ss.since % 16 == 0:
+            ss.resort_now = _any_rank_drifting(ss)
 
 
 def gather_positions(ss: ShardedSim):

@@ -22,7 +22,14 @@ sys.path.insert(0, ROOT)
 from mpmavatar_amd import dist as mdist  # noqa: E402
 from mpmavatar_amd import scenes  # noqa: E402
 
-SCENES = {"garment": scenes.small_garment, "sheet": scenes.small_sheet, "cube": scenes.small_cube,
+def _fast_cube():
+    """A cube thrown sideways at 20 m/s: crosses a grid cell every ~30 substeps, so the drift flag keeps coming up."""
+    sc = scenes.small_cube()
+    sc.v = (sc.v + np.array([[20.0, 0.0, 5.0]], np.float32)).astype(np.float32)
+    return sc
+
+
+SCENES = {"garment": scenes.small_garment, "sheet": scenes.small_sheet, "cube": scenes.small_cube, "fastcube": _fast_cube,
           "demo": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=False)}
 
 
@@ -69,8 +76,12 @@ def main():
     else:
         assert torch.cuda.is_available()
         from mpmavatar_amd import harness
-        ss = mdist.build_sharded(sc, "cuda:0", rank, world, rebin_interval=8)
+        ss = mdist.build_sharded(sc, "cuda:0", rank, world, rebin_interval=int(os.environ.get("MPMHIP_TEST_REBIN", "8")))
         mdist.run(ss, steps)
+        if ss.transport == "torch":
+            print(f"dist[{scene_name}] rank {rank}: {ss.resorts} collective re-sorts in {steps} substeps", flush=True)
+            st = ss.sim.solver.stats()
+            ok &= st["n_dropped"] == 0
         got = mdist.gather_positions(ss)
         parts = [None] * world
         dist.gather_object(got, parts if rank == 0 else None, dst=0)

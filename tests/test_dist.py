@@ -63,6 +63,31 @@ def test_sharded_ghost_resync_at_resort():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene,steps", [("fastcube", 200), ("sheet", 60)])
+def test_sharded_adaptive_collective_resort(scene, steps):
+    """rebin_interval = 0: the ranks re-sort together when the max-reduced early-warning drift flag asks for it (polled
+    every 16 substeps).  The thrown cube needs several re-sorts in 200 substeps, the resting sheet only the first one;
+    both must match the single context and drop nothing."""
+    import re
+    out = _launch(2, "gpu", scene, steps, extra_env={"MPMHIP_TEST_REBIN": "0"})
+    assert "max rel dx" in out
+    n = [int(x) for x in re.findall(r"rank \d+: (\d+) collective re-sorts", out)]
+    assert len(n) == 2 and n[0] == n[1]                 # every rank took the same decisions
+    assert (n[0] >= 3) if scene == "fastcube" else (n[0] <= 2)
+
+
+@pytest.mark.gpu
+def test_in_library_rccl_transport_single_rank_adaptive():
+    """The same policy inside the library's RCCL loop (ncclAllReduce of the flag, read back with a lag), world size 1."""
+    env = dict(os.environ, MPMHIP_DIST_TRANSPORT="rccl", MPMHIP_TEST_REBIN="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "gpu", "fastcube", "200"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "max rel dx" in r.stdout
+
+
+@pytest.mark.gpu
 def test_in_library_rccl_transport_single_rank():
     """World size 1 through the library's own RCCL communicator (dlopen, ncclCommInitRank, ncclAllGather of the block
     map, empty send/recv groups) -- the multi-rank send/recv itself cannot run on a one-GPU box."""
