@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--rebin-interval", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-phase HIP-event pass")
+    ap.add_argument("--force-dist", action="store_true", help="diagnostics: run the sharded driver even with one rank "
+                    "(launch under torch.distributed.run --nproc-per-node 1)")
     args = ap.parse_args()
 
     import torch
@@ -110,7 +112,8 @@ def main():
     dev = f"cuda:{local_rank}"
 
     sc = scenes.REGISTRY[args.scene]()
-    if world > 1:
+    sharded = world > 1 or args.force_dist
+    if sharded:
         import torch.distributed as dist
         from mpmavatar_amd import dist as mdist
         backend = os.environ.get("MPMHIP_DIST_BACKEND", "nccl")  # "gloo": host-staged exchange (2 ranks on 1 GPU tests)
@@ -137,7 +140,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
@@ -153,7 +156,7 @@ def main():
                    "exchange": transport},
     }
 
-    if world == 1:
+    if not sharded:
         sv = sim.solver
         st = sv.stats()
         n_act, n_col, n_mov = st["n_active_nodes"], st["n_collider_nodes"], st["n_mover_nodes"]
@@ -191,7 +194,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(sc)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         dist.destroy_process_group()
 
