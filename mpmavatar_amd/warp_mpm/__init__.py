@@ -3,7 +3,7 @@
 Same module, class and method names as /root/reference/warp_mpm/{mpm_solver,mpm_data_structure,warp_utils}.py;
 see INTEGRATION.md for the three-line change in the reference drivers.
 """
-from .mpm_data_structure import MPMModelStruct, MPMStateStruct  # noqa: F401
+from .mpm_data_structure import MPMModelStruct, MPMSmallStateStruct, MPMStateStruct  # noqa: F401
 from .mpm_solver import MPMWARP  # noqa: F401
 from .warp_utils import from_torch_safe, to_torch  # noqa: F401
 

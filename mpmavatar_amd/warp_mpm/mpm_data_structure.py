@@ -239,6 +239,44 @@ class MPMStateStruct(_Tracked):
         new_state.init_grid(grid_res=self.grid_res, device=device, requires_grad=requires_grad)
         return new_state
 
+    # mpm_data_structure.py:523-530
+    def to_small_state(self, device="cuda:0", requires_grad=True):
+        small_state = MPMSmallStateStruct()
+        small_state.init(self.n_particles, self.n_elements, self.n_vertices, device=device, requires_grad=requires_grad)
+        small_state.set_require_grad(requires_grad=requires_grad)
+        return small_state
+
+
+class MPMSmallStateStruct:
+    """mpm_data_structure.py:533-607: the reduced state (x, v, C, d) the reference's differentiable kernels write into.
+    Nothing on the substep path reads it (those kernels are dead in both drivers); kept so that
+    ``MPMStateStruct.to_small_state`` / ``to_large_state`` callers keep working."""
+
+    def init(self, n_particles: int, n_elements: int, n_vertices: int, device=None, requires_grad=False) -> None:
+        dev = _dev(device)
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+        self.particle_x, self.particle_v = z(n_particles, 3), z(n_particles, 3)
+        self.particle_C, self.particle_d = z(n_particles, 3, 3), z(n_elements, 3, 3)
+
+    def set_require_grad(self, requires_grad=True):  # :567-572, forward-only solver
+        return None
+
+    def to_large_state(self, mpm_state: "MPMStateStruct", device="cuda:0", requires_grad=True):
+        """:574-607 (the reference builds the state and drops it: no return statement; returned here).  copy_state
+        (:982-993): x, v, C for every particle, d and R_inv for the elements."""
+        new_state = mpm_state.partial_clone(device=device, requires_grad=requires_grad)
+        for name in ("particle_D_inv", "faces"):
+            new_state._raw(name).copy_(mpm_state._raw(name))
+        n_e = self.particle_d.shape[0]
+        new_state._raw("particle_x").copy_(self.particle_x)
+        new_state._raw("particle_v").copy_(self.particle_v)
+        new_state._raw("particle_C").copy_(self.particle_C.reshape(new_state._raw("particle_C").shape))
+        if n_e:
+            new_state._raw("particle_d").copy_(self.particle_d.reshape(new_state._raw("particle_d").shape))
+            new_state._raw("particle_R_inv").copy_(mpm_state._raw("particle_R_inv"))
+        new_state._raw("vertex_force").zero_()
+        return new_state
+
 
 class MPMModelStruct(_Tracked):
     _fields = ("E", "nu", "mu", "lam", "gamma", "kappa", "yield_stress")

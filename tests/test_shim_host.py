@@ -117,3 +117,24 @@ def test_icosphere_is_closed_and_outward():
     c = V[F].mean(1) - 1.0
     assert ((n * c).sum(1) > 0).all()
     assert math.isclose(np.linalg.norm(V - 1.0, axis=1).max(), 0.5, rel_tol=1e-5)
+
+
+def test_small_state_round_trip():
+    """to_small_state / MPMSmallStateStruct.to_large_state (mpm_data_structure.py:523-607): the reduced state has x, v,
+    C for every particle and d for the elements; going back copies those and the static fields (vol, density, mass,
+    selection, D_inv, faces, R_inv), zeroes vertex_force and gives the new state its own grid size."""
+    from mpmavatar_amd.warp_mpm import MPMSmallStateStruct
+    st, _ = make_state()
+    small = st.to_small_state(device="cpu")
+    assert isinstance(small, MPMSmallStateStruct)
+    assert small.particle_x.shape == (12, 3) and small.particle_C.shape == (12, 3, 3) and small.particle_d.shape == (4, 3, 3)
+    assert float(small.particle_x.abs().sum()) == 0.0
+    small.particle_x.copy_(torch.rand(12, 3)); small.particle_v.copy_(torch.rand(12, 3))
+    small.particle_C.copy_(torch.rand(12, 3, 3)); small.particle_d.copy_(torch.rand(4, 3, 3))
+    big = small.to_large_state(st, device="cpu")
+    assert torch.equal(big.particle_x, small.particle_x) and torch.equal(big.particle_v, small.particle_v)
+    assert torch.equal(big.particle_C.reshape(12, 3, 3), small.particle_C)
+    assert torch.equal(big.particle_d.reshape(4, 3, 3), small.particle_d)
+    for name in ("particle_vol", "particle_mass", "particle_density", "particle_selection", "particle_D_inv", "faces", "particle_R_inv"):
+        assert torch.equal(getattr(big, name), getattr(st, name)), name
+    assert float(big.vertex_force.abs().sum()) == 0.0 and big.grid_res == st.grid_res
