@@ -95,7 +95,7 @@ class TwinMPM:
         self.has_collider = sc.mesh_vertices is not None
         self.has_mover = sc.num_joint_v > 0 or sc.num_joint_f > 0
         self.njv, self.njf = sc.num_joint_v, sc.num_joint_f
-        self.bcs = list(sc.bcs)
+        self.bcs = [(k, dict(v)) for k, v in sc.bcs]   # own copies: a moving cuboid updates its point
         self.time = 0.0
         G3 = self.G ** 3
         self.grid_m = np.zeros(G3)
@@ -297,9 +297,21 @@ class TwinMPM:
         t = np.float32(self.time)
         for kind, kw in self.bcs:
             st, en = kw.get("start_time", 0.0), kw.get("end_time", 999.0)
-            if not (t >= np.float32(st) and t < np.float32(en)):
-                continue
+            inside = bool(t >= np.float32(st) and t < np.float32(en))
             V = self.grid_v_out.reshape(G, G, G, 3)
+            if kind == "velocity_cuboid":   # set_velocity_on_cuboid + host-side modify, mpm_solver.py:929-984
+                if inside:
+                    ii = np.stack(np.meshgrid(np.arange(G), np.arange(G), np.arange(G), indexing="ij"), -1)
+                    pos = (ii.astype(np.float32) * np.float32(self.dx)).astype(np.float32)   # node position as the fp32 kernels see it
+                    off = np.abs((pos - np.asarray(kw["point"], np.float32)).astype(np.float32))
+                    box = (off < np.asarray(kw["size"], np.float32)).all(-1)
+                    V[box] = np.asarray(kw["velocity"], np.float64)
+                    kw["point"] = [float(np.float32(p) + np.float32(dt) * np.float32(u)) for p, u in zip(kw["point"], kw["velocity"])]
+                elif int(kw.get("reset", 0)) == 1 and t < np.float32(en) + np.float32(15.0) * np.float32(dt):
+                    V[...] = 0.0
+                continue
+            if not inside:
+                continue
             if kind == "bounding_box":
                 pad = 3
                 for a in range(3):
@@ -312,7 +324,13 @@ class TwinMPM:
                 ii = np.stack(np.meshgrid(np.arange(G), np.arange(G), np.arange(G), indexing="ij"), -1)
                 off = ii * self.dx - np.asarray(kw["point"], np.float64)
                 below = (off * nrm).sum(-1) < 0
-                V[below] = 0.0  # quirk Q1: every non-'cut' surface type ends up writing zero
+                if kw.get("surface", "sticky") == "cut":   # surface_type 11, mpm_solver.py:614-622
+                    z = ii[..., 2] * self.dx
+                    keep = below & (z >= 0.4) & (z <= 0.53)
+                    V[keep] = V[keep] * np.array([0.3, 0.0, 0.3])
+                    V[below & ~keep] = 0.0
+                else:
+                    V[below] = 0.0  # quirk Q1: every other surface type ends up writing zero
             else:
                 raise NotImplementedError(kind)
 

@@ -71,3 +71,26 @@ def test_openmp_build_matches_serial(oracle_lib):
     run_scene(a, sc, 10)
     run_scene(b, sc, 10)
     assert rel(b.x, a.x) < 1e-6 and rel(b.v, a.v) < 1e-3
+
+
+@pytest.mark.parametrize("surface", ["sticky", "cut"])
+def test_moving_cuboid_with_reset_and_plane_kinds(surface, oracle_lib):
+    """Grid BCs the twin states independently: a velocity cuboid that drags part of a cube along, moves with its own
+    velocity (host-side modify, mpm_solver.py:975-981), ends and zeroes the whole grid for 15 more substeps (reset = 1,
+    :968-970), over a plane of kind 'sticky' / 'cut' (:600-655; the cut band keeps 0.3 * (vx, 0, vz) for 0.4 <= z <= 0.53)."""
+    sc = scenes.small_cube(n=6)
+    lo = float(sc.x[:, 1].min())
+    c = sc.x.mean(0)
+    sc.bcs = [("bounding_box", {}),
+              ("surface_collider", {"point": [0.0, lo + 0.02, 0.0], "normal": [0.0, 1.0, 0.0], "surface": surface, "friction": 0.0}),
+              ("velocity_cuboid", {"point": [float(c[0]) + 0.013, float(c[1]) + 0.011, float(c[2]) + 0.007], "size": [0.04, 0.2, 0.2],
+                                   "velocity": [0.6, 0.0, 0.2], "start_time": 0.0, "end_time": 0.0015, "reset": 1})]
+    o, t = oracle_from_scene(sc), TwinMPM(sc)
+    seen_drag = seen_zero = False
+    for k in range(45):   # 15 substeps in the window, 15 of zeroed grid, 15 free
+        run_scene(o, sc, 1, k0=k); run_scene(t, sc, 1, k0=k)
+        assert rel(o.x, t.x) < 1e-5, k
+        assert np.abs(np.asarray(o.v, np.float64) - t.v).max() < 2e-4 * max(np.abs(t.v).max(), 0.1), k
+        seen_drag |= 2 <= k < 14 and np.abs(t.v[:, 0]).max() > 0.5
+        seen_zero |= 16 <= k < 29 and np.abs(t.v).max() == 0.0
+    assert seen_drag and seen_zero and np.abs(t.v).max() > 0.0

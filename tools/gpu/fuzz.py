@@ -69,6 +69,14 @@ for case in range(n_cases):
         from oracle.scene_adapter import oracle_from_scene, run_scene
         print("  scene:", kind, "bcs", sc.bcs, "params", sc.params, "env", {k: os.environ[k] for k in ("MPMHIP_FUSE_GRID", "MPMHIP_FUSE_TRAD", "MPMHIP_PREDICTIVE_SORT")}, flush=True)
         o = oracle_from_scene(sc); run_scene(o, sc, steps)
+        if os.environ.get("FUZZ_CPU_TWIN"):   # no GPU: how far apart are the fp32 oracle and the float64 twin on this case?
+            from oracle.twin import TwinMPM
+            tw = TwinMPM(sc); o3 = oracle_from_scene(sc)
+            for k in range(steps):
+                run_scene(tw, sc, 1, k0=k); run_scene(o3, sc, 1, k0=k)
+                if k < 6 or k % 8 == 0 or k == steps - 1:
+                    print(f"    step {k + 1}: oracle-twin dx {rel(o3.x, tw.x):.1e} dv {rel(o3.v, tw.v):.1e}  max|v| {np.abs(tw.v).max():.2f}", flush=True)
+            sys.exit(0)
         if os.environ.get("FUZZ_TRACE"):   # step-by-step divergence of the baseline back end from the oracle
             o2 = oracle_from_scene(sc)
             tb = harness.build_solver(sc, "cuda:0", mode="baseline")
