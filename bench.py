@@ -85,6 +85,17 @@ def cpu_baseline(sc, budget_s=20.0):
 
 
 def main():
+    # stdout carries exactly one line (the JSON result); everything else this process prints -- the shim repeats the
+    # reference's "Particles initialized from torch data." messages -- goes to stderr
+    real_stdout = sys.stdout
+    sys.stdout = sys.stderr
+    try:
+        _main(real_stdout)
+    finally:
+        sys.stdout = real_stdout
+
+
+def _main(out_stream):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -193,7 +204,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sc)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=out_stream, flush=True)
     if sharded:
         import torch.distributed as dist
         dist.destroy_process_group()
