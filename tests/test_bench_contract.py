@@ -1,0 +1,47 @@
+"""bench.py's output contract: exactly one JSON line on stdout with the driver's keys, the `roofline` and `cpu_baseline`
+objects at N = 1.  CPU: the committed line of the last profile.  GPU: a short live run on the small cube."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": float,
+        "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict}
+
+
+def _check(o, n_gpus=1, with_cpu=True):
+    for k, t in KEYS.items():
+        assert k in o and isinstance(o[k], t), (k, o.get(k))
+    assert "vs_baseline" in o and o["vs_baseline"] is None          # BASELINE.md publishes no number for this metric
+    assert o["unit"] == "substeps/s" and o["higher_is_better"] is True and o["scaling"] == "strong" and o["data"] == "synthetic"
+    assert o["n_gpus"] == n_gpus and "workload" in o["config"] and "model" not in o["config"]
+    assert abs(o["value"] - 1e3 / o["ms_per_step"]) < 1e-6 * o["value"]
+    if n_gpus == 1:
+        r = o["roofline"]
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+        assert r["traffic"] is None or r["traffic"] > 0
+        if with_cpu:
+            c = o["cpu_baseline"]
+            assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "substeps/s" and c["sample"]
+
+
+def test_committed_bench_line_follows_the_contract():
+    lines = [l for l in open(os.path.join(ROOT, "profiles", "r01f_bench_fast.json")).read().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    o = json.loads(lines[0])
+    _check(o)
+    assert o["config"]["workload"] == "sheet-500k" and o["config"]["n_particles"] == 497762 and o["config"]["n_grid"] == 256
+
+
+@pytest.mark.gpu
+def test_live_bench_prints_exactly_one_json_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scene", "cube-8k", "--steps", "40", "--warmup", "10",
+                        "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(out) == 1, r.stdout[:500]
+    _check(json.loads(out[0]), with_cpu=False)
