@@ -1022,11 +1022,11 @@ __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p
     V3 S0 = col0(q.Sdt), S1 = col1(q.Sdt), S2 = col2(q.Sdt);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      float wx = sel3(i, st.w0.x, st.w1.x, st.w2.x), dwx = sel3(i, st.dw0.x, st.dw1.x, st.dw2.x);
+      float wx = sel3(i, st.w0.x, st.w1.x, st.w2.x), dwx = (i == 0 ? st.fx.x - 1.5f : (i == 1 ? 2.0f - 2.0f * st.fx.x : st.fx.x - 0.5f));
       V3 Bi = q.a0 + (float)i * Cx;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        float wy = sel3(j, st.w0.y, st.w1.y, st.w2.y), dwy = sel3(j, st.dw0.y, st.dw1.y, st.dw2.y);
+        float wy = sel3(j, st.w0.y, st.w1.y, st.w2.y), dwy = (j == 0 ? st.fx.y - 1.5f : (j == 1 ? 2.0f - 2.0f * st.fx.y : st.fx.y - 0.5f));
         float wxy = wx * wy, wxym = wxy * q.mass;
         V3 Bij = Bi + (float)j * Cy;
         V3 T = wxym * Bij + ((dwx * wy) * S0 + (wx * dwy) * S1 + wxy * q.vfdt);
@@ -1034,7 +1034,7 @@ __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p
         V3 Q = wxy * S2;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          float wzk = sel3(k, st.w0.z, st.w1.z, st.w2.z), dwzk = sel3(k, st.dw0.z, st.dw1.z, st.dw2.z);
+          float wzk = sel3(k, st.w0.z, st.w1.z, st.w2.z), dwzk = (k == 0 ? st.fx.z - 1.5f : (k == 1 ? 2.0f - 2.0f * st.fx.z : st.fx.z - 0.5f));
           float wm = wxym * wzk;
           if (k > 0) T = T + dT;
           V3 add = wzk * T + dwzk * Q;
