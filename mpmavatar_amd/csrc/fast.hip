@@ -1022,11 +1022,11 @@ __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p
     V3 S0 = col0(q.Sdt), S1 = col1(q.Sdt), S2 = col2(q.Sdt);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      float wx = sel3(i, st.w0.x, st.w1.x, st.w2.x), dwx = (i == 0 ? st.fx.x - 1.5f : (i == 1 ? 2.0f - 2.0f * st.fx.x : st.fx.x - 0.5f));
+      float wx = (i == 0 ? 0.5f * (1.5f - st.fx.x) * (1.5f - st.fx.x) : (i == 1 ? 0.75f - (st.fx.x - 1.0f) * (st.fx.x - 1.0f) : 0.5f * (st.fx.x - 0.5f) * (st.fx.x - 0.5f))), dwx = (i == 0 ? st.fx.x - 1.5f : (i == 1 ? 2.0f - 2.0f * st.fx.x : st.fx.x - 0.5f));
       V3 Bi = q.a0 + (float)i * Cx;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        float wy = sel3(j, st.w0.y, st.w1.y, st.w2.y), dwy = (j == 0 ? st.fx.y - 1.5f : (j == 1 ? 2.0f - 2.0f * st.fx.y : st.fx.y - 0.5f));
+        float wy = (j == 0 ? 0.5f * (1.5f - st.fx.y) * (1.5f - st.fx.y) : (j == 1 ? 0.75f - (st.fx.y - 1.0f) * (st.fx.y - 1.0f) : 0.5f * (st.fx.y - 0.5f) * (st.fx.y - 0.5f))), dwy = (j == 0 ? st.fx.y - 1.5f : (j == 1 ? 2.0f - 2.0f * st.fx.y : st.fx.y - 0.5f));
         float wxy = wx * wy, wxym = wxy * q.mass;
         V3 Bij = Bi + (float)j * Cy;
         V3 T = wxym * Bij + ((dwx * wy) * S0 + (wx * dwy) * S1 + wxy * q.vfdt);
