@@ -1022,11 +1022,13 @@ __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p
     V3 S0 = col0(q.Sdt), S1 = col1(q.Sdt), S2 = col2(q.Sdt);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      float wx = (i == 0 ? 0.5f * (1.5f - st.fx.x) * (1.5f - st.fx.x) : (i == 1 ? 0.75f - (st.fx.x - 1.0f) * (st.fx.x - 1.0f) : 0.5f * (st.fx.x - 0.5f) * (st.fx.x - 0.5f))), dwx = (i == 0 ? st.fx.x - 1.5f : (i == 1 ? 2.0f - 2.0f * st.fx.x : st.fx.x - 0.5f));
+      // x / y weights and all derivatives are recomputed from the fractional offsets where they are used: keeping the
+      // stencil's 18 values live through the loop nest costs 12-16 VGPRs, i.e. a wavefront per SIMD
+      float wx = bspline_w(i, st.fx.x), dwx = bspline_dw(i, st.fx.x);
       V3 Bi = q.a0 + (float)i * Cx;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        float wy = (j == 0 ? 0.5f * (1.5f - st.fx.y) * (1.5f - st.fx.y) : (j == 1 ? 0.75f - (st.fx.y - 1.0f) * (st.fx.y - 1.0f) : 0.5f * (st.fx.y - 0.5f) * (st.fx.y - 0.5f))), dwy = (j == 0 ? st.fx.y - 1.5f : (j == 1 ? 2.0f - 2.0f * st.fx.y : st.fx.y - 0.5f));
+        float wy = bspline_w(j, st.fx.y), dwy = bspline_dw(j, st.fx.y);
         float wxy = wx * wy, wxym = wxy * q.mass;
         V3 Bij = Bi + (float)j * Cy;
         V3 T = wxym * Bij + ((dwx * wy) * S0 + (wx * dwy) * S1 + wxy * q.vfdt);
@@ -1034,7 +1036,7 @@ __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p
         V3 Q = wxy * S2;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          float wzk = sel3(k, st.w0.z, st.w1.z, st.w2.z), dwzk = (k == 0 ? st.fx.z - 1.5f : (k == 1 ? 2.0f - 2.0f * st.fx.z : st.fx.z - 0.5f));
+          float wzk = sel3(k, st.w0.z, st.w1.z, st.w2.z), dwzk = bspline_dw(k, st.fx.z);
           float wm = wxym * wzk;
           if (k > 0) T = T + dT;
           V3 add = wzk * T + dwzk * Q;

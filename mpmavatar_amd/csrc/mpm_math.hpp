@@ -400,6 +400,12 @@ __device__ __forceinline__ Stencil make_stencil(V3 x, float inv_dx) {
   return s;
 }
 __device__ __forceinline__ float sel3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
+// weight of stencil node i (compile-time 0..2) at fractional offset f, and its derivative: the values make_stencil
+// stores, recomputed where a kernel would otherwise keep nine of them in registers for a whole loop nest
+__device__ __forceinline__ float bspline_w(int i, float f) {
+  return i == 0 ? 0.5f * (1.5f - f) * (1.5f - f) : (i == 1 ? 0.75f - (f - 1.0f) * (f - 1.0f) : 0.5f * (f - 0.5f) * (f - 0.5f));
+}
+__device__ __forceinline__ float bspline_dw(int i, float f) { return i == 0 ? f - 1.5f : (i == 1 ? 2.0f - 2.0f * f : f - 0.5f); }
 
 // body-mesh vertex i at this substep: x + adv*v with the multiply and the add rounded separately (the caller's
 // torch expression mesh_x + f*mesh_v, train_material_params.py:623)
