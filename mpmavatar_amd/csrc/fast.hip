@@ -565,7 +565,6 @@ __device__ __forceinline__ bool splat_ok(int G, const Stencil &s) {
 // face that drifted out of its tile margin since the last re-sort falls back to global atomics.
 // (Tried and dropped: gathering the faces per node block inside the grid stage -- no atomics at all, but the few
 // wavefronts next to the body serialise ~50 faces x 60 dependent instructions each and set the kernel's tail.)
-constexpr int COL_CH = 7;
 
 __device__ __forceinline__ int face_block(V3 fp, const Dims &d) {
   int bx = (int)(fp.x * d.inv_dx - 0.5f), by = (int)(fp.y * d.inv_dx - 0.5f), bz = (int)(fp.z * d.inv_dx - 0.5f);
@@ -2255,7 +2254,6 @@ static int step_phase_c(mpmhip_ctx *c, const StepArgs &a) {
   hipStream_t s = c->stream;
   int rc;
   (void)rc; (void)d; (void)s;
-  Bufs &b = f->buf[f->cur];
   {
     ScopedPhase ph(c, "g2p_e");
     // unprofiled: deferred into the next substep's stress kernel (k_stress_elem<true>); multi-GPU ranks have unpacked
