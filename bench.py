@@ -45,7 +45,7 @@ def phase_bytes(sc, n_active, n_coll, n_mov):
 
 # kernels of the fused substep loop per reference phase (rocprofv3 names without template arguments, except where the
 # argument selects the fused form; k_g2p<true> also does the grid stage)
-PHASE_KERNELS = {"p2g": ["k_p2g"], "g2p_v": ["k_g2p<true>"], "grid_update": ["k_grid<true>"],
+PHASE_KERNELS = {"p2g": ["k_p2g"], "g2p_v": ["k_g2p"], "grid_update": ["k_grid<true>"],
                  "compute_stress_from_F_trial": ["k_stress_elem<true>", "k_stress_trad"], "g2p_e": ["k_elem_finalize"]}
 
 
