@@ -2351,7 +2351,7 @@ static int step_phase_c(mpmhip_ctx *c, const StepArgs &a) {
     // unprofiled: deferred into the next substep's stress kernel (k_stress_elem<true>); multi-GPU ranks have unpacked
     // their ghost vertices by now, so the same holds there
     f->elem_pending = d.n_e > 0;
-    if (c->profiling) flush_elements(c);
+    if (c->profiling || (f->g.dbg & 64)) flush_elements(c);
   }
   f->steps_since_rebin += 1;
   if (!f->dist && !f->flag_pending && (f->steps_since_rebin & f->poll_mask) == 0) {

@@ -297,25 +297,37 @@ struct QR3 {
   float r00, r01, r02, r11, r12, r22;
 };
 
+// The return mapping below branches on r22 > 1 and on a friction threshold, and a flat garment sits exactly on the
+// first: these two functions are compiled without FMA contraction so that every kernel that inlines them (fused and
+// stand-alone element finalize, both back ends) takes the same branch on the same input, whatever the surrounding
+// code lets the compiler fuse (needs -ffp-contract=fast-honor-pragmas, see build.py).
 __device__ __forceinline__ QR3 qr_cloth(const M3 &d) {
+#pragma clang fp contract(off)
+  // (written out: the pragma covers this body, not the bodies of dot / length / cross / operator*)
   V3 d0 = col0(d), d1 = col1(d), d2 = col2(d);
   QR3 o;
-  o.r00 = length(d0);
-  o.q0 = (1.0f / o.r00) * d0;
-  o.r01 = dot(o.q0, d1);
-  V3 u1 = d1 - o.r01 * o.q0;
-  o.r11 = length(u1);
-  o.q1 = (1.0f / o.r11) * u1;
-  o.q2 = cross(o.q0, o.q1);
-  o.r02 = dot(o.q0, d2);
-  o.r12 = dot(o.q1, d2);
-  o.r22 = dot(o.q2, d2);
+  o.r00 = sqrtf((d0.x * d0.x + d0.y * d0.y) + d0.z * d0.z);
+  float i0 = 1.0f / o.r00;
+  o.q0 = v3(i0 * d0.x, i0 * d0.y, i0 * d0.z);
+  o.r01 = (o.q0.x * d1.x + o.q0.y * d1.y) + o.q0.z * d1.z;
+  float ax = o.r01 * o.q0.x, ay = o.r01 * o.q0.y, az = o.r01 * o.q0.z;
+  V3 u1 = v3(d1.x - ax, d1.y - ay, d1.z - az);
+  o.r11 = sqrtf((u1.x * u1.x + u1.y * u1.y) + u1.z * u1.z);
+  float i1 = 1.0f / o.r11;
+  o.q1 = v3(i1 * u1.x, i1 * u1.y, i1 * u1.z);
+  float c0a = o.q0.y * o.q1.z, c0b = o.q0.z * o.q1.y, c1a = o.q0.z * o.q1.x, c1b = o.q0.x * o.q1.z;
+  float c2a = o.q0.x * o.q1.y, c2b = o.q0.y * o.q1.x;
+  o.q2 = v3(c0a - c0b, c1a - c1b, c2a - c2b);
+  o.r02 = (o.q0.x * d2.x + o.q0.y * d2.y) + o.q0.z * d2.z;
+  o.r12 = (o.q1.x * d2.x + o.q1.y * d2.y) + o.q1.z * d2.z;
+  o.r22 = (o.q2.x * d2.x + o.q2.y * d2.y) + o.q2.z * d2.z;
   return o;
 }
 
 // returns the new third director d3 (columns d1,d2 are unchanged)
 __device__ __forceinline__ V3 anisotropy_return_mapping(const QR3 &q, float gamma, float kappa, float friction_coeff,
                                                         float &r02, float &r12, float &r22) {
+#pragma clang fp contract(off)
   r02 = q.r02; r12 = q.r12; r22 = q.r22;
   if (q.r22 > 1.0f) {
     r22 = 1.0f;
@@ -327,7 +339,10 @@ __device__ __forceinline__ V3 anisotropy_return_mapping(const QR3 &q, float gamm
       r12 = q.r12 * friction_coeff * fn / ff;
     }
   }
-  return r02 * q.q0 + r12 * q.q1 + r22 * q.q2;
+  float ax = r02 * q.q0.x, ay = r02 * q.q0.y, az = r02 * q.q0.z;
+  float bx = r12 * q.q1.x, by = r12 * q.q1.y, bz = r12 * q.q1.z;
+  float cx = r22 * q.q2.x, cy = r22 * q.q2.y, cz = r22 * q.q2.z;
+  return v3((ax + bx) + cx, (ay + by) + cy, (az + bz) + cz);
 }
 
 // Given the QR of the *mapped* d (q0,q1,q2 unchanged by the return mapping because d1,d2 are;

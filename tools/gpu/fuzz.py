@@ -60,6 +60,8 @@ for case in range(n_cases):
     os.environ["MPMHIP_FUSE_GRID"] = str(int(rng.random() < 0.8))
     os.environ["MPMHIP_FUSE_TRAD"] = str(int(rng.random() < 0.8))
     os.environ["MPMHIP_PREDICTIVE_SORT"] = str(int(rng.random() < 0.8))
+    for kv in os.environ.get("FUZZ_ENV", "").split():   # replay with some switches forced, e.g. FUZZ_ENV="MPMHIP_FUSE_GRID=0"
+        k, v = kv.split("="); os.environ[k] = v
     sc.dt = 1e-4 * dt_scale
     if kind != "blob" and dt_scale > 3: sc.dt = 3e-4
     fused = bool(rng.random() < 0.7)
@@ -77,9 +79,48 @@ for case in range(n_cases):
                 if k < 6 or k % 8 == 0 or k == steps - 1:
                     print(f"    step {k + 1}: oracle-twin dx {rel(o3.x, tw.x):.1e} dv {rel(o3.v, tw.v):.1e}  max|v| {np.abs(tw.v).max():.2f}", flush=True)
             sys.exit(0)
+        if os.environ.get("FUZZ_TRACE") == "finalize":   # fused element finalize (in the stress kernel) vs the stand-alone kernel
+            for kk in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64):
+                if kk > steps: break
+                os.environ["MPMHIP_DBG"] = "0"; A = harness.build_solver(sc, "cuda:0", mode="fast", rebin_interval=-1000000); harness.run(A, kk, fused=True)
+                os.environ["MPMHIP_DBG"] = "64"; B = harness.build_solver(sc, "cuda:0", mode="fast", rebin_interval=-1000000); harness.run(B, kk, fused=True)
+                ne = sc.n_elements
+                f = lambda t, n: getattr(t.state, n).cpu().numpy().reshape(sc.n_particles if n != "particle_d" else ne, -1)
+                out = []
+                for n in ("particle_x", "particle_v", "particle_C", "particle_d"):
+                    a, b = f(A, n), f(B, n)
+                    d = np.abs(a - b).max(1)
+                    out.append(f"{n[9:]} max {d.max():.1e} at {int(d.argmax())}")
+                print(f"    after {kk} substeps: " + "; ".join(out), flush=True)
+            sys.exit(0)
+        if os.environ.get("FUZZ_TRACE") == "finalize2":
+            def run(dbg, kk):
+                os.environ["MPMHIP_DBG"] = dbg
+                t = harness.build_solver(sc, "cuda:0", mode="fast", rebin_interval=-1000000); harness.run(t, kk, fused=True)
+                return t.state.particle_d.cpu().numpy().reshape(sc.n_elements, 9), t.state.particle_x.cpu().numpy()
+            for kk in (8, 9, 10, 11, 12):
+                A1, _ = run("0", kk); A2, _ = run("0", kk); B1, xb = run("64", kk); B2, _ = run("64", kk)
+                o4 = oracle_from_scene(sc); run_scene(o4, sc, kk)
+                od = np.asarray(o4.d).reshape(sc.n_elements, 9)
+                dd = np.abs(A1 - B1).max(1); e = int(dd.argmax())
+                print(f"    k={kk}: A1-A2 {np.abs(A1 - A2).max():.1e}  B1-B2 {np.abs(B1 - B2).max():.1e}  A1-B1 {dd.max():.1e} at {e}  A1-oracle {np.abs(A1 - od).max():.1e}  B1-oracle {np.abs(B1 - od).max():.1e}", flush=True)
+                print("       A d[e]:", np.round(A1[e], 5), "\n       B d[e]:", np.round(B1[e], 5), "\n       O d[e]:", np.round(od[e], 5), flush=True)
+            sys.exit(0)
+        if os.environ.get("FUZZ_TRACE") == "modes":   # how the same fast solver is driven
+            for label, drive in (("one fused call", lambda t: harness.run(t, steps, fused=True)),
+                                 ("per-step calls, no read-back", lambda t: harness.run(t, steps, fused=False)),
+                                 ("fused calls of 10 with a read-back in between", lambda t: [(harness.run(t, min(10, steps - k), fused=True), t.state.particle_x.sum().item()) for k in range(0, steps, 10)]),
+                                 ("fused calls of 10 + stats()", lambda t: [(harness.run(t, min(10, steps - k), fused=True), t.solver.stats()) for k in range(0, steps, 10)]),
+                                 ("fused calls of 10 + synchronize()", lambda t: [(harness.run(t, min(10, steps - k), fused=True), t.solver.synchronize()) for k in range(0, steps, 10)]),
+                                 ("fused calls of 10, no read-back", lambda t: [harness.run(t, min(10, steps - k), fused=True) for k in range(0, steps, 10)])):
+                t = harness.build_solver(sc, "cuda:0", mode="fast", rebin_interval=-1000000); drive(t)
+                st = t.solver.stats()
+                print(f"  {label:48s}: dx {rel(t.state.particle_x.cpu().numpy(), o.x):.1e} dv {rel(t.state.particle_v.cpu().numpy(), o.v):.1e} rebins {st['rebins']} fallback {st['n_fallback_particles']}", flush=True)
+            sys.exit(0)
         if os.environ.get("FUZZ_TRACE"):   # step-by-step divergence of the baseline back end from the oracle
             o2 = oracle_from_scene(sc)
-            tb = harness.build_solver(sc, "cuda:0", mode="baseline")
+            tb = (harness.build_solver(sc, "cuda:0", mode="fast", rebin_interval=-1000000) if os.environ["FUZZ_TRACE"] == "fast"
+                  else harness.build_solver(sc, "cuda:0", mode="baseline"))
             for k in range(steps):
                 run_scene(o2, sc, 1, k0=k); harness.run(tb, 1, fused=False)
                 if k == 0:
@@ -91,7 +132,7 @@ for case in range(n_cases):
                     for i, j, kk in np.argwhere(d > 1e-3)[:10]:
                         print("     node", (i, j, kk), "gpu", vo[i, j, kk], "oracle", og[i, j, kk], "m", om[i, j, kk])
                 if k < 12 or k % 8 == 0:
-                    print(f"    step {k + 1}: baseline-oracle dx {rel(tb.state.particle_x.cpu().numpy(), o2.x):.1e} dv {rel(tb.state.particle_v.cpu().numpy(), o2.v):.1e}", flush=True)
+                    print(f"    step {k + 1}: {tb.solver._mode if hasattr(tb.solver, '_mode') else ''} gpu-oracle dx {rel(tb.state.particle_x.cpu().numpy(), o2.x):.1e} dv {rel(tb.state.particle_v.cpu().numpy(), o2.v):.1e}", flush=True)
         for label, kw in (("fast adaptive", dict(mode="fast", rebin_interval=0)), ("fast single sort", dict(mode="fast", rebin_interval=-1000000)),
                           ("fast every 5", dict(mode="fast", rebin_interval=-5)), ("baseline", dict(mode="baseline"))):
             t = harness.build_solver(sc, "cuda:0", **kw); harness.run(t, steps, fused=fused)
