@@ -30,7 +30,7 @@ def _check(o, n_gpus=1, with_cpu=True):
 
 
 def test_committed_bench_line_follows_the_contract():
-    lines = [l for l in open(os.path.join(ROOT, "profiles", "r01h_bench_fast.json")).read().splitlines() if l.startswith("{")]
+    lines = [l for l in open(os.path.join(ROOT, "profiles", "r01i_bench_fast.json")).read().splitlines() if l.startswith("{")]
     assert len(lines) == 1
     o = json.loads(lines[0])
     _check(o)
