@@ -38,8 +38,8 @@ namespace mpm {
 namespace {
 
 constexpr int TPB = 256;
-constexpr int CHUNK = 256;     // particles of one block handled by one workgroup of p2g / g2p (192 measured: no gain on
-                               // the sheet, 8-10 % slower on the dense scenes)
+constexpr int CHUNK = 256;     // particles of one block handled by one workgroup of p2g / g2p (192, re-measured with
+                               // the 92/95-VGPR kernels: sheet -1 us, garment and dense scenes 15 % slower)
 constexpr int PT = CHUNK;      // threads of those workgroups (and of the extra workgroups riding in their launches)
 constexpr int TILE = 8;        // tile edge in nodes: block (4) + 1 below + 3 above
 constexpr int TILE3 = TILE * TILE * TILE;
