@@ -1723,6 +1723,7 @@ struct FastState {
   Dims d{};
   bool dist = false;  // multi-GPU: re-sorts only on request (all ranks re-sort together)
   bool dist_keep_cur = false;  // re-sort inside mpmhip_rccl_steps: the caller's mesh pointers are valid
+  bool g2p_two_pass = false;   // k_g2p<., true>: see there (default: scenes without traditional particles)
   // adaptive collective re-sorts (mpmhip_rccl_steps with rebin_interval <= 0): the ranks' drift flags are max-reduced
   // every DIST_POLL substeps and read DIST_LAG substeps later, so every rank takes the same decision at the same substep
   int dist_since = 0;
@@ -2086,6 +2087,8 @@ int fast_init(mpmhip_ctx *c) {
   f->g.ab_flag = f->ab_flag;
   if (const char *e = getenv("MPMHIP_DBG")) f->g.dbg = (int)strtoul(e, nullptr, 0);
   if (const char *e = getenv("MPMHIP_FUSE_GRID")) f->fuse_grid = atoi(e) != 0;
+  f->g2p_two_pass = cfg.n_particles - cfg.n_elements - cfg.n_vertices == 0;
+  if (const char *e = getenv("MPMHIP_G2P_TWO_PASS")) f->g2p_two_pass = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_FUSE_TRAD")) f->fuse_trad = atoi(e) != 0;
   MPM_HIP_CHECK(c, hipHostMalloc((void **)&f->h_pin, 64 * sizeof(int), hipHostMallocDefault));
   MPM_HIP_CHECK(c, hipEventCreateWithFlags(&f->ev_flag, hipEventDisableTiming));
@@ -2325,9 +2328,9 @@ static int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
     ScopedPhase ph(c, "g2p_v");
     if (f->n_chunks_g) {
       if (fused)
-        G2P_LAUNCH(true, d.n_t == 0, xcd_grid(f->n_chunks_g), PT, 0, s, b, f->chunks_g, f->n_chunks_g, d, dt, f->g, gp, bcl);
+        G2P_LAUNCH(true, f->g2p_two_pass, xcd_grid(f->n_chunks_g), PT, 0, s, b, f->chunks_g, f->n_chunks_g, d, dt, f->g, gp, bcl);
       else
-        G2P_LAUNCH(false, d.n_t == 0, xcd_grid(f->n_chunks_g), PT, 0, s, b, f->chunks_g, f->n_chunks_g, d, dt, f->g, gp, bcl);
+        G2P_LAUNCH(false, f->g2p_two_pass, xcd_grid(f->n_chunks_g), PT, 0, s, b, f->chunks_g, f->n_chunks_g, d, dt, f->g, gp, bcl);
     }
   }
   if (fused) {
