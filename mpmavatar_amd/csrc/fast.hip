@@ -334,7 +334,8 @@ struct GridPtrs {
   int *m_flag;      // [block] 1 = p2g (or a halo sum) may have written this block's mass / momentum this substep
   int *counters;    // [0] particles outside their tile margin, [1] dropped contributions (inactive block)
   int dbg;          // MPMHIP_DBG bitmask (perf experiments only, results are wrong): 1 skip p2g flush, 2 skip the p2g
-                    // scatter, 8 / 16 skip vertex-force / stress loads, 128 skip the LDS atomics only
+                    // scatter, 8 / 16 skip vertex-force / stress loads, 128 skip the LDS atomics only; 64 (results stay
+                    // right) runs the stand-alone element finalize every substep instead of fusing it into the stress kernel
 };
 
 struct GridParams {
