@@ -1767,8 +1767,33 @@ struct FastState {
   int64_t stat_steps = 0;
   int n_P = 0, n_A = 0, n_chunks = 0;
   int *h_pin = nullptr;  // pinned host scratch
-  std::vector<int> h_ranges, h_plist;
-  std::vector<ChunkRec> h_chunks, h_chunks_g;
+  // host staging of the re-sort in pinned memory: device->host copies really are asynchronous, and the chunk table can
+  // be uploaded without waiting for the copy (the next re-sort synchronises long before it touches the buffer again)
+  template <class T>
+  struct Pinned {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    bool reserve(size_t want) {
+      if (want <= cap) return true;
+      size_t nc = want + want / 2 + 256;
+      T *q = nullptr;
+      if (hipHostMalloc((void **)&q, nc * sizeof(T), hipHostMallocDefault) != hipSuccess) return false;
+      if (p) { memcpy(q, p, n * sizeof(T)); (void)hipHostFree(p); }
+      p = q; cap = nc;
+      return true;
+    }
+    bool resize(size_t want) { if (!reserve(want)) return false; n = want; return true; }
+    bool push_back(const T &v) { if (n == cap && !reserve(n + 1)) return false; p[n++] = v; return true; }
+    void clear() { n = 0; }
+    size_t size() const { return n; }
+    T *data() { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    T *begin() { return p; }
+    T *end() { return p + n; }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = cap = 0; }
+  };
+  Pinned<int> h_ranges, h_plist;
+  Pinned<ChunkRec> h_chunks, h_chunks_g;
   bool elem_pending = false;  // element finalise of the last substep still to be done (fused into the next stress)
   int steps_since_rebin = 0;
   hipEvent_t ev_flag = nullptr;
@@ -1839,6 +1864,22 @@ int scan_flags(mpmhip_ctx *c, const int *flag, int *index, int n, int *total) {
   MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 1, flag + (n - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
   *total = f->h_pin[0] + f->h_pin[1];
+  return MPMHIP_OK;
+}
+
+// the same scan without the wait: the two addends of the total land in h_pin[slot], h_pin[slot + 1] once the stream gets there
+int scan_flags_async(mpmhip_ctx *c, const int *flag, int *index, int n, int slot) {
+  FastState *f = c->fast;
+  size_t need = 0;
+  MPM_HIP_CHECK(c, rocprim::exclusive_scan(nullptr, need, flag, index, 0, (size_t)n, rocprim::plus<int>(), c->stream));
+  if (need > f->scan_tmp_bytes) {
+    MPM_HIP_CHECK(c, hipMalloc(&f->scan_tmp, need));
+    f->allocs.push_back(f->scan_tmp);
+    f->scan_tmp_bytes = need;
+  }
+  MPM_HIP_CHECK(c, rocprim::exclusive_scan(f->scan_tmp, need, flag, index, 0, (size_t)n, rocprim::plus<int>(), c->stream));
+  MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + slot, index + (n - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + slot + 1, flag + (n - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
   return MPMHIP_OK;
 }
 
@@ -1954,18 +1995,24 @@ int rebin(mpmhip_ctx *c) {
   hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, f->pb_flag, f->pb_index, nb, f->plist);
   hipLaunchKernelGGL(k_ranges, nblk(d.n_p), TPB, 0, s, skeys, d, f->blk_bits, f->pb_index, f->n_P, f->ranges);
   hipLaunchKernelGGL(k_dilate, nblk((size_t)f->n_P * 27), TPB, 0, s, f->plist, f->n_P, d.NB, f->ab_flag);
-  if ((rc = scan_flags(c, f->ab_flag, f->ab_index, nb, &f->n_A))) return rc;
-  if ((rc = ensure_cap(c, &f->alist, &f->cap_A, f->n_A, 1))) return rc;
+  // active-block count, block ranges and block ids come back in ONE wait (the list is sized by its upper bound)
+  if ((rc = scan_flags_async(c, f->ab_flag, f->ab_index, nb, 2))) return rc;
+  if ((rc = ensure_cap(c, &f->alist, &f->cap_A, (int)std::min<long long>((long long)nb, 27LL * f->n_P), 1))) return rc;
   hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, f->ab_flag, f->ab_index, nb, f->alist);
   // chunk records on the host from the compact ranges
-  f->h_ranges.resize((size_t)f->n_P * 10);
-  f->h_plist.resize((size_t)f->n_P);
+  if (!f->h_ranges.resize((size_t)f->n_P * 10) || !f->h_plist.resize((size_t)f->n_P))
+    return fail(c, MPMHIP_ERR_HIP, "re-sort: pinned host staging");
   MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_ranges.data(), f->ranges, (size_t)f->n_P * 10 * sizeof(int), hipMemcpyDeviceToHost, s));
   MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_plist.data(), f->plist, (size_t)f->n_P * sizeof(int), hipMemcpyDeviceToHost, s));
   MPM_HIP_CHECK(c, hipStreamSynchronize(s));
+  f->n_A = f->h_pin[2] + f->h_pin[3];
   // two lists: p2g walks the simulated particles of a block, g2p those plus the ghost copies (identical without ghosts)
   f->h_chunks.clear();
   f->h_chunks_g.clear();
+  {  // every block contributes at most tot / CHUNK + 1 records
+    size_t bound = (size_t)f->n_P + (size_t)d.n_p / CHUNK + 8;
+    if (!f->h_chunks.reserve(bound) || !f->h_chunks_g.reserve(bound)) return fail(c, MPMHIP_ERR_HIP, "re-sort: pinned host staging");
+  }
   bool any_ghost = false;
   for (int p = 0; p < f->n_P; ++p) {
     auto R = [&](int k) { return f->h_ranges[(size_t)k * f->n_P + p]; };
@@ -2000,7 +2047,6 @@ int rebin(mpmhip_ctx *c) {
   if (any_ghost)
     MPM_HIP_CHECK(c, hipMemcpyAsync(f->chunks + f->n_chunks, f->h_chunks_g.data(), f->h_chunks_g.size() * sizeof(ChunkRec),
                                     hipMemcpyHostToDevice, s));
-  MPM_HIP_CHECK(c, hipStreamSynchronize(s));  // the host vectors are pageable: the copies must finish before reuse
   if (!c->colliders.empty() && c->num_mesh_f) {
     int nf = c->num_mesh_f;
     hipLaunchKernelGGL(k_face_keys, nblk(nf), TPB, 0, s, c->cur_pts, c->cur_vel, c->cur_f, c->mesh_idx, nf, d, f->fkeys[0], f->fiota);
@@ -2102,6 +2148,7 @@ void fast_destroy(mpmhip_ctx *c) {
   if (f->rccl.comm) (void)f->rccl.CommDestroy(f->rccl.comm);
   for (void *p : f->allocs) (void)hipFree(p);
   if (f->h_pin) (void)hipHostFree(f->h_pin);
+  f->h_ranges.release(); f->h_plist.release(); f->h_chunks.release(); f->h_chunks_g.release();
   if (f->ev_flag) (void)hipEventDestroy(f->ev_flag);
   delete f;
   c->fast = nullptr;
