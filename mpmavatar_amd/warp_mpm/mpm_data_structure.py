@@ -143,6 +143,10 @@ class MPMStateStruct(_Tracked):
         print("Particles initialized from torch data.")
         print("Total particles: ", tensor_x.shape[0])
 
+    def set_particles(self, *args, **kwargs):
+        """BASELINE.json's prose name for ``from_torch`` (the reference itself has no such method)."""
+        return self.from_torch(*args, **kwargs)
+
     def _check_classes(self):
         """The kernels' launch ranges assume elements | traditional | vertices index blocks
         (mpm_solver.py:327-332,518-534); the flag arrays must agree with that layout."""
