@@ -10,9 +10,16 @@ A "step" is one substep (MPMWARP.p2g2p: stress -> p2g -> grid -> g2p) over the w
 HBM before the timed region.  N > 1 shards particles by spatial slab (strong scaling: total work fixed) with an
 RCCL halo exchange of the shared grid blocks after p2g (mpmavatar_amd/dist.py).
 
+With --gpus N > 1 and no launcher in the environment (WORLD_SIZE unset) the script starts the N ranks itself
+(torch.distributed.run, 127.0.0.1); on a box with fewer GPUs it stops with a message instead.
+
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  "roofline":     dominant kernel, algorithmic bytes per launch / HIP-event launch time vs 8 TB/s
-  "kernels":      the same for every phase of the substep
+  "roofline":     dominant kernel OF THE TIMED LOOP (HIP events around the fused launches, same kernels as the timed
+                  region), algorithmic bytes per launch / launch time vs 8 TB/s
+  "kernels":      every launch of the timed loop the same way ("kernels_mode": "fused-loop"), and
+  "phases":       the reference's phases, each as its own un-fused launch (time_profile keys of the reference)
+  "value_draped": the same rate after --advance more substeps (the sheet has draped over the sphere, moves fast,
+                  re-sorts often), with the re-sorts that fell into that window
   "cpu_baseline": the CPU oracle (restatement of the reference algorithm; the reference's Warp path cannot run
                   here) timed on this box's host cores on a bounded number of substeps of the same scene.
 """
@@ -45,6 +52,8 @@ def phase_bytes(sc, n_active, n_coll, n_mov):
 
 # kernels of the fused substep loop per reference phase (rocprofv3 names without template arguments, except where the
 # argument selects the fused form; k_g2p<true> also does the grid stage)
+FUSED_BYTES_NOTE = ("fused loop: k_stress_elem<true> also finalizes the previous substep's elements (g2p_e's x/v/d1/d2 part), "
+                    "k_g2p<true> also runs the grid stage; bytes are attributed to the launch that moves them")
 PHASE_KERNELS = {"p2g": ["k_p2g"], "g2p_v": ["k_g2p"], "grid_update": ["k_grid<true>"],
                  "compute_stress_from_F_trial": ["k_stress_elem<true>", "k_stress_trad"], "g2p_e": ["k_elem_finalize"]}
 
@@ -104,7 +113,9 @@ def _main(out_stream):
     ap.add_argument("--mode", default="fast", choices=["fast", "baseline"])
     ap.add_argument("--rebin-interval", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernels", action="store_true", help="skip the per-phase HIP-event pass")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the HIP-event passes")
+    ap.add_argument("--advance", type=int, default=2000, help="untimed substeps before the second (draped-state) measurement; "
+                    "0 = skip it")
     ap.add_argument("--force-dist", action="store_true", help="diagnostics: run the sharded driver even with one rank "
                     "(launch under torch.distributed.run --nproc-per-node 1)")
     args = ap.parse_args()
@@ -112,11 +123,32 @@ def _main(out_stream):
     import torch
     from mpmavatar_amd import harness, scenes
 
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs MI355X GPUs (the solver has no CPU path)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, RCCL)
+        shared = os.environ.get("MPMHIP_DIST_BACKEND") == "gloo"  # test mode: ranks may share a GPU
+        if torch.cuda.device_count() < args.gpus and not shared:
+            sys.exit(f"bench.py --gpus {args.gpus}: this box has {torch.cuda.device_count()} GPU(s); "
+                     "the sharded run needs one GPU per rank")
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            sys.exit(f"bench.py: the {args.gpus}-rank run failed (exit code {r.returncode})")
+        print(lines[-1], file=out_stream, flush=True)
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if os.environ.get("MPMHIP_DIST_BACKEND") == "gloo":
         local_rank = local_rank % torch.cuda.device_count()  # ranks may share a GPU in the gloo test mode
     torch.cuda.set_device(local_rank)
@@ -167,6 +199,19 @@ def _main(out_stream):
                    "exchange": transport},
     }
 
+    def timed(n):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(n)
+        torch.cuda.synchronize()
+        barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if sharded:
+            import torch.distributed as dist
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item())
+
     if not sharded:
         sv = sim.solver
         st = sv.stats()
@@ -177,30 +222,71 @@ def _main(out_stream):
                               "fallback_particles": st["n_fallback_particles"], "alg_bytes_per_substep": b_alg["substep"]})
         out["substep_GBps"] = b_alg["substep"] / (ms_per_step * 1e-3) / 1e9
         out["substep_frac_of_hbm_peak"] = out["substep_GBps"] / HBM_PEAK_GBS
-        if not args.no_kernels:
-            # per-phase launch durations: HIP events recorded on the solver's stream around each phase
-            sv.enable_profiling(True)
-            sv.time_profile.clear()
-            harness.run(sim, args.steps, fused=False)
-            sv.enable_profiling(False)
+        if not args.no_kernels and args.mode == "fast":
+            # (1) the launches of the timed loop itself: HIP events on the solver's stream around each fused launch
             pb = phase_bytes(sc, n_act, n_col, n_mov)
+            cloth = sc.n_elements > 0
+            fused_bytes = {
+                "compute_stress_from_F_trial": (188 + 60) * sc.n_elements + 12 * sc.n_vertices,       # + element finalize
+                "p2g": pb["p2g"] + 116 * sc.n_traditional + 28 * n_col + 16 * n_mov,                   # + trad. stress, splats
+                "g2p_v": pb["g2p_v"] + 28 * n_act + 40 * n_col + 16 * n_mov,                            # + grid stage
+            }
+            fused_kernel = {"compute_stress_from_F_trial": "k_stress_elem<true>", "p2g": "k_p2g", "g2p_v": "k_g2p", "rebin": "re-sort"}
+            sv.enable_profiling(True, fused=True)
+            sv.time_profile.clear()
+            harness.run(sim, args.steps, fused=True)
+            sv.enable_profiling(False)
             kernels = []
             for name, samples in sv.time_profile.items():
                 ms = sum(samples) / max(len(samples), 1)
+                k = {"name": fused_kernel.get(name, name), "phase": name, "ms": ms, "launches": len(samples)}
                 if name == "rebin":
-                    ms = sum(samples) / args.steps  # amortised
+                    k["ms_per_substep"] = sum(samples) / args.steps
+                if name in fused_bytes and ms > 0 and (cloth or name != "compute_stress_from_F_trial"):
+                    k["alg_bytes"] = fused_bytes[name]
+                    k["GBps"] = fused_bytes[name] / (ms * 1e-3) / 1e9
+                    k["frac"] = k["GBps"] / HBM_PEAK_GBS
+                    tr, src = pmc_traffic(name, args.scene)
+                    if tr:
+                        k["traffic"], k["traffic_GBps"], k["traffic_source"] = tr, tr / (ms * 1e-3) / 1e9, src
+                kernels.append(k)
+            sv.time_profile.clear()
+            out["kernels"], out["kernels_mode"], out["kernels_note"] = kernels, "fused-loop", FUSED_BYTES_NOTE
+            dom = max((k for k in kernels if "alg_bytes" in k), key=lambda k: k["ms"])
+            out["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": dom["frac"], "traffic": dom.get("traffic"),
+                               "traffic_source": dom.get("traffic_source"), "alg_bytes_per_launch": dom["alg_bytes"],
+                               "ms_per_launch": dom["ms"], "measured": "HIP events around the launch in the fused loop"}
+            # (2) the reference's phases, each as its own launch (what MPMWARP.time_profile reports)
+            sv.enable_profiling(True)
+            harness.run(sim, min(args.steps, 50), fused=False)
+            sv.enable_profiling(False)
+            phases = []
+            for name, samples in sv.time_profile.items():
+                ms = sum(samples) / max(len(samples), 1)
                 k = {"name": name, "ms": ms}
                 if name in pb and ms > 0:
-                    k["alg_bytes"] = pb[name]
-                    k["GBps"] = pb[name] / (ms * 1e-3) / 1e9
+                    k["alg_bytes"], k["GBps"] = pb[name], pb[name] / (ms * 1e-3) / 1e9
                     k["frac"] = k["GBps"] / HBM_PEAK_GBS
-                kernels.append(k)
-            out["kernels"] = kernels
-            dom = max((k for k in kernels if "alg_bytes" in k), key=lambda k: k["ms"])
-            traffic, src = pmc_traffic(dom["name"], args.scene)
-            out["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": dom["frac"], "traffic": traffic, "traffic_source": src,
-                               "alg_bytes_per_launch": dom["alg_bytes"], "ms_per_launch": dom["ms"]}
+                phases.append(k)
+            out["phases"], out["phases_mode"] = phases, "per-phase (un-fused launches, one sync each; not the timed loop)"
+    if args.advance > 0:
+        # the steady state: after `advance` more substeps the sheet lies draped over the sphere, moves at metres per second and
+        # the particle order is rebuilt every few dozen substeps; re-sorts inside the window are part of the number
+        run(args.advance)
+        n_d = max(args.steps, 200)
+        r0 = sim.solver.stats()["rebins"] if not sharded else None
+        el = timed(n_d)
+        out["value_draped"] = n_d / el
+        out["ms_per_step_draped"] = 1e3 * el / n_d
+        out["draped"] = {"advance": args.advance, "steps": n_d,
+                         "rebins_in_window": (sim.solver.stats()["rebins"] - r0) if not sharded else None}
+        if not sharded:
+            st = sim.solver.stats()
+            b_d = harness.algorithmic_bytes(sc, st["n_active_nodes"], st["n_collider_nodes"], st["n_mover_nodes"])
+            out["draped"].update({"n_active_nodes": st["n_active_nodes"], "n_collider_nodes": st["n_collider_nodes"],
+                                  "fallback_particles": st["n_fallback_particles"],
+                                  "substep_frac_of_hbm_peak": b_d["substep"] / (out["ms_per_step_draped"] * 1e-3) / 1e9 / HBM_PEAK_GBS})
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sc)
     if rank == 0:

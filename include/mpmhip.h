@@ -76,7 +76,8 @@ typedef struct {
   float *vertex_force;      /* [n_vertices*3] */
   const float *particle_vol;  /* [n_particles] */
   const float *particle_mass; /* [n_particles] */
-  const int32_t *particle_selection; /* [n_particles], 0 = simulate */
+  const int32_t *particle_selection; /* [n_particles], 0 = simulate, anything else = not simulated (mpm_utils.py:492); the
+                                        value 2 marks a ghost copy, but only after mpmhip_dist_enable */
 } mpmhip_state_ptrs;
 
 /* MPMModelStruct arrays, mpm_data_structure.py:621-630.  All [dev], [n_particles]. */
@@ -269,7 +270,11 @@ int mpmhip_export_grid(mpmhip_ctx *ctx, float *grid_m, float *grid_v_in, float *
 /* counts for the algorithmic-bytes formula; synchronous, runs small count kernels */
 int mpmhip_get_stats(mpmhip_ctx *ctx, mpmhip_stats *out);
 /* MPMWARP.time_profile / print_time_profile, mpm_solver.py:16,538-541: when enabled every phase is
- * bracketed by hipEvents (forces a sync per substep, like ScopedTimer(synchronize=True)). */
+ * bracketed by hipEvents (forces a sync per substep, like ScopedTimer(synchronize=True)).
+ * on = 1: every reference phase is its own launch (the reference's keys; un-fused kernels);
+ * on = 2: event pairs around the launches of the production loop -- the same (fused) kernels an unprofiled run
+ *         executes, keys compute_stress_from_F_trial / p2g / g2p_v / rebin (what bench.py's roofline uses);
+ * on = 0: off (no events, no syncs). */
 int mpmhip_profile_enable(mpmhip_ctx *ctx, int32_t on);
 int mpmhip_profile_count(const mpmhip_ctx *ctx);
 /* i-th phase: name, accumulated milliseconds, number of samples */

@@ -532,7 +532,8 @@ int mpmhip_get_stats(mpmhip_ctx *c, mpmhip_stats *out) {
 
 int mpmhip_profile_enable(mpmhip_ctx *c, int32_t on) {
   if (!c) return MPMHIP_ERR_INVALID;
-  c->profiling = on != 0;
+  c->profiling = on == 1;   // 1: the reference's phases, each its own launch + sync (time_profile keys)
+  c->prof_fused = on == 2;  // 2: event pairs around the launches of the production loop (bench.py's roofline)
   return MPMHIP_OK;
 }
 int mpmhip_profile_count(const mpmhip_ctx *c) { return c ? (int)c->phases.size() : 0; }

@@ -96,7 +96,8 @@ struct mpmhip_ctx {
   int64_t substeps = 0;
   std::string err;
 
-  bool profiling = false;
+  bool profiling = false;   // one launch per reference phase, one sync per phase (ScopedTimer semantics)
+  bool prof_fused = false;  // event pairs around the launches of the production (fused) loop; same kernels as unprofiled
   std::vector<mpm::Phase> phases;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -126,7 +127,7 @@ struct ScopedPhase {
   mpmhip_ctx *c;
   int idx;
   ScopedPhase(mpmhip_ctx *ctx, const char *name) : c(ctx), idx(-1) {
-    if (!c->profiling) return;
+    if (!c->profiling && !c->prof_fused) return;
     for (size_t i = 0; i < c->phases.size(); ++i)
       if (c->phases[i].name == name || std::string(c->phases[i].name) == name) idx = (int)i;
     if (idx < 0) {

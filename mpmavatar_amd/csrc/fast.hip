@@ -104,7 +104,7 @@ inline unsigned xcd_grid(int n) { return (unsigned)(((n + 8 * XCD_RUN - 1) / (8 
 // ------------------------------------------------------------------------------------------------
 // import / export between the caller's AoS arrays (reference layout) and the sorted SoA state
 // ------------------------------------------------------------------------------------------------
-__global__ void k_import(mpmhip_state_ptrs st, mpmhip_model_ptrs md, Bufs b, const int *perm, Dims d) {
+__global__ void k_import(mpmhip_state_ptrs st, mpmhip_model_ptrs md, Bufs b, const int *perm, Dims d, int dist) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= d.n_p) return;
   int o = perm[s];
@@ -112,7 +112,10 @@ __global__ void k_import(mpmhip_state_ptrs st, mpmhip_model_ptrs md, Bufs b, con
   for (int c = 0; c < 3; ++c) b.all.at(A_V + c, s) = st.particle_v[3 * (size_t)o + c];
   for (int c = 0; c < 9; ++c) b.all.at(A_C + c, s) = st.particle_C[9 * (size_t)o + c];
   b.all.at(A_MASS, s) = st.particle_mass[o];
-  b.sel[s] = st.particle_selection[o];
+  // only selection == 0 is simulated (mpm_utils.py:492,725,797,1028).  The value 2 means "ghost copy of another rank's
+  // particle" to the multi-GPU driver and only there; on a single context every nonzero value is "not simulated".
+  int sel = st.particle_selection[o];
+  b.sel[s] = dist ? sel : (sel != 0 ? 1 : 0);
   if (s < d.n_nv) {
     for (int c = 0; c < 9; ++c) b.nv.at(N_STRESS + c, s) = st.particle_stress[9 * (size_t)o + c];
     b.nv.at(N_VOL, s) = st.particle_vol[o];
@@ -1901,7 +1904,8 @@ int do_import(mpmhip_ctx *c) {
     f->have_order = true;
   }
   if (d.n_p)
-    hipLaunchKernelGGL(k_import, nblk(d.n_p), TPB, 0, c->stream, c->st, c->md, f->buf[f->cur], f->perm[f->cur], d);
+    hipLaunchKernelGGL(k_import, nblk(d.n_p), TPB, 0, c->stream, c->st, c->md, f->buf[f->cur], f->perm[f->cur], d,
+                       f->dist ? 1 : 0);
   if (d.n_e && d.n_v) {  // cloth topology -> ELL adjacency (original indices); K = max valence
     hipStream_t s = c->stream;
     MPM_HIP_CHECK(c, hipMemsetAsync(f->adj_cnt, 0, ((size_t)d.n_v + 1) * sizeof(int), s));
@@ -2397,12 +2401,12 @@ static int step_phase_c(mpmhip_ctx *c, const StepArgs &a) {
   hipStream_t s = c->stream;
   int rc;
   (void)rc; (void)d; (void)s;
-  {
+  // unprofiled: the element finalize is deferred into the next substep's stress kernel (k_stress_elem<true>); multi-GPU
+  // ranks have unpacked their ghost vertices by now, so the same holds there
+  f->elem_pending = d.n_e > 0;
+  if (c->profiling || (f->g.dbg & 64)) {
     ScopedPhase ph(c, "g2p_e");
-    // unprofiled: deferred into the next substep's stress kernel (k_stress_elem<true>); multi-GPU ranks have unpacked
-    // their ghost vertices by now, so the same holds there
-    f->elem_pending = d.n_e > 0;
-    if (c->profiling || (f->g.dbg & 64)) flush_elements(c);
+    flush_elements(c);
   }
   f->steps_since_rebin += 1;
   if (!f->dist && !f->flag_pending && (f->steps_since_rebin & f->poll_mask) == 0) {

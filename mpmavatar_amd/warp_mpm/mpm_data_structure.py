@@ -221,6 +221,9 @@ class MPMStateStruct(_Tracked):
     def reset_density(self, tensor_density: Tensor, selection_mask: Optional[Tensor] = None, device="cuda:0",
                       requires_grad=True, update_mass=False):
         dev = _dev(device)
+        s = self._solver() if self._solver is not None else None
+        if s is not None:
+            s._before_caller_write(self)
         n = tensor_density.shape[0]
         self._raw("particle_density")[:n].copy_(tensor_density.detach().to(device=dev, dtype=torch.float32))
         if update_mass:
@@ -230,6 +233,9 @@ class MPMStateStruct(_Tracked):
     # mpm_data_structure.py:469-486
     def reset_rest_dir(self, tensor_R_inv: Tensor, device="cuda:0"):
         dev = _dev(device)
+        s = self._solver() if self._solver is not None else None
+        if s is not None:
+            s._before_caller_write(self)
         n = tensor_R_inv.shape[0]
         self._raw("particle_R_inv")[:n].copy_(tensor_R_inv.detach().to(device=dev, dtype=torch.float32))
         self._touch()
@@ -309,6 +315,9 @@ class MPMModelStruct(_Tracked):
 
     # mpm_data_structure.py:678-684, 870-879
     def finalize_mu_lam(self, n_particles, device="cuda:0"):
+        s = self._solver() if self._solver is not None else None
+        if s is not None:
+            s._before_caller_write(self)  # plastic materials update mu / lam / yield_stress: flush those first
         E, nu = self._raw("E"), self._raw("nu")
         self._raw("mu").copy_(E / (2.0 * (1.0 + nu)))
         self._raw("lam").copy_(E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu)))

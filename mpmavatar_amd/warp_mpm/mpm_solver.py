@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import sys
 from typing import Optional
 
 import numpy as np
@@ -174,30 +175,65 @@ class MPMWARP(object):
             self._bound_scalar_version = md._scalar_version
 
     # hooks used by MPMStateStruct / MPMModelStruct
+    #
+    # The reference hands out zero-copy views of the solver's arrays (``wp.to_torch(mpm_state.particle_x)``): live in both
+    # directions.  The fast back end keeps its own sorted copy, so the shim emulates that:
+    #   * reading a solver-written field pulls the results into the tensor first;
+    #   * every tensor ever handed out stays on a watch list with torch's in-place-modification counter
+    #     (``Tensor._version``): before each substep the counters are compared and, if one moved, the state is re-imported
+    #     (writes that bypass torch -- raw pointers, another library -- need ``state._touch()``);
+    #   * a handed-out tensor the caller still holds on to (``x = state.particle_x`` kept across substeps) is refreshed
+    #     after every substep, so that it does not go stale.  A read-and-drop (``.clone()``, ``.cpu()``: what the reference
+    #     drivers do once per frame) costs nothing per substep.
+    def _watch(self, obj):
+        snap = self._read_snaps.setdefault(id(obj), {})
+        for name in type(obj)._fields:
+            t = obj._t.get(name)
+            if isinstance(t, torch.Tensor):
+                snap[name] = (t, t._version)
+            else:
+                snap.pop(name, None)
+
     def _before_caller_read(self, obj):
         if self._ctx and (obj is self._bound_state or obj is self._bound_model):
             self._call("mpmhip_pull_state")
-            # The caller may modify what it reads (the reference hands out zero-copy views).  torch counts in-place
-            # modifications per tensor (Tensor._version): remember the counters and re-import before the next substep
-            # only if one of them moved -- a plain read-back (clone / .cpu(), once per frame in the drivers) then costs
-            # no re-import and no re-sort.  Writes that bypass torch need state._touch().
-            snap = {}
-            for name in type(obj)._fields:
-                t = obj._t.get(name)
-                if isinstance(t, torch.Tensor):
-                    snap[name] = (t, t._version)
-            self._read_snaps[id(obj)] = snap
+            self._watch(obj)
 
     def _push_if_modified(self):
         if not self._read_snaps:
             return
-        dirty = any(t._version != v for snap in self._read_snaps.values() for t, v in snap.values())
-        self._read_snaps.clear()
+        dirty = False
+        for obj in (self._bound_state, self._bound_model):
+            snap = self._read_snaps.get(id(obj))
+            if not snap:
+                continue
+            for name, (t, v) in list(snap.items()):
+                if obj._t.get(name) is not t:      # field was rebound to another tensor: _bind() sees that
+                    del snap[name]
+                elif t._version != v:
+                    dirty = True
         if dirty:
             self._call("mpmhip_push_state")
+            for obj in (self._bound_state, self._bound_model):
+                if id(obj) in self._read_snaps:
+                    self._watch(obj)
+
+    def _refresh_held(self):
+        """After a substep: if the caller still holds a tensor it was handed, write the new results into it now."""
+        for obj in (self._bound_state, self._bound_model):
+            snap = self._read_snaps.get(id(obj)) if obj is not None else None
+            if not snap:
+                continue
+            for name in type(obj)._synced:
+                ent = snap.get(name)
+                # references we know of: obj._t, the watch-list tuple, `ent`'s own lookup is the same tuple, getrefcount's
+                # argument.  Anything beyond that is the caller's.
+                if ent is not None and sys.getrefcount(ent[0]) > 3:
+                    self._call("mpmhip_pull_state")
+                    return
 
     def _before_caller_write(self, obj):
-        if self._ctx and obj is self._bound_state:
+        if self._ctx and (obj is self._bound_state or obj is self._bound_model):
             self._call("mpmhip_push_state")
 
     # ------------------------------------------------------------------ parameters
@@ -211,6 +247,7 @@ class MPMWARP(object):
                 raise TypeError("Undefined material type")
             mpm_model.material = _MATERIALS[kwargs["material"]]
         if "yield_stress" in kwargs:
+            self._before_caller_write(mpm_model)  # results first (hardening updates yield_stress), then the new value
             mpm_model._raw("yield_stress").fill_(float(kwargs["yield_stress"]))
             mpm_model._touch()
         if "hardening" in kwargs:
@@ -225,6 +262,7 @@ class MPMWARP(object):
         if "g" in kwargs:
             mpm_model.gravitational_accelaration = (kwargs["g"][0], kwargs["g"][1], kwargs["g"][2])
         if "density" in kwargs:
+            self._before_caller_write(mpm_state)
             mpm_state._raw("particle_density").fill_(float(kwargs["density"]))
             torch.mul(mpm_state._raw("particle_density"), mpm_state._raw("particle_vol"), out=mpm_state._raw("particle_mass"))
             mpm_state._touch()
@@ -234,6 +272,7 @@ class MPMWARP(object):
 
     # mpm_solver.py:128-187
     def set_E_nu(self, mpm_model, E, nu, gamma, kappa, device="cuda:0"):
+        self._before_caller_write(mpm_model)
         for name, val in (("E", E), ("nu", nu), ("gamma", gamma), ("kappa", kappa)):
             dst = mpm_model._raw(name)
             if isinstance(val, float):
@@ -287,6 +326,8 @@ class MPMWARP(object):
             self._call("mpmhip_step", float(dt), dp(mx), dp(mv), dp(jt), n_jt, jvp, jfp)
         if self._profiling:
             self._collect_profile()
+        if self._read_snaps:
+            self._refresh_held()
 
     def _dummy_ptr(self):
         if not hasattr(self, "_dummy"):
@@ -297,9 +338,11 @@ class MPMWARP(object):
         self._call("mpmhip_synchronize")
 
     # ------------------------------------------------------------------ profiling (mpm_solver.py:16,538-541)
-    def enable_profiling(self, on=True):
+    def enable_profiling(self, on=True, fused=False):
+        """on: fill ``time_profile`` like the reference's ScopedTimers (one launch + one sync per reference phase).
+        fused=True: time the launches of the production loop instead (same kernels as an unprofiled run)."""
         self._profiling = bool(on)
-        self._lib.mpmhip_profile_enable(self._ctx, 1 if on else 0)
+        self._lib.mpmhip_profile_enable(self._ctx, (2 if fused else 1) if on else 0)
 
     def _collect_profile(self):
         name, ms, cnt = C.c_char_p(), C.c_double(), C.c_int64()

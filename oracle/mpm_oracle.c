@@ -824,7 +824,7 @@ static void apply_pre(orc_sim *s, const orc_pre *op, float dt) {
           for (int a = 0; a < 3; ++a) h[a] = off[a] - dn * op->normal[a];
           float hd = v_len(h);
           float cosine = (off[0] * op->axis1[0] + off[1] * op->axis1[1] + off[2] * op->axis1[2]) / hd;
-          float theta = acosf(cosine);
+          float theta = acosf(fminf(fmaxf(cosine, -1.0f), 1.0f)); /* wp.acos clamps its argument */
           if (!(off[0] * op->axis2[0] + off[1] * op->axis2[1] + off[2] * op->axis2[2] > 0.f)) theta = -theta;
           float a1 = -hd * sinf(theta) * op->rotation_scale;
           float a2 = hd * cosf(theta) * op->rotation_scale;
@@ -836,19 +836,25 @@ static void apply_pre(orc_sim *s, const orc_pre *op, float dt) {
   }
 }
 
+/* the two loops over pre-p2g particle operations, mpm_solver.py:260-279 */
+void orc_pre_p2g(orc_sim *s, float dt) {
+  for (int k = 0; k < s->n_pre; ++k)                                  /* :260 impulses */
+    if (s->pre[k].type == ORC_PRE_IMPULSE || s->pre[k].type == ORC_PRE_IMPULSE_MASK) apply_pre(s, &s->pre[k], dt);
+  for (int k = 0; k < s->n_pre; ++k)                                  /* :269 velocity modifiers */
+    if (s->pre[k].type == ORC_PRE_VEL_SET || s->pre[k].type == ORC_PRE_VEL_ROTATE) apply_pre(s, &s->pre[k], dt);
+}
+
 /* MPMWARP.p2g2p, mpm_solver.py:229-536 */
-void orc_p2g2p(orc_sim *s, float dt, const float *mesh_x, const float *mesh_v,
+void orc_p2g2p(orc_sim *s, double dt_host, const float *mesh_x, const float *mesh_v,
                const float *joint_t_v, int n_joint_t, const float *joint_v_v,
                const float *joint_f_v) {
+  const float dt = (float)dt_host; /* kernels take fp32 dt; MPMWARP.time advances by the Python double (:536) */
 #ifdef ORC_OMP
   if (s->n_threads > 0) omp_set_num_threads(s->n_threads);
 #endif
   orc_zero_grid(s);                                                   /* :244 */
   memset(s->vertex_force, 0, (size_t)s->n_vertices * 3 * sizeof(float)); /* :251 */
-  for (int k = 0; k < s->n_pre; ++k)                                  /* :260 impulses */
-    if (s->pre[k].type == ORC_PRE_IMPULSE || s->pre[k].type == ORC_PRE_IMPULSE_MASK) apply_pre(s, &s->pre[k], dt);
-  for (int k = 0; k < s->n_pre; ++k)                                  /* :269 velocity modifiers */
-    if (s->pre[k].type == ORC_PRE_VEL_SET || s->pre[k].type == ORC_PRE_VEL_ROTATE) apply_pre(s, &s->pre[k], dt);
+  orc_pre_p2g(s, dt);                                                 /* :260-279 */
   if (mesh_x) memcpy(s->mesh_points, mesh_x, (size_t)s->num_mesh_v * 3 * sizeof(float));     /* :285-299 */
   if (mesh_v) memcpy(s->mesh_velocities, mesh_v, (size_t)s->num_mesh_v * 3 * sizeof(float)); /* :301-315 */
   orc_compute_stress_from_F_trial(s, dt);                             /* :327 */
@@ -861,10 +867,10 @@ void orc_p2g2p(orc_sim *s, float dt, const float *mesh_x, const float *mesh_v,
   for (int k = 0; k < s->n_bc; ++k) orc_apply_bc(s, k, dt);           /* :487-501 */
   orc_g2p_v(s, dt);                                                   /* :518 */
   orc_g2p_e(s, dt);                                                   /* :529 */
-  s->time = s->time + (double)dt;                                     /* :536 */
+  s->time = s->time + dt_host;                                        /* :536 */
 }
 
-void orc_p2g2p_n(orc_sim *s, float dt, int n, const float *mesh_x, const float *mesh_v,
+void orc_p2g2p_n(orc_sim *s, double dt_host, int n, const float *mesh_x, const float *mesh_v,
                  const float *joint_t_v, int n_joint_t, const float *joint_v_v,
                  const float *joint_f_v) {
   float *cur = NULL;
@@ -873,11 +879,11 @@ void orc_p2g2p_n(orc_sim *s, float dt, int n, const float *mesh_x, const float *
   for (int k = 0; k < n; ++k) {
     const float *mx = mesh_x;
     if (cur) { /* train_material_params.py:623: mesh_x + substep_size*substep_local*mesh_v */
-      float f = dt * (float)k;
+      float f = (float)dt_host * (float)k;
       for (size_t i = 0; i < nm; ++i) cur[i] = mesh_x[i] + f * mesh_v[i];
       mx = cur;
     }
-    orc_p2g2p(s, dt, mx, mesh_v, joint_t_v, n_joint_t, joint_v_v, joint_f_v);
+    orc_p2g2p(s, dt_host, mx, mesh_v, joint_t_v, n_joint_t, joint_v_v, joint_f_v);
   }
   free(cur);
 }

@@ -127,6 +127,7 @@ typedef struct {
 
 /* individual kernels (exposed so tests can pin them one at a time) */
 void orc_zero_grid(orc_sim *s);
+void orc_pre_p2g(orc_sim *s, float dt);
 void orc_compute_stress_from_F_trial(orc_sim *s, float dt);
 void orc_p2g(orc_sim *s, float dt);
 void orc_grid_normalization_and_gravity(orc_sim *s, float dt);
@@ -139,13 +140,13 @@ void orc_g2p_v(orc_sim *s, float dt);
 void orc_g2p_e(orc_sim *s, float dt);
 
 /* one substep = MPMWARP.p2g2p (mpm_solver.py:229-536); NULL pointers = argument None */
-void orc_p2g2p(orc_sim *s, float dt, const float *mesh_x, const float *mesh_v,
+void orc_p2g2p(orc_sim *s, double dt, const float *mesh_x, const float *mesh_v,
                const float *joint_t_v, int n_joint_t, const float *joint_v_v,
                const float *joint_f_v);
 
 /* n substeps with the caller's mesh advection mesh_x + k*dt*mesh_v
  * (train_material_params.py:622-626); mesh_x may be NULL */
-void orc_p2g2p_n(orc_sim *s, float dt, int n, const float *mesh_x, const float *mesh_v,
+void orc_p2g2p_n(orc_sim *s, double dt, int n, const float *mesh_x, const float *mesh_v,
                  const float *joint_t_v, int n_joint_t, const float *joint_v_v,
                  const float *joint_f_v);
 

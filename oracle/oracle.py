@@ -98,12 +98,12 @@ def _load(omp: bool):
     assert lib.orc_sizeof_sim() == C.sizeof(_Sim), "ctypes mirror of orc_sim out of date"
     sp = C.POINTER(_Sim)
     for name, args in {
-        "orc_zero_grid": [sp], "orc_compute_stress_from_F_trial": [sp, C.c_float], "orc_p2g": [sp, C.c_float],
+        "orc_zero_grid": [sp], "orc_pre_p2g": [sp, C.c_float], "orc_compute_stress_from_F_trial": [sp, C.c_float], "orc_p2g": [sp, C.c_float],
         "orc_grid_normalization_and_gravity": [sp, C.c_float], "orc_add_damping_via_grid": [sp, C.c_float],
         "orc_mesh_collide": [sp, C.c_int], "orc_particle_move": [sp, C.c_int, fp, C.c_int, fp, fp],
         "orc_apply_bc": [sp, C.c_int, C.c_float], "orc_g2p_v": [sp, C.c_float], "orc_g2p_e": [sp, C.c_float],
-        "orc_p2g2p": [sp, C.c_float, fp, fp, fp, C.c_int, fp, fp],
-        "orc_p2g2p_n": [sp, C.c_float, C.c_int, fp, fp, fp, C.c_int, fp, fp],
+        "orc_p2g2p": [sp, C.c_double, fp, fp, fp, C.c_int, fp, fp],
+        "orc_p2g2p_n": [sp, C.c_double, C.c_int, fp, fp, fp, C.c_int, fp, fp],
         "orc_svd3": [fp, fp, fp, fp], "orc_qr_signfixed": [fp, fp, fp],
         "orc_anisotropy_return_mapping": [fp, C.c_float, C.c_float, C.c_float, fp],
         "orc_kirchhoff_anisotropy": [fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, fp, fp, fp, fp],
@@ -351,11 +351,32 @@ class OracleMPM:
         op = self._new_pre(PRE_VEL_SET, mask, start_time, end_time)
         op.velocity = f3(*velocity)
 
+    def enforce_particle_velocity_rotation(self, point, normal, half_height_and_radius, rotation_scale, translation_scale,
+                                           start_time, end_time):
+        """mpm_solver.py:1156-1257 (host part :1168-1193: unit normal, two horizontal axes; selection mpm_utils.py:1230-1248)."""
+        ns = 1.0 / math.sqrt(float(normal[0] ** 2 + normal[1] ** 2 + normal[2] ** 2))
+        nrm = np.array([ns * x for x in normal], np.float32)
+        h1 = np.array([1.0, 1.0, 1.0], np.float32)
+        if abs(float(nrm @ h1)) < 0.01:
+            h1 = np.array([0.72, 0.37, -0.67], np.float32)
+        h1 = h1 - np.float32(h1 @ nrm) * nrm
+        h1 = h1 * np.float32(1.0 / np.sqrt(np.float32(h1 @ h1)))
+        h2 = np.cross(h1, nrm).astype(np.float32)
+        off = self.x - np.asarray(point, np.float32)
+        dn = off @ nrm
+        horiz = np.linalg.norm(off - dn[:, None] * nrm[None], axis=1)
+        mask = ((np.abs(dn) < np.float32(half_height_and_radius[0])) & (horiz < np.float32(half_height_and_radius[1]))).astype(np.int32)
+        op = self._new_pre(PRE_VEL_ROTATE, mask, start_time, end_time)
+        op.point, op.normal, op.axis1, op.axis2 = f3(*point), f3(*nrm), f3(*h1), f3(*h2)
+        op.rotation_scale, op.translation_scale = rotation_scale, translation_scale
+
     # ------------------------------------------------------------ kernels
     def _sp(self):
         return C.byref(self.sim)
 
     def zero_grid(self): self.lib.orc_zero_grid(self._sp())
+    def pre_p2g(self, dt): self.lib.orc_pre_p2g(self._sp(), dt)
+    def damping(self, scale): self.lib.orc_add_damping_via_grid(self._sp(), scale)
     def compute_stress(self, dt): self.lib.orc_compute_stress_from_F_trial(self._sp(), dt)
     def p2g(self, dt): self.lib.orc_p2g(self._sp(), dt)
     def grid_update(self, dt): self.lib.orc_grid_normalization_and_gravity(self._sp(), dt)

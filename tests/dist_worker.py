@@ -76,8 +76,13 @@ def main():
     else:
         assert torch.cuda.is_available()
         from mpmavatar_amd import harness
-        ss = mdist.build_sharded(sc, "cuda:0", rank, world, rebin_interval=int(os.environ.get("MPMHIP_TEST_REBIN", "8")))
+        # one GPU per rank when the box has them (needed by the in-library RCCL transport); otherwise the ranks share cuda:0
+        dev = f"cuda:{rank}" if torch.cuda.device_count() >= world else "cuda:0"
+        torch.cuda.set_device(dev)
+        ss = mdist.build_sharded(sc, dev, rank, world, rebin_interval=int(os.environ.get("MPMHIP_TEST_REBIN", "8")))
         mdist.run(ss, steps)
+        if os.environ.get("MPMHIP_DIST_TRANSPORT") == "rccl" and world > 1 and torch.cuda.device_count() >= world:
+            ok &= ss.transport == "rccl"   # the test asked for the in-library loop: falling back silently is a failure
         if ss.transport == "torch":
             print(f"dist[{scene_name}] rank {rank}: {ss.resorts} collective re-sorts in {steps} substeps", flush=True)
             st = ss.sim.solver.stats()
@@ -86,7 +91,7 @@ def main():
         parts = [None] * world
         dist.gather_object(got, parts if rank == 0 else None, dst=0)
         if rank == 0:
-            ref = harness.build_solver(sc, "cuda:0", mode="fast")
+            ref = harness.build_solver(sc, dev, mode="fast")
             harness.run(ref, steps)
             x = ref.state.particle_x.cpu().numpy()
             ne, nt = sc.n_elements, sc.n_traditional

@@ -1,0 +1,77 @@
+"""Helpers for the fixtures that the REFERENCE'S OWN SOURCE produced (tests/golden/ref_*.npz, generated in the build
+container by tests/golden/make_golden_ref.py: /root/reference/warp_mpm/*.py imported unchanged over a NumPy stand-in of
+the ``warp`` module).  Only data is read here; nothing of the reference is needed at test time.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+
+import numpy as np
+
+from mpmavatar_amd.scenes import Scene
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+_ARRAYS = ("x", "v", "vol", "faces", "d", "R_inv", "mesh_vertices", "mesh_faces", "mesh_v", "joint_verts_v", "joint_faces_v",
+           "selection")
+
+
+def names(kind):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, f"ref_{kind}_*.npz")))
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def scene_from_npz(z) -> Scene:
+    meta = json.loads(str(z["scene_meta"]))
+    kw = {k: (z["scene_" + k] if "scene_" + k in z.files else None) for k in _ARRAYS}
+    bcs = [(kind, d) for kind, d in meta.pop("bcs")]
+    return Scene(params=meta.pop("params"), bcs=bcs, **meta, **kw)
+
+
+def rel(a, b, floor=1e-3):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if a.size == 0:
+        return 0.0
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), floor))
+
+
+PRE_OPS = {"impulse": "add_impulse_on_particles", "vel_translation": "enforce_particle_velocity_translation",
+           "vel_rotation": "enforce_particle_velocity_rotation"}
+
+
+def launches(z):
+    return json.loads(str(z["launches"]))
+
+
+def pre_ops(z):
+    return json.loads(str(z["preops_json"]))
+
+
+def state_after(z, upto):
+    """The reference's complete state after launch number `upto` (-1: before the traced substep)."""
+    st = {k[4:]: z[k] for k in z.files if k.startswith("pre_")}
+    for i in range(upto + 1):
+        pref = f"L{i:02d}_"
+        for k in z.files:
+            if k.startswith(pref):
+                st[k[len(pref):]] = z[k]
+    return st
+
+
+def step_inputs(sc, step):
+    """p2g2p arguments at substep `step` (NumPy), as oracle.scene_adapter.run_scene builds them."""
+    kw = {}
+    if sc.mesh_vertices is not None:
+        kw["mesh_x"] = (sc.mesh_vertices + np.float32(sc.dt * step) * sc.mesh_v).astype(np.float32)
+        kw["mesh_v"] = np.ascontiguousarray(sc.mesh_v, np.float32)
+    if sc.joint_verts_v is not None:
+        kw["joint_verts_v"] = np.ascontiguousarray(sc.joint_verts_v, np.float32)
+        kw["joint_faces_v"] = np.ascontiguousarray(sc.joint_faces_v, np.float32).reshape(-1, 3)
+    if sc.joint_t_hold > 0:
+        kw["joint_traditional_v"] = np.zeros((sc.joint_t_count(step), 3), np.float32)
+    return kw

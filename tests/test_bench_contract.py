@@ -45,3 +45,29 @@ def test_live_bench_prints_exactly_one_json_line():
     out = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(out) == 1, r.stdout[:500]
     _check(json.loads(out[0]), with_cpu=False)
+
+
+@pytest.mark.gpu
+def test_bench_gpus_n_without_a_launcher():
+    """`python bench.py --gpus 2` as the driver calls it (no WORLD_SIZE in the environment): on a box with >= 2 GPUs the
+    script starts the ranks itself and prints one line with n_gpus = 2; on a one-GPU box it stops with a message (no
+    assert, no traceback); with the gloo test transport two ranks share the GPU and the sharded path runs either way."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scene", "cube-8k", "--steps", "20", "--warmup", "5",
+            "--advance", "0", "--no-cpu-baseline"]
+    r = subprocess.run(base, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    if torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, r.stderr[-2000:]
+        o = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+        _check(o, n_gpus=2, with_cpu=False)
+        assert o["config"]["exchange"] == "rccl"
+    else:
+        assert r.returncode != 0 and r.stdout.strip() == ""
+        assert "needs one GPU per rank" in r.stderr and "Traceback" not in r.stderr
+    r = subprocess.run(base, cwd=ROOT, env=dict(env, MPMHIP_DIST_BACKEND="gloo", OMP_NUM_THREADS="1"), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(out) == 1, r.stdout[:500]
+    _check(json.loads(out[0]), n_gpus=2, with_cpu=False)

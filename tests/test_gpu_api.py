@@ -226,3 +226,66 @@ def test_headline_size_grid_mass_is_conserved(big_pair):
     m, _, _ = a.solver.export_grid()
     total = float(a.state.particle_mass.double().sum())
     assert float(m.double().sum()) == pytest.approx(total, rel=1e-5)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_held_tensor_stays_live_and_late_writes_are_seen(mode):
+    """The reference's ``wp.to_torch`` view is live in both directions.  A tensor the caller keeps across substeps must
+    (a) show the new results after every substep and (b) have in-place edits picked up whenever they happen -- not only
+    right after the read (the version snapshots used to be dropped after one substep)."""
+    sc = scenes.small_cube()
+    a = harness.build_solver(sc, "cuda:0", mode=mode)
+    b = harness.build_solver(sc, "cuda:0", mode=mode)
+    x = a.state.particle_x          # held across substeps
+    v = a.state.particle_v
+    harness.run(a, 5, fused=True)
+    harness.run(b, 5, fused=True)
+    assert rel(x.cpu().numpy(), b.state.particle_x.cpu().numpy()) < 1e-7   # (a): no re-read of the attribute
+    harness.run(a, 3)
+    harness.run(b, 3)
+    assert rel(x.cpu().numpy(), b.state.particle_x.cpu().numpy()) < 1e-7
+    v.add_(torch.tensor([0.0, 0.25, 0.0], device=v.device))                 # (b): late in-place write through the held tensor
+    b.state.particle_v.add_(torch.tensor([0.0, 0.25, 0.0], device=v.device))
+    harness.run(a, 4, fused=True)
+    harness.run(b, 4, fused=True)
+    assert rel(a.state.particle_v.cpu().numpy(), b.state.particle_v.cpu().numpy()) < 1e-6
+    assert float(a.state.particle_v[:, 1].mean()) > 0.2
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_model_parameters_set_after_stepping_are_kept(mode):
+    """yield_stress / E set through the shim after some substeps used to be overwritten by the export of the
+    (hardened) internal values before the re-import read them."""
+    sc = scenes.small_cube(material="metal", params={"yield_stress": 0.05, "hardening": 1, "xi": 0.5})
+    a = harness.build_solver(sc, "cuda:0", mode=mode)
+    harness.run(a, 10, fused=True)
+    a.solver.set_parameters_dict(a.model, a.state, {"yield_stress": 7.0})
+    harness.run(a, 1)
+    ys = a.model.yield_stress.cpu().numpy()
+    assert np.abs(ys - 7.0).max() < 0.5, ys[:4]        # (may harden a little from 7.0; must not be back at ~0.05)
+    ones = torch.ones(sc.n_particles, device=a.state.device)
+    a.solver.set_E_nu_from_torch(a.model, ones * 50.0, ones * 0.2, ones * 1.0, ones * 1.0)
+    a.solver.prepare_mu_lam(a.model, a.state)
+    harness.run(a, 1)
+    assert np.allclose(a.model.mu.cpu().numpy(), 50.0 / (2 * 1.2), rtol=1e-5)
+
+
+def test_selection_two_is_not_simulated_on_a_single_context(oracle_lib):
+    """Only particle_selection == 0 is simulated (mpm_utils.py:492,725,797,1028).  The fast back end uses the value 2 for
+    ghost copies of the multi-GPU driver; on a plain context it must mean 'frozen', as in the baseline back end."""
+    res = {}
+    for mode in MODES:
+        sc = scenes.small_sheet()
+        sel = np.zeros(sc.n_particles, np.int32)
+        sel[: sc.n_elements : 3] = 2
+        sel[sc.n_elements :: 5] = 2
+        sc.selection = sel
+        sim = harness.build_solver(sc, "cuda:0", mode=mode)
+        harness.run(sim, 10, fused=True)
+        res[mode] = sim.state.particle_x.cpu().numpy()
+        assert np.abs(res[mode][sel != 0] - sc.x[sel != 0]).max() == 0.0
+    assert rel(res["fast"], res["baseline"]) < 1e-6
+    from oracle.scene_adapter import run_scene
+    o = _oracle(sc)
+    run_scene(o, sc, 10)
+    assert rel(res["fast"], o.x) < 1e-5

@@ -1,0 +1,45 @@
+"""The reference drivers' own import lines must resolve against this repository unchanged."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# run_demo.py:27-32 and train_material_params.py:28-33, verbatim (the ``warp`` import resolves to the four-name facade
+# when mpmavatar_amd/compat is on the path; with NVIDIA Warp installed it would resolve to Warp and work just as well)
+DRIVER_IMPORTS = '''
+import warp as wp
+from warp_mpm.mpm_data_structure import (
+    MPMStateStruct,
+    MPMModelStruct,
+)
+from warp_mpm.mpm_solver import MPMWARP
+'''
+
+CHECK = DRIVER_IMPORTS + '''
+import mpmavatar_amd.warp_mpm as shim
+assert MPMWARP is shim.MPMWARP and MPMStateStruct is shim.MPMStateStruct and MPMModelStruct is shim.MPMModelStruct
+import torch
+t = torch.zeros(4, 3)
+assert wp.to_torch(t) is t          # run_demo.py:532: wp.to_torch(self.mpm_state.particle_x).clone()
+assert hasattr(wp, "init") and hasattr(wp, "config")
+for name in ("p2g2p", "set_parameters_dict", "set_E_nu_from_torch", "prepare_mu_lam", "add_mesh_collider", "add_particle_mover",
+             "add_surface_collider", "add_bounding_box", "set_velocity_on_cuboid", "print_time_profile"):
+    assert callable(getattr(MPMWARP, name)), name
+for name in ("init", "from_torch", "reset_state", "continue_from_torch", "reset_density"):
+    assert callable(getattr(MPMStateStruct, name)), name
+print("ok")
+'''
+
+
+def test_reference_import_lines_resolve_unchanged():
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "mpmavatar_amd", "compat")]))
+    r = subprocess.run([sys.executable, "-c", CHECK], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_facade_from_the_package():
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    code = "from warp_mpm import wp; import torch; t = torch.ones(2); assert wp.to_torch(t) is t; print('ok')"
+    r = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
