@@ -185,6 +185,10 @@ int mpmhip_synchronize(mpmhip_ctx *ctx);
 /* MPMWARP.time (never reset by reset_state, quirk Q3) */
 double mpmhip_get_time(const mpmhip_ctx *ctx);
 int mpmhip_set_time(mpmhip_ctx *ctx, double t);
+/* mpm_solver.py:536: `self.time = self.time + dt` adds the caller's Python float (a double) while the kernels receive dt as
+ * fp32.  Tell the library that double once (and whenever dt changes); steps whose fp32 dt equals (float)dt_host then advance
+ * MPMWARP.time by dt_host exactly as the reference does.  Without it time advances by (double)(float)dt. */
+int mpmhip_set_host_dt(mpmhip_ctx *ctx, double dt_host);
 
 /* ---- multi-GPU (one process and one context per GPU; not in the reference) --------------------
  * Particles are sharded across ranks by the caller (mpmavatar_amd/dist.py: static spatial slabs); every rank runs

@@ -108,6 +108,7 @@ SIGNATURES = {
     "mpmhip_synchronize": (C.c_int, [vp]),
     "mpmhip_get_time": (C.c_double, [vp]),
     "mpmhip_set_time": (C.c_int, [vp, C.c_double]),
+    "mpmhip_set_host_dt": (C.c_int, [vp, C.c_double]),
     "mpmhip_export_grid": (C.c_int, [vp, vp, vp, vp]),
     "mpmhip_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
     "mpmhip_profile_enable": (C.c_int, [vp, C.c_int32]),
@@ -124,6 +125,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    global LIB_PATH
+    LIB_PATH = os.environ.get("MPMHIP_LIB", LIB_PATH)  # kernel A/B experiments: another build of the same sources
     if not os.path.exists(LIB_PATH):
         raise MPMHipError(ERR_INVALID, f"{LIB_PATH} not found: build it with `python -m mpmavatar_amd.build` "
                                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")

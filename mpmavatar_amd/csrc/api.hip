@@ -357,7 +357,7 @@ static int step_checked(mpmhip_ctx *c, const StepArgs &a) {
     hipLaunchKernelGGL(k_mesh_store, (unsigned)((nm + 255) / 256), 256, 0, c->stream, c->mesh_points, c->mesh_vel,
                        a.mesh_x, a.mesh_v, c->cur_f, nm);
   }
-  c->time = c->time + (double)a.dt;  // mpm_solver.py:536
+  c->time = c->time + c->time_inc(a.dt);  // mpm_solver.py:536
   c->substeps += 1;
   return MPMHIP_OK;
 }
@@ -452,7 +452,7 @@ int mpmhip_dist_step_end(mpmhip_ctx *c) {
   StepArgs a{};
   int rc = fast_dist_phase(c, 2, a);
   if (rc) return rc;
-  c->time = c->time + (double)c->fast_dt;
+  c->time = c->time + c->time_inc(c->fast_dt);
   c->substeps += 1;
   return MPMHIP_OK;
 }
@@ -498,6 +498,11 @@ int mpmhip_synchronize(mpmhip_ctx *c) {
 }
 
 double mpmhip_get_time(const mpmhip_ctx *c) { return c ? c->time : 0.0; }
+int mpmhip_set_host_dt(mpmhip_ctx *c, double dt) {
+  CHECK_CTX(c);
+  c->host_dt = dt;
+  return MPMHIP_OK;
+}
 int mpmhip_set_time(mpmhip_ctx *c, double t) {
   if (!c) return MPMHIP_ERR_INVALID;
   c->time = t;

@@ -92,6 +92,11 @@ struct mpmhip_ctx {
   std::vector<mpm::PreOp> pre;
 
   double time = 0.0;
+  double host_dt = 0.0;  // the caller's dt as the double it is in Python (mpmhip_set_host_dt); 0 = not given
+  // MPMWARP.time advances by the Python float (mpm_solver.py:536: self.time + dt in double precision) while the kernels get
+  // fp32 dt; with only the fp32 value known the increment is (double)(float)dt, which drifts from the reference's time by
+  // 2.5e-8 relative and can move a time-windowed BC / particle operation by one substep
+  double time_inc(float dt) const { return (host_dt != 0.0 && (float)host_dt == dt) ? host_dt : (double)dt; }
   float fast_dt = 0.f;  // dt of the substep in flight (dist phases)
   int64_t substeps = 0;
   std::string err;

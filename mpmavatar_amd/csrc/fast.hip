@@ -346,6 +346,10 @@ struct GridParams {
   int has_col, has_mov, mov_on;
   float col_friction;
   int count;
+  // further mesh colliders (mpm_solver.py:385-419 loops over a list): they all splat the solver's one body mesh, so their
+  // weight / velocity / normal fields are identical and only the friction of the collide step differs
+  int n_col_more = 0;
+  float col_friction_more[3] = {0.0f, 0.0f, 0.0f};
 };
 
 // One node of the grid stage.  ZERO = true consumes the accumulators (re-zeroes what it read); ZERO = false only reads
@@ -369,7 +373,12 @@ __device__ __forceinline__ V3 node_update(int blk, int l, const Dims &d, const G
     float wc = pc[0];
     if (wc != 0.0f) {
       V3 vin = v3(pc[64], pc[128], pc[192]), nrm = v3(pc[256], pc[320], pc[384]);
-      if (wc > 1e-15f) { v = collide_node(v, (1.0f / wc) * vin, nrm, gp.col_friction); ncol = 1; }
+      if (wc > 1e-15f) {
+        V3 vm = (1.0f / wc) * vin;
+        v = collide_node(v, vm, nrm, gp.col_friction);
+        for (int k = 0; k < gp.n_col_more; ++k) v = collide_node(v, vm, nrm, gp.col_friction_more[k]);
+        ncol = 1;
+      }
       if (ZERO) { pc[0] = 0.0f; pc[64] = 0.0f; pc[128] = 0.0f; pc[192] = 0.0f; pc[256] = 0.0f; pc[320] = 0.0f; pc[384] = 0.0f; }
     }
   }
@@ -1243,6 +1252,95 @@ __device__ __forceinline__ G2PResult g2p_gather(const float4 *tile, int ox, int 
   return g2p_finish(s, d, nv, Mx, My, Mz, Fx, Fy, Fz);
 }
 
+#ifndef MPMHIP_G2P_PK
+#define MPMHIP_G2P_PK 1
+#endif
+#if MPMHIP_G2P_PK
+// the same gather in two passes (velocity + APIC matrix, then the velocity gradient): 12 and 9 accumulators instead
+// of 21 at a time.  The sums are written on PAIRS of accumulators (ext_vector_type(2)) so that hipcc emits
+// v_pk_fma_f32 -- two fp32 FMAs per issue slot, the scalar factor broadcast through op_sel -- instead of one v_fma_f32
+// per component: g2p is bound by VALU issue (690 VALU instructions per wavefront, SIMDs ~100 % busy at five waves), not by
+// LDS or HBM.  Pairing: (x, y) of every vector, and the z components two by two where they share a source
+// ((s0.z, s2.z) <- u.z; (nv.z, Mz.z) <- (s0.z, s2.z); (Mx.z, My.z) <- s0.z).  Same products, same summation order per
+// accumulator as the scalar form above.
+typedef float F2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ F2 f2s(float a) { return F2{a, a}; }
+__device__ __forceinline__ F2 fma2(F2 a, F2 b, F2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ void g2p_gather_vC(const float4 *tile, int ox, int oy, int oz, V3 x, const Dims &d, V3 &v, M3 &C) {
+  Stencil s = make_stencil(x, d.inv_dx);
+  int base = tile_idx(s.bx - ox, s.by - oy, s.bz - oz);
+  F2 nvxy = f2s(0.f), nvz_Mzz = f2s(0.f), Mzxy = f2s(0.f), Mxxy = f2s(0.f), Myxy = f2s(0.f), Mxz_Myz = f2s(0.f);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float wx = bspline_w(i, s.fx.x);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float wy = bspline_w(j, s.fx.y);
+      F2 s0xy = f2s(0.f), s0z_s2z = f2s(0.f), s2xy = f2s(0.f);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float wzk = sel3(k, s.w0.z, s.w1.z, s.w2.z);
+        const float4 t4 = tile[base + tile_idx(i, j, k)];
+        F2 uxy = F2{t4.x, t4.y};
+        s0xy = fma2(f2s(wzk), uxy, s0xy);
+        if (k > 0) {
+          float kw = (float)k * wzk;
+          s0z_s2z = fma2(F2{wzk, kw}, f2s(t4.z), s0z_s2z);
+          s2xy = fma2(f2s(kw), uxy, s2xy);
+        } else {
+          s0z_s2z.x = fmaf(wzk, t4.z, s0z_s2z.x);
+        }
+      }
+      float wxy = wx * wy;
+      nvxy = fma2(f2s(wxy), s0xy, nvxy);
+      nvz_Mzz = fma2(f2s(wxy), s0z_s2z, nvz_Mzz);
+      Mzxy = fma2(f2s(wxy), s2xy, Mzxy);
+      if (i > 0) Mxxy = fma2(f2s((float)i * wxy), s0xy, Mxxy);
+      if (j > 0) Myxy = fma2(f2s((float)j * wxy), s0xy, Myxy);
+      if (i > 0 || j > 0) Mxz_Myz = fma2(F2{(float)i * wxy, (float)j * wxy}, f2s(s0z_s2z.x), Mxz_Myz);
+    }
+  }
+  float c4 = 4.0f * d.inv_dx;
+  V3 nv = v3(nvxy.x, nvxy.y, nvz_Mzz.x);
+  V3 Mx = v3(Mxxy.x, Mxxy.y, Mxz_Myz.x), My = v3(Myxy.x, Myxy.y, Mxz_Myz.y), Mz = v3(Mzxy.x, Mzxy.y, nvz_Mzz.y);
+  v = nv;
+  C = m3_cols(c4 * (Mx - s.fx.x * nv), c4 * (My - s.fx.y * nv), c4 * (Mz - s.fx.z * nv));
+}
+__device__ __forceinline__ M3 g2p_gather_grad(const float4 *tile, int ox, int oy, int oz, V3 x, const Dims &d) {
+  Stencil s = make_stencil(x, d.inv_dx);
+  int base = tile_idx(s.bx - ox, s.by - oy, s.bz - oz);
+  F2 Fxxy = f2s(0.f), Fyxy = f2s(0.f), Fzxy = f2s(0.f), Fxz_Fyz = f2s(0.f);
+  float Fzz = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float wx = bspline_w(i, s.fx.x), dwx = bspline_dw(i, s.fx.x);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float wy = bspline_w(j, s.fx.y), dwy = bspline_dw(j, s.fx.y);
+      F2 s0xy = f2s(0.f), s0z_s1z = f2s(0.f), s1xy = f2s(0.f);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float wzk = sel3(k, s.w0.z, s.w1.z, s.w2.z), dwzk = bspline_dw(k, s.fx.z);
+        const float4 t4 = tile[base + tile_idx(i, j, k)];
+        F2 uxy = F2{t4.x, t4.y};
+        s0xy = fma2(f2s(wzk), uxy, s0xy);
+        s0z_s1z = fma2(F2{wzk, dwzk}, f2s(t4.z), s0z_s1z);
+        s1xy = fma2(f2s(dwzk), uxy, s1xy);
+      }
+      float a = dwx * wy, bb = wx * dwy, c = wx * wy;
+      Fxxy = fma2(f2s(a), s0xy, Fxxy);
+      Fyxy = fma2(f2s(bb), s0xy, Fyxy);
+      Fzxy = fma2(f2s(c), s1xy, Fzxy);
+      Fxz_Fyz = fma2(F2{a, bb}, f2s(s0z_s1z.x), Fxz_Fyz);
+      Fzz = fmaf(c, s0z_s1z.y, Fzz);
+    }
+  }
+  V3 Fx = v3(Fxxy.x, Fxxy.y, Fxz_Fyz.x), Fy = v3(Fyxy.x, Fyxy.y, Fxz_Fyz.y), Fz = v3(Fzxy.x, Fzxy.y, Fzz);
+  return m3_cols(d.inv_dx * Fx, d.inv_dx * Fy, d.inv_dx * Fz);
+}
+
+#else
 // the same gather in two passes (velocity + APIC matrix, then the velocity gradient): 12 and 9 accumulators instead
 // of 21 at a time
 __device__ __forceinline__ void g2p_gather_vC(const float4 *tile, int ox, int oy, int oz, V3 x, const Dims &d, V3 &v, M3 &C) {
@@ -1301,6 +1399,8 @@ __device__ __forceinline__ M3 g2p_gather_grad(const float4 *tile, int ox, int oy
   }
   return m3_cols(d.inv_dx * Fx, d.inv_dx * Fy, d.inv_dx * Fz);
 }
+
+#endif
 
 // same sums for a particle that drifted out of its tile margin: rolled loop over the global grid (zero outside
 // active blocks); kept small so that it does not set the kernel's register budget
@@ -1380,6 +1480,12 @@ __device__ __forceinline__ void g2p_write(const Bufs &b, int cls, int s, V3 x, V
 // 95 instead of 114 VGPRs, a fifth wavefront per SIMD.  Pays when many lanes are vertices (cloth scenes: a third of the
 // particles skip the second sweep); traditional-only scenes read every node twice and keep the single sweep.
 template <bool FUSED, bool TWO_PASS>
+#ifndef MPMHIP_G2P_WAVES
+#define MPMHIP_G2P_WAVES 0
+#endif
+#if MPMHIP_G2P_WAVES
+__attribute__((amdgpu_waves_per_eu(MPMHIP_G2P_WAVES, 8)))
+#endif
 __global__ __launch_bounds__(PT) void k_g2p(Bufs b, const ChunkRec *recs, int n_chunks, Dims d, float dt, GridPtrs g,
                                              GridParams gp, BCList bcl) {
   __shared__ float4 tile[TILE_PAD];  // node velocity, 16 bytes per node
@@ -2160,7 +2266,10 @@ void fast_destroy(mpmhip_ctx *c) {
 
 int fast_add_collider_storage(mpmhip_ctx *c, MeshCollider &mc) {
   FastState *f = c->fast;
-  if (!c->colliders.empty()) return fail(c, MPMHIP_ERR_LIMIT, "fast mode supports one mesh collider (the reference drivers register one)");
+  if (!c->colliders.empty()) {  // same body mesh, same splat: the extra collider only adds a collide step with its friction
+    mc.weight = c->colliders[0].weight;
+    return MPMHIP_OK;
+  }
   int rc, nf = c->num_mesh_f;
   for (int i = 0; i < 2; ++i)
     if ((rc = dalloc(c, &f->fkeys[i], (size_t)nf))) return rc;
@@ -2178,7 +2287,10 @@ int fast_add_collider_storage(mpmhip_ctx *c, MeshCollider &mc) {
 
 int fast_add_mover_storage(mpmhip_ctx *c, Mover &mv) {
   FastState *f = c->fast;
-  if (!c->movers.empty()) return fail(c, MPMHIP_ERR_LIMIT, "fast mode supports one particle mover (the reference drivers register one)");
+  if (!c->movers.empty()) {  // every mover is handed the same joint velocities (mpm_solver.py:421-481) and OVERWRITES the
+    mv.weight = c->movers[0].weight;  // touched nodes: a second one repeats the first one's result exactly
+    return MPMHIP_OK;
+  }
   int rc = MPMHIP_OK;
   for (int i = 0; i < 2 && !rc; ++i) rc = dalloc(c, &f->mov2[i], f->nblocks * GCH_MOV * 64);
   select_buffer(f, f->par);
@@ -2364,6 +2476,8 @@ static int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
   GridParams gp{dt, c->sc.g[0], c->sc.g[1], c->sc.g[2], c->sc.grid_v_damping_scale, (float)c->time,
                 (c->colliders.empty() || !c->num_mesh_f) ? 0 : 1, c->movers.empty() ? 0 : 1, mov_on ? 1 : 0,
                 c->colliders.empty() ? 0.0f : c->colliders[0].friction, 0};
+  gp.n_col_more = std::max(0, std::min(3, (int)c->colliders.size() - 1));
+  for (int k = 0; k < gp.n_col_more; ++k) gp.col_friction_more[k] = c->colliders[k + 1].friction;
   BCList bcl{};
   bcl.n = (int)c->bcs.size();
   for (int k = 0; k < bcl.n; ++k) bcl.bc[k] = c->bcs[k];
@@ -2705,7 +2819,7 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
     if ((rc = fast_dist_phase(c, 1, a))) return rc;
     if (!f->ghost_g2p && (rc = rccl_exchange(c, false))) return rc;
     if ((rc = fast_dist_phase(c, 2, a))) return rc;
-    c->time = c->time + (double)dt;
+    c->time = c->time + c->time_inc(dt);
     c->substeps += 1;
     f->dist_since += 1;
     if (adaptive && !f->dflag_pending && f->dist_since % DIST_POLL == 0) {

@@ -317,6 +317,9 @@ def run(ss: ShardedSim, n_steps: int):
     dp = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
     jv, jf = sim.joint_verts_v, sim.joint_faces_v
     dummy = sv._dummy_ptr()
+    if sv._host_dt != sc.dt:  # MPMWARP.time advances by the Python float (mpm_solver.py:536)
+        sv._call("mpmhip_set_host_dt", float(sc.dt))
+        sv._host_dt = sc.dt
     if ss.transport == "rccl":
         jvp = None if jv is None else (dp(jv) or dummy)
         jfp = None if jf is None else (dp(jf) or dummy)

@@ -88,6 +88,7 @@ class MPMWARP(object):
         self._masks = []
         self._profiling = False
         self._read_snaps = {}
+        self._host_dt = None
         # bookkeeping lists kept for API familiarity (mpm_solver.py:30-43)
         self.grid_postprocess, self.collider_params, self.modify_bc = [], [], []
         self.mesh_colliders, self.mesh_collider_params = [], []
@@ -155,6 +156,7 @@ class MPMWARP(object):
             self._call("mpmhip_bind_state", C.byref(p))
             st._attach(self)
             self._bound_state, self._bound_state_version = st, st._version
+            self._watch(st)   # tensors the caller took before the first substep are handed-out tensors too
         md = mpm_model
         if md is not self._bound_model or md._version != self._bound_model_version:
             p = L.ModelPtrs()
@@ -166,6 +168,7 @@ class MPMWARP(object):
             self._call("mpmhip_bind_model", C.byref(p))
             md._attach(self)
             self._bound_model, self._bound_model_version = md, md._version
+            self._watch(md)
         if md._scalar_version != self._bound_scalar_version:
             g = md.gravitational_accelaration
             s = L.ModelScalars(int(md.material), float(md.friction_coeff), float(md.alpha), _f3(g), float(md.hardening),
@@ -306,6 +309,9 @@ class MPMWARP(object):
                    fused=True)
 
     def _step(self, mpm_model, mpm_state, dt, n, mesh_x, mesh_v, jt, jv, jf, fused=False):
+        if dt != self._host_dt:   # MPMWARP.time advances by the Python float, the kernels get fp32 (mpm_solver.py:536)
+            self._call("mpmhip_set_host_dt", float(dt))
+            self._host_dt = dt
         self._push_if_modified()
         self._bind(mpm_model, mpm_state)
         has_mesh = hasattr(self, "mesh")
@@ -348,7 +354,8 @@ class MPMWARP(object):
         name, ms, cnt = C.c_char_p(), C.c_double(), C.c_int64()
         for i in range(self._lib.mpmhip_profile_count(self._ctx)):
             self._lib.mpmhip_profile_get(self._ctx, i, C.byref(name), C.byref(ms), C.byref(cnt))
-            self.time_profile.setdefault(name.value.decode(), []).append(ms.value)
+            if cnt.value > 0:  # one entry per bracketed launch (a fused call of n substeps brackets n launches per phase)
+                self.time_profile.setdefault(name.value.decode(), []).extend([ms.value / cnt.value] * cnt.value)
         self._lib.mpmhip_profile_reset(self._ctx)
 
     def print_time_profile(self):

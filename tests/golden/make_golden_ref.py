@@ -337,7 +337,32 @@ def make_trace(name, sc, extra, with_pre=False):
     save(name, payload)
 
 
-def make_seq(name, sc, checkpoints, extra=None, alt=False):
+def permuted_scene(sc, seed=11):
+    """The same cloth scene with the particles enumerated in another order (joint entries stay in front of their class, as the
+    mover's launch ranges require): the serial kernels then accumulate their atomic_adds in another order -- rounding-level
+    differences in the grid sums, nothing else.  Returns the scene and the map from original to permuted particle index."""
+    import copy
+    assert sc.n_traditional == 0
+    rng = np.random.default_rng(seed)
+    n_e, n_v, njf, njv = sc.n_elements, sc.n_vertices, sc.num_joint_f, sc.num_joint_v
+    pe = np.concatenate([rng.permutation(njf), njf + rng.permutation(n_e - njf)])      # new element k = old element pe[k]
+    pv = np.concatenate([rng.permutation(njv), njv + rng.permutation(n_v - njv)])
+    inv_v = np.empty(n_v, np.int64)
+    inv_v[pv] = np.arange(n_v)
+    out = copy.deepcopy(sc)
+    order = np.concatenate([pe, n_e + pv])
+    out.x, out.v, out.vol = sc.x[order], sc.v[order], sc.vol[order]
+    out.faces = inv_v[sc.faces[pe]].astype(np.int32)
+    out.d, out.R_inv = sc.d[pe], sc.R_inv[pe]
+    if sc.joint_verts_v is not None:
+        out.joint_verts_v = sc.joint_verts_v[pv[:njv]]
+        out.joint_faces_v = np.asarray(sc.joint_faces_v).reshape(-1, 3)[pe[:njf]]
+    new_of_old = np.empty(n_e + n_v, np.int64)
+    new_of_old[order] = np.arange(n_e + n_v)
+    return out, new_of_old
+
+
+def make_seq(name, sc, checkpoints, extra=None, alt=False, permuted=False):
     """alt=True: the same run once more with svd3 / qr3 evaluated in fp32 instead of fp64 (and the other sign conventions),
     stored as alt_s<k>_*: how far the reference is from ITSELF when those two builtins are accurate to fp32 rounding only
     -- as any fp32 implementation, Warp's included, is.  This is the sensitivity envelope of the path (the cloth model's
@@ -362,6 +387,15 @@ def make_seq(name, sc, checkpoints, extra=None, alt=False):
             print(f"   {name}{' (alt)' if tag else ''}: substep {cp} after {time.time() - t0:.0f} s"
                   + (f"; yield stress now {ys.min():.3f}..{ys.max():.3f}" if ys.max() > 0 else ""), flush=True)
     wp.SVD_MODE, wp.QR_MODE = "lapack", "householder"
+    if permuted:  # second envelope sample: same builtins, other particle order (stored in the ORIGINAL order as alt2_s<k>_*)
+        psc, new_of_old = permuted_scene(sc)
+        sim = build_reference(psc)
+        for cp in checkpoints:
+            run_reference(sim, cp - sim.steps_done)
+            st = full_state(sim)
+            for f in ("particle_x", "particle_v"):
+                payload[f"alt2_s{cp}_{f}"] = st[f][new_of_old]
+            print(f"   {name} (permuted): substep {cp}", flush=True)
     payload["checkpoints"] = np.array(checkpoints)
     save(name, payload)
 
@@ -406,10 +440,10 @@ FIXTURES = {
     # --- whole-substep sequences of the small test scenes
     **{f"ref_seq_cube_{m}": (lambda m=m: make_seq(f"ref_seq_cube_{m}", _seq_cube(m), [1, 10, 50, 100], alt=True))
        for m in ["jelly", "sand", "metal", "foam", "plasticine"]},
-    "ref_seq_sheet": lambda: make_seq("ref_seq_sheet", _small_sheet(), [1, 5, 20, 40, 80], alt=True),
-    "ref_seq_sheet_gamma0": lambda: make_seq("ref_seq_sheet_gamma0", _small_sheet(gamma=0.0), [1, 10, 50, 100, 200], alt=True),
-    "ref_seq_garment": lambda: make_seq("ref_seq_garment", _small_garment(), [1, 5, 20, 40, 80], alt=True),
-    "ref_seq_garment_gamma0": lambda: make_seq("ref_seq_garment_gamma0", _small_garment(gamma=0.0), [1, 10, 50, 100], alt=True),
+    "ref_seq_sheet": lambda: make_seq("ref_seq_sheet", _small_sheet(), [1, 5, 20, 40, 80], alt=True, permuted=True),
+    "ref_seq_sheet_gamma0": lambda: make_seq("ref_seq_sheet_gamma0", _small_sheet(gamma=0.0), [1, 10, 50, 100, 200], alt=True, permuted=True),
+    "ref_seq_garment": lambda: make_seq("ref_seq_garment", _small_garment(), [1, 5, 20, 40, 80], alt=True, permuted=True),
+    "ref_seq_garment_gamma0": lambda: make_seq("ref_seq_garment_gamma0", _small_garment(gamma=0.0), [1, 10, 50, 100], alt=True, permuted=True),
     "ref_seq_demo": lambda: make_seq("ref_seq_demo", scenes.demo_mix(n_grid=24, n_sheet=10, sand=(10, 3, 6), hold=(8, 4, 40)),
                                      [1, 5, 20, 40], alt=True),
 }

@@ -179,3 +179,26 @@ def test_staged_sand_release(mode, sand, oracle_lib):
     b = harness.build_solver(mk(), "cuda:0", mode=mode)
     harness.run(b, 80, fused=True)
     assert rel(b.state.particle_x.cpu().numpy(), g["particle_x"]) < 1e-6
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_several_mesh_colliders_and_movers(mode, oracle_lib):
+    """mpm_solver.py:385-419,421-481 loop over LISTS of mesh colliders / particle movers.  All colliders splat the solver's
+    one body mesh (only the friction of their collide step differs) and every mover is handed the same joint velocities, so
+    the fast back end shares the splat and repeats the collide step; the result must match the oracle, which runs the
+    reference's loops literally."""
+    from mpmavatar_amd import harness
+    from oracle.scene_adapter import oracle_from_scene, run_scene
+    sc = scenes.small_garment()
+    o = oracle_from_scene(sc)
+    o.add_mesh_collider(friction=0.15)
+    o.add_mesh_collider(friction=0.9)
+    o.add_particle_mover()
+    run_scene(o, sc, 40)
+    sim = harness.build_solver(sc, "cuda:0", mode=mode)
+    sim.solver.add_mesh_collider(sim.solver.mesh.id, n_grid=sc.n_grid, friction=0.15)
+    sim.solver.add_mesh_collider(sim.solver.mesh.id, n_grid=sc.n_grid, friction=0.9)
+    sim.solver.add_particle_mover(n_grid=sc.n_grid)
+    harness.run(sim, 40, fused=(mode == "fast"))
+    assert rel(sim.state.particle_x.cpu().numpy(), o.x) < 1e-5
+    assert rel(sim.state.particle_v.cpu().numpy(), o.v) < 2e-3   # cloth at rest: R22 = 1 sensitivity, see module docstring
