@@ -271,6 +271,9 @@ int mpmhip_bind_gaussians(int32_t device, void *stream, int32_t n_gaussians, con
 /* dense reference-layout copies of grid_m [G^3], grid_v_in [G^3*3], grid_v_out [G^3*3] as they
  * stand after the last substep's grid stage ([dev] outputs, any may be NULL).  Synchronous. */
 int mpmhip_export_grid(mpmhip_ctx *ctx, float *grid_m, float *grid_v_in, float *grid_v_out);
+/* performance experiments only (kernel ablations, MPMHIP_DBG bit mask of csrc/fast.hip; most bits make the results wrong) */
+int mpmhip_set_debug_flags(mpmhip_ctx *ctx, int32_t flags);
+int mpmhip_debug_counter(mpmhip_ctx *ctx, int32_t index, int64_t *out); /* device-side experiment counters, synchronous */
 /* counts for the algorithmic-bytes formula; synchronous, runs small count kernels */
 int mpmhip_get_stats(mpmhip_ctx *ctx, mpmhip_stats *out);
 /* MPMWARP.time_profile / print_time_profile, mpm_solver.py:16,538-541: when enabled every phase is

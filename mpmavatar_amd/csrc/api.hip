@@ -520,6 +520,18 @@ int mpmhip_export_grid(mpmhip_ctx *c, float *grid_m, float *grid_v_in, float *gr
   return MPMHIP_OK;
 }
 
+int mpmhip_set_debug_flags(mpmhip_ctx *c, int32_t flags) {
+  CHECK_CTX(c);
+  if (!fast_mode(c) || !c->fast) return fail(c, MPMHIP_ERR_INVALID, "set_debug_flags: fast mode only");
+  return fast_set_debug_flags(c, flags);
+}
+
+int mpmhip_debug_counter(mpmhip_ctx *c, int32_t index, int64_t *out) {
+  CHECK_CTX(c);
+  if (!fast_mode(c) || !c->fast) return fail(c, MPMHIP_ERR_INVALID, "debug_counter: fast mode only");
+  return fast_debug_counter(c, index, out);
+}
+
 int mpmhip_get_stats(mpmhip_ctx *c, mpmhip_stats *out) {
   CHECK_CTX(c);
   if (!out) return fail(c, MPMHIP_ERR_INVALID, "get_stats: null");

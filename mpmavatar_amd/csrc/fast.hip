@@ -215,13 +215,14 @@ __global__ void k_export(mpmhip_state_ptrs st, mpmhip_model_ptrs md, Bufs b, VAd
 // due.  The low bits then order by the CURRENT cell relative to that block's tile (6x6x6 positions), which is what
 // the DPP pre-reduction of p2g wants to see in neighbouring lanes.  cell_bits == 6 (very large grids whose keys would
 // not fit 32 bits otherwise): no prediction, cell = position inside the block.
+typedef unsigned SortKey;  // class | state | block | tile cell: 2 + 2 + 18 + 8 = 30 bits at 256^3
 __device__ __forceinline__ int kf_blk(int kf) { return kf & 255; }
 __device__ __forceinline__ int kf_cell(int kf) { return kf >> 8; }
-__device__ __forceinline__ unsigned make_key(V3 x, V3 v, float lead, int cls, int state, const Dims &d, int kf) {
+__device__ __forceinline__ SortKey make_key(V3 x, V3 v, float lead, int cls, int state, const Dims &d, int kf) {
   int bb = kf_blk(kf), cb = kf_cell(kf);
   int cx = (int)(x.x * d.inv_dx - 0.5f), cy = (int)(x.y * d.inv_dx - 0.5f), cz = (int)(x.z * d.inv_dx - 0.5f);
   int bx = cx, by = cy, bz = cz;
-  if (cb == 8) {
+  if (cb >= 8) {
     float lim = d.dx;  // at most one cell: the current cell must stay inside the predicted block's tile margin
     V3 xp = v3(x.x + fminf(fmaxf(lead * v.x, -lim), lim), x.y + fminf(fmaxf(lead * v.y, -lim), lim),
                x.z + fminf(fmaxf(lead * v.z, -lim), lim));
@@ -229,18 +230,18 @@ __device__ __forceinline__ unsigned make_key(V3 x, V3 v, float lead, int cls, in
     bx = min(max(px, cx - 1), cx + 1); by = min(max(py, cy - 1), cy + 1); bz = min(max(pz, cz - 1), cz + 1);
   }
   bx = min(max(bx, 0), d.G - 3); by = min(max(by, 0), d.G - 3); bz = min(max(bz, 0), d.G - 3);
-  unsigned blk = (unsigned)blk_of(bx, by, bz, d.NB);
-  unsigned cell;
-  if (cb == 8) {  // current cell in the predicted block's tile: 0..5 per axis when inside the margin (clamped otherwise)
+  SortKey blk = (SortKey)blk_of(bx, by, bz, d.NB);
+  SortKey cell;
+  if (cb >= 8) {  // current cell in the predicted block's tile: 0..5 per axis when inside the margin (clamped otherwise)
     int lx = min(max(cx - (4 * (bx >> 2) - 1), 0), 5), ly = min(max(cy - (4 * (by >> 2) - 1), 0), 5), lz = min(max(cz - (4 * (bz >> 2) - 1), 0), 5);
-    cell = (unsigned)((lx * 6 + ly) * 6 + lz);
+    cell = (SortKey)((lx * 6 + ly) * 6 + lz);
   } else {
-    cell = (unsigned)loc_of(bx, by, bz);
+    cell = (SortKey)loc_of(bx, by, bz);
   }
-  return ((unsigned)cls << (bb + cb + 2)) | ((unsigned)state << (bb + cb)) | (blk << cb) | cell;
+  return ((SortKey)cls << (bb + cb + 2)) | ((SortKey)state << (bb + cb)) | (blk << cb) | cell;
 }
 
-__global__ void k_keys(Bufs b, Dims d, int kf, float lead, int ghost_g2p, unsigned *keys, int *iota) {
+__global__ void k_keys(Bufs b, Dims d, int kf, float lead, int ghost_g2p, SortKey *keys, int *iota) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= d.n_p) return;
   int cls = s < d.n_e ? 0 : (s < d.n_nv ? 1 : 2);
@@ -278,14 +279,14 @@ __global__ void k_face_slots(Bufs b, const int *inv, int *face_slot, Dims d) {
 }
 
 // (the parameter named blk_bits below is the packed key format kf)
-__device__ __forceinline__ int key_block(unsigned k, int kf) { return (int)((k >> kf_cell(kf)) & ((1u << kf_blk(kf)) - 1u)); }
-__device__ __forceinline__ int key_state(unsigned k, int kf) { return (int)((k >> (kf_blk(kf) + kf_cell(kf))) & 3u); }
-__device__ __forceinline__ bool key_inactive(unsigned k, int blk_bits) { return key_state(k, blk_bits) >= 2; }
+__device__ __forceinline__ int key_block(SortKey k, int kf) { return (int)((k >> kf_cell(kf)) & ((1u << kf_blk(kf)) - 1u)); }
+__device__ __forceinline__ int key_state(SortKey k, int kf) { return (int)((k >> (kf_blk(kf) + kf_cell(kf))) & 3u); }
+__device__ __forceinline__ bool key_inactive(SortKey k, int blk_bits) { return key_state(k, blk_bits) >= 2; }
 
-__global__ void k_mark_blocks(const unsigned *keys, int n, int blk_bits, int *pb_flag) {
+__global__ void k_mark_blocks(const SortKey *keys, int n, int blk_bits, int *pb_flag) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
-  unsigned k = keys[s];
+  SortKey k = keys[s];
   if (!key_inactive(k, blk_bits)) pb_flag[key_block(k, blk_bits)] = 1;
 }
 
@@ -295,10 +296,10 @@ __global__ void k_compact(const int *flag, const int *index, int n, int *list) {
 }
 
 // ranges[(cls*2+0)*n_P + slot] = first sorted index, [(cls*2+1)*n_P + slot] = one past the last
-__global__ void k_ranges(const unsigned *keys, Dims d, int blk_bits, const int *pb_index, int n_P, int *ranges) {
+__global__ void k_ranges(const SortKey *keys, Dims d, int blk_bits, const int *pb_index, int n_P, int *ranges) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= d.n_p) return;
-  unsigned k = keys[s];
+  SortKey k = keys[s];
   if (key_inactive(k, blk_bits)) return;
   int cls = s < d.n_e ? 0 : (s < d.n_nv ? 1 : 2);
   int c0 = cls == 0 ? 0 : (cls == 1 ? d.n_e : d.n_nv), c1 = cls == 0 ? d.n_e : (cls == 1 ? d.n_nv : d.n_p);
@@ -337,7 +338,7 @@ struct GridPtrs {
   int *m_flag;      // [block] 1 = p2g (or a halo sum) may have written this block's mass / momentum this substep
   int *counters;    // [0] particles outside their tile margin, [1] dropped contributions (inactive block)
   int dbg;          // MPMHIP_DBG bitmask (perf experiments only, results are wrong): 1 skip p2g flush, 2 skip the p2g
-                    // scatter, 8 / 16 skip vertex-force / stress loads, 128 skip the LDS atomics only; 64 (results stay
+                    // scatter, 8 / 16 skip vertex-force / stress loads, 128 skip the LDS atomics only, 256 skip the splat workgroups; 64 (results stay
                     // right) runs the stand-alone element finalize every substep instead of fusing it into the stress kernel
 };
 
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(TPB) void k_zero_blocks(ZeroArgs z) { zero_blocks_w
 // finished elements earlier (re-sort, read-back, pre-p2g operations, joint-face splats, multi-GPU ghosts).
 template <bool FINALIZE>
 __global__ void k_stress_elem(Bufs b, F3 *ef, Dims d, float friction_coeff, const int *face_slot,
-                              const unsigned *skeys, int blk_bits, int *counters) {
+                              const SortKey *skeys, int blk_bits, int *counters) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.n_e) return;
   if (b.sel[e] == 1) {  // not simulated (selection == 2 marks a ghost copy: stress yes, transfers no)
@@ -834,17 +835,19 @@ __device__ __forceinline__ P2GRaw p2g_issue(const Bufs &b, const VAdj &va, bool 
   if (w_v) r.ab = adj_load(va, (valid && cls == 2) ? s - d.n_nv : 0, 0);
   return r;
 }
+// Lanes without a particle (valid = false) loaded slot 0 and keep its (finite) stencil / velocity data with zero forces: they
+// only have to stay finite -- their key is unique, so the segmented scan never merges them with a neighbour (a masked DPP
+// step still multiplies the neighbour's value by 0.0) and they never issue an atomic.  No select between two particle
+// records: hipcc lowers a select on the aggregate through scratch memory.
 template <bool TRAD>
 __device__ __forceinline__ P2GParticle p2g_finish(const P2GRaw &r, const Bufs &b, const VAdj &va, bool valid, int cls, int s,
-                                                  const Dims &d, float rpic, float dt, bool w_v, const P2GParticle &zero,
-                                                  const TradParams &tp) {
+                                                  const Dims &d, float rpic, float dt, bool w_v, const TradParams &tp) {
   V3 vf = v3(0, 0, 0);
   if (w_v) {
     vf = adj_gather(va, r.ab, vf);
     int vl = (valid && cls == 2) ? s - d.n_nv : 0;
     for (int k0 = ADJ_BATCH; k0 < va.K; k0 += ADJ_BATCH) vf = adj_gather(va, adj_load(va, vl, k0), vf);
   }
-  if (!valid) return zero;
   P2GParticle q;
   q.s = make_stencil(r.x, d.inv_dx);
   q.mass = r.mass;
@@ -855,9 +858,9 @@ __device__ __forceinline__ P2GParticle p2g_finish(const P2GRaw &r, const Bufs &b
   q.Cdx = d.dx * C;
   q.Sdt = m3_zero();
   q.vfdt = v3(0, 0, 0);
-  if (cls == 0) {
+  if (valid && cls == 0) {
     q.Sdt = (-dt * d.inv_dx) * r.S;
-  } else if (cls == 1) {
+  } else if (valid && cls == 1) {
     M3 S = r.S;
     if (TRAD) {  // r.S holds F_trial: k_stress_trad's body
       int t = s - d.n_e;
@@ -870,7 +873,7 @@ __device__ __forceinline__ P2GParticle p2g_finish(const P2GRaw &r, const Bufs &b
       st9(b.nv, N_STRESS, s, S);
     }
     q.Sdt = (-dt * d.inv_dx * r.vol) * S;
-  } else {
+  } else if (valid) {
     q.vfdt = dt * vf;
   }
   return q;
@@ -880,7 +883,7 @@ template <bool TRAD>
 __device__ __forceinline__ P2GParticle p2g_load(const Bufs &b, const VAdj &va, int cls, int s, const Dims &d, float rpic,
                                                 float dt, const TradParams &tp) {
   P2GRaw r = p2g_issue<TRAD>(b, va, true, cls, s, d, cls != 2, cls == 2);
-  return p2g_finish<TRAD>(r, b, va, true, cls, s, d, rpic, dt, cls == 2, P2GParticle{}, tp);
+  return p2g_finish<TRAD>(r, b, va, true, cls, s, d, rpic, dt, cls == 2, tp);
 }
 
 // ---- wave-level pre-reduction -------------------------------------------------------------------------
@@ -1014,8 +1017,7 @@ __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p
     int lx = q.s.bx - ox, ly = q.s.by - oy, lz = q.s.bz - oz;
     if ((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u) {
       esc[atomicAdd(&esc_n, 1)] = (int)threadIdx.x;  // drifted out of the tile margin: handled after the tile pass
-      valid = false;
-      q = p2g_zero(ox, oy, oz, d);
+      valid = false;  // (keeps its finite values: unique key, no atomics -- see p2g_finish)
     } else {
       key = (lx * TILE + ly) * TILE + lz;
       base = tile_idx(lx, ly, lz);
@@ -1028,6 +1030,10 @@ __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p
     int dist = __ffsll((unsigned long long)(tails >> (threadIdx.x & 63))) - 1;
     bool do_add = valid && (dist & ((1 << STEPS) - 1)) == 0;
     if (g.dbg & 128) do_add = false;
+    if (g.dbg & 512) {  // measurement: lanes that issue LDS atomics per lane that holds a particle
+      unsigned long long ba = __ballot(do_add), bv = __ballot(valid);
+      if ((threadIdx.x & 63) == 0) { atomicAdd(g.counters + 8, __popcll(ba)); atomicAdd(g.counters + 9, __popcll(bv)); }
+    }
     const Stencil &st = q.s;
     // factored stencil: add_ijk = wz_k (wxym_ij (B_ij + k Cz) + P_ij) + dwz_k Q_ij,  wm = wxym_ij wz_k,  wxym = wx wy m
     V3 Cx = col0(q.Cdx), Cy = col1(q.Cdx), Cz = col2(q.Cdx);
@@ -1115,6 +1121,7 @@ __global__ __launch_bounds__(PT) void k_p2g(Bufs b, VAdj va, const ChunkRec *rec
   __shared__ int esc_n;
   if ((int)blockIdx.x < sa.n_extra) {  // extra workgroups first: they are the long-latency ones
     int e = blockIdx.x;
+    if (g.dbg & 256) return;
     if (e < sa.n_fbins) col_splat_wg(tile, sa, e, d, g);
     else if (e < sa.n_fbins + sa.n_mov_wg) mover_splat_wg(b, sa.js, e - sa.n_fbins, d, g);
     return;
@@ -1146,7 +1153,7 @@ __global__ __launch_bounds__(PT) void k_p2g(Bufs b, VAdj va, const ChunkRec *rec
         fz = (int)((raw.x.z + la * raw.v.z) * d.inv_dx - 0.5f) - oz;
     if ((unsigned)fx > 5u || (unsigned)fy > 5u || (unsigned)fz > 5u) g.counters[6] = 1;
   }
-  P2GParticle q = p2g_finish<TRAD>(raw, b, va, valid, cls, s, d, rpic, dt, w_v, p2g_zero(ox, oy, oz, d), tp);
+  P2GParticle q = p2g_finish<TRAD>(raw, b, va, valid, cls, s, d, rpic, dt, w_v, tp);
   __syncthreads();
   p2g_scatter<STEPS>(tile, esc, &esc_n, q, valid, ox, oy, oz, d, g);
   __syncthreads();
@@ -1252,95 +1259,6 @@ __device__ __forceinline__ G2PResult g2p_gather(const float4 *tile, int ox, int 
   return g2p_finish(s, d, nv, Mx, My, Mz, Fx, Fy, Fz);
 }
 
-#ifndef MPMHIP_G2P_PK
-#define MPMHIP_G2P_PK 1
-#endif
-#if MPMHIP_G2P_PK
-// the same gather in two passes (velocity + APIC matrix, then the velocity gradient): 12 and 9 accumulators instead
-// of 21 at a time.  The sums are written on PAIRS of accumulators (ext_vector_type(2)) so that hipcc emits
-// v_pk_fma_f32 -- two fp32 FMAs per issue slot, the scalar factor broadcast through op_sel -- instead of one v_fma_f32
-// per component: g2p is bound by VALU issue (690 VALU instructions per wavefront, SIMDs ~100 % busy at five waves), not by
-// LDS or HBM.  Pairing: (x, y) of every vector, and the z components two by two where they share a source
-// ((s0.z, s2.z) <- u.z; (nv.z, Mz.z) <- (s0.z, s2.z); (Mx.z, My.z) <- s0.z).  Same products, same summation order per
-// accumulator as the scalar form above.
-typedef float F2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ F2 f2s(float a) { return F2{a, a}; }
-__device__ __forceinline__ F2 fma2(F2 a, F2 b, F2 c) { return __builtin_elementwise_fma(a, b, c); }
-
-__device__ __forceinline__ void g2p_gather_vC(const float4 *tile, int ox, int oy, int oz, V3 x, const Dims &d, V3 &v, M3 &C) {
-  Stencil s = make_stencil(x, d.inv_dx);
-  int base = tile_idx(s.bx - ox, s.by - oy, s.bz - oz);
-  F2 nvxy = f2s(0.f), nvz_Mzz = f2s(0.f), Mzxy = f2s(0.f), Mxxy = f2s(0.f), Myxy = f2s(0.f), Mxz_Myz = f2s(0.f);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    float wx = bspline_w(i, s.fx.x);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float wy = bspline_w(j, s.fx.y);
-      F2 s0xy = f2s(0.f), s0z_s2z = f2s(0.f), s2xy = f2s(0.f);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        float wzk = sel3(k, s.w0.z, s.w1.z, s.w2.z);
-        const float4 t4 = tile[base + tile_idx(i, j, k)];
-        F2 uxy = F2{t4.x, t4.y};
-        s0xy = fma2(f2s(wzk), uxy, s0xy);
-        if (k > 0) {
-          float kw = (float)k * wzk;
-          s0z_s2z = fma2(F2{wzk, kw}, f2s(t4.z), s0z_s2z);
-          s2xy = fma2(f2s(kw), uxy, s2xy);
-        } else {
-          s0z_s2z.x = fmaf(wzk, t4.z, s0z_s2z.x);
-        }
-      }
-      float wxy = wx * wy;
-      nvxy = fma2(f2s(wxy), s0xy, nvxy);
-      nvz_Mzz = fma2(f2s(wxy), s0z_s2z, nvz_Mzz);
-      Mzxy = fma2(f2s(wxy), s2xy, Mzxy);
-      if (i > 0) Mxxy = fma2(f2s((float)i * wxy), s0xy, Mxxy);
-      if (j > 0) Myxy = fma2(f2s((float)j * wxy), s0xy, Myxy);
-      if (i > 0 || j > 0) Mxz_Myz = fma2(F2{(float)i * wxy, (float)j * wxy}, f2s(s0z_s2z.x), Mxz_Myz);
-    }
-  }
-  float c4 = 4.0f * d.inv_dx;
-  V3 nv = v3(nvxy.x, nvxy.y, nvz_Mzz.x);
-  V3 Mx = v3(Mxxy.x, Mxxy.y, Mxz_Myz.x), My = v3(Myxy.x, Myxy.y, Mxz_Myz.y), Mz = v3(Mzxy.x, Mzxy.y, nvz_Mzz.y);
-  v = nv;
-  C = m3_cols(c4 * (Mx - s.fx.x * nv), c4 * (My - s.fx.y * nv), c4 * (Mz - s.fx.z * nv));
-}
-__device__ __forceinline__ M3 g2p_gather_grad(const float4 *tile, int ox, int oy, int oz, V3 x, const Dims &d) {
-  Stencil s = make_stencil(x, d.inv_dx);
-  int base = tile_idx(s.bx - ox, s.by - oy, s.bz - oz);
-  F2 Fxxy = f2s(0.f), Fyxy = f2s(0.f), Fzxy = f2s(0.f), Fxz_Fyz = f2s(0.f);
-  float Fzz = 0.f;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    float wx = bspline_w(i, s.fx.x), dwx = bspline_dw(i, s.fx.x);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float wy = bspline_w(j, s.fx.y), dwy = bspline_dw(j, s.fx.y);
-      F2 s0xy = f2s(0.f), s0z_s1z = f2s(0.f), s1xy = f2s(0.f);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        float wzk = sel3(k, s.w0.z, s.w1.z, s.w2.z), dwzk = bspline_dw(k, s.fx.z);
-        const float4 t4 = tile[base + tile_idx(i, j, k)];
-        F2 uxy = F2{t4.x, t4.y};
-        s0xy = fma2(f2s(wzk), uxy, s0xy);
-        s0z_s1z = fma2(F2{wzk, dwzk}, f2s(t4.z), s0z_s1z);
-        s1xy = fma2(f2s(dwzk), uxy, s1xy);
-      }
-      float a = dwx * wy, bb = wx * dwy, c = wx * wy;
-      Fxxy = fma2(f2s(a), s0xy, Fxxy);
-      Fyxy = fma2(f2s(bb), s0xy, Fyxy);
-      Fzxy = fma2(f2s(c), s1xy, Fzxy);
-      Fxz_Fyz = fma2(F2{a, bb}, f2s(s0z_s1z.x), Fxz_Fyz);
-      Fzz = fmaf(c, s0z_s1z.y, Fzz);
-    }
-  }
-  V3 Fx = v3(Fxxy.x, Fxxy.y, Fxz_Fyz.x), Fy = v3(Fyxy.x, Fyxy.y, Fxz_Fyz.y), Fz = v3(Fzxy.x, Fzxy.y, Fzz);
-  return m3_cols(d.inv_dx * Fx, d.inv_dx * Fy, d.inv_dx * Fz);
-}
-
-#else
 // the same gather in two passes (velocity + APIC matrix, then the velocity gradient): 12 and 9 accumulators instead
 // of 21 at a time
 __device__ __forceinline__ void g2p_gather_vC(const float4 *tile, int ox, int oy, int oz, V3 x, const Dims &d, V3 &v, M3 &C) {
@@ -1399,8 +1317,6 @@ __device__ __forceinline__ M3 g2p_gather_grad(const float4 *tile, int ox, int oy
   }
   return m3_cols(d.inv_dx * Fx, d.inv_dx * Fy, d.inv_dx * Fz);
 }
-
-#endif
 
 // same sums for a particle that drifted out of its tile margin: rolled loop over the global grid (zero outside
 // active blocks); kept small so that it does not set the kernel's register budget
@@ -1480,12 +1396,6 @@ __device__ __forceinline__ void g2p_write(const Bufs &b, int cls, int s, V3 x, V
 // 95 instead of 114 VGPRs, a fifth wavefront per SIMD.  Pays when many lanes are vertices (cloth scenes: a third of the
 // particles skip the second sweep); traditional-only scenes read every node twice and keep the single sweep.
 template <bool FUSED, bool TWO_PASS>
-#ifndef MPMHIP_G2P_WAVES
-#define MPMHIP_G2P_WAVES 0
-#endif
-#if MPMHIP_G2P_WAVES
-__attribute__((amdgpu_waves_per_eu(MPMHIP_G2P_WAVES, 8)))
-#endif
 __global__ __launch_bounds__(PT) void k_g2p(Bufs b, const ChunkRec *recs, int n_chunks, Dims d, float dt, GridPtrs g,
                                              GridParams gp, BCList bcl) {
   __shared__ float4 tile[TILE_PAD];  // node velocity, 16 bytes per node
@@ -1580,7 +1490,7 @@ __global__ __launch_bounds__(PT) void k_g2p(Bufs b, const ChunkRec *recs, int n_
 }
 
 // second half of g2p_e (mpm_utils.py:838-857): x, v = mean of the three updated vertices; d1, d2 = edges
-__global__ void k_elem_finalize(Bufs b, const int *face_slot, const unsigned *skeys, int blk_bits, int *counters, Dims d) {
+__global__ void k_elem_finalize(Bufs b, const int *face_slot, const SortKey *skeys, int blk_bits, int *counters, Dims d) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.n_e) return;
   if (b.sel[e] == 1) return;
@@ -1862,7 +1772,7 @@ struct FastState {
   int *adj_cnt = nullptr, *adj_o = nullptr, *adj_s = nullptr;
   int adj_K = 0, adj_cap = 0;
   VAdj va() const { return VAdj{adj_s, eforce, adj_K, d.n_v, d.n_e}; }
-  unsigned *keys[2] = {nullptr, nullptr};
+  SortKey *keys[2] = {nullptr, nullptr};
   int *order = nullptr, *iota = nullptr;
   void *sort_tmp = nullptr, *scan_tmp = nullptr;
   size_t sort_tmp_bytes = 0, scan_tmp_bytes = 0;
@@ -2092,7 +2002,7 @@ int rebin(mpmhip_ctx *c) {
   if (d.n_e) hipLaunchKernelGGL(k_face_slots, nblk(d.n_e), TPB, 0, s, f->buf[cur], f->inv, f->face_slot, d);
   if (d.n_e && d.n_v)
     hipLaunchKernelGGL(k_adj_sorted, nblk(d.n_v), TPB, 0, s, f->adj_o, f->adj_s, f->perm[cur], f->inv, f->adj_K, d);
-  const unsigned *skeys = f->keys[1];
+  const SortKey *skeys = f->keys[1];
   int nb = (int)f->nblocks;
   MPM_HIP_CHECK(c, hipMemsetAsync(f->pb_flag, 0, f->nblocks * sizeof(int), s));
   MPM_HIP_CHECK(c, hipMemsetAsync(f->ab_flag, 0, f->nblocks * sizeof(int), s));
@@ -2236,7 +2146,7 @@ int fast_init(mpmhip_ctx *c) {
   }
   select_buffer(f, 0);
   if ((rc = dalloc(c, &f->g.vout, f->nblocks * GCH_VOUT * 64))) return rc;
-  if ((rc = dalloc(c, &f->g.counters, 8))) return rc;
+  if ((rc = dalloc(c, &f->g.counters, 16))) return rc;
   if ((rc = dalloc(c, &f->pb_flag, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->pb_index, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->ab_flag, f->nblocks))) return rc;
@@ -2852,6 +2762,19 @@ int fast_export_grid(mpmhip_ctx *c, float *m, float *v_in, float *v_out) {
   materialize_grid(c, false);
   if (f->n_A) hipLaunchKernelGGL(k_export_grid, (unsigned)((f->n_A + 3) / 4), TPB, 0, c->stream, f->alist, f->n_A, d, f->g, m, v_out);
   MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return MPMHIP_OK;
+}
+
+int fast_set_debug_flags(mpmhip_ctx *c, int flags) {
+  c->fast->g.dbg = flags;
+  return MPMHIP_OK;
+}
+int fast_debug_counter(mpmhip_ctx *c, int index, int64_t *out) {
+  if (index < 0 || index >= 16 || !out) return fail(c, MPMHIP_ERR_INVALID, "debug_counter: index out of range");
+  int v = 0;
+  MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  MPM_HIP_CHECK(c, hipMemcpy(&v, c->fast->g.counters + index, sizeof(int), hipMemcpyDeviceToHost));
+  *out = v;
   return MPMHIP_OK;
 }
 
