@@ -166,7 +166,10 @@ def _main(out_stream):
             dist.init_process_group(backend)
         sim = mdist.build_sharded(sc, dev, rank, world, rebin_interval=args.rebin_interval)
         transport = sim.transport
-        run = lambda n: mdist.run(sim, n)
+        box = {"ss": sim}
+
+        def run(n):  # a re-partition (particle migration) replaces the sharded simulation object
+            box["ss"] = mdist.run(box["ss"], n)
         barrier = lambda: dist.barrier()
     else:
         sim = harness.build_solver(sc, dev, mode=args.mode, rebin_interval=args.rebin_interval)

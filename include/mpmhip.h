@@ -247,9 +247,11 @@ int mpmhip_rccl_set_ghosts(mpmhip_ctx *ctx, int32_t n_peers, const int32_t *peer
  * substeps, read 4 substeps later so that all ranks act at the same substep) asks for it, at the latest every 256
  * (or -rebin_interval) substeps.  Halo (and, in ghost mode 0, ghost) exchanges with ncclSend/ncclRecv groups on the context's stream; in ghost mode 1
  * the ghosts are re-synchronised before every re-sort instead.  Mesh advection factor of substep k is
- * (step_index + k) * dt */
+ * (step_index + k) * dt.  joint_traditional_v: velocities of the LAST n_joint_t traditional particles this rank owns (the
+ * staged release of run_demo.py:524; a rank's share of the held particles is a suffix of its owned ones), or NULL */
 int mpmhip_rccl_steps(mpmhip_ctx *ctx, float dt, int32_t n, int64_t step_index, int32_t rebin_interval,
-                      const float *mesh_x, const float *mesh_v, const float *joint_verts_v, const float *joint_faces_v);
+                      const float *mesh_x, const float *mesh_v, const float *joint_traditional_v, int32_t n_joint_t,
+                      const float *joint_verts_v, const float *joint_faces_v);
 
 /* ---- after the solver: per-face frames and bound Gaussians --------------------------------
  * Stand-alone maps on [dev] arrays (no solver context; `stream` is a hipStream_t, NULL = default stream).

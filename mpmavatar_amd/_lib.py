@@ -104,7 +104,7 @@ SIGNATURES = {
     "mpmhip_rccl_unique_id": (C.c_int, [C.c_char * 128]),
     "mpmhip_rccl_init": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_char * 128]),
     "mpmhip_rccl_set_ghosts": (C.c_int, [vp, C.c_int32, ip, ip, C.POINTER(ip), ip, C.POINTER(ip), ip, C.POINTER(ip), ip, C.POINTER(ip)]),
-    "mpmhip_rccl_steps": (C.c_int, [vp, C.c_float, C.c_int32, C.c_int64, C.c_int32, vp, vp, vp, vp]),
+    "mpmhip_rccl_steps": (C.c_int, [vp, C.c_float, C.c_int32, C.c_int64, C.c_int32, vp, vp, vp, C.c_int32, vp, vp]),
     "mpmhip_synchronize": (C.c_int, [vp]),
     "mpmhip_get_time": (C.c_double, [vp]),
     "mpmhip_set_time": (C.c_int, [vp, C.c_double]),

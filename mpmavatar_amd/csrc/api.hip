@@ -444,11 +444,13 @@ int mpmhip_dist_step_begin(mpmhip_ctx *c, float dt, const float *mesh_x, const f
 }
 int mpmhip_dist_step_mid(mpmhip_ctx *c) {
   CHECK_CTX(c);
+  if (!fast_mode(c) || !c->fast) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
   StepArgs a{};
   return fast_dist_phase(c, 1, a);
 }
 int mpmhip_dist_step_end(mpmhip_ctx *c) {
   CHECK_CTX(c);
+  if (!fast_mode(c) || !c->fast) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
   StepArgs a{};
   int rc = fast_dist_phase(c, 2, a);
   if (rc) return rc;
@@ -475,13 +477,15 @@ int mpmhip_rccl_set_ghosts(mpmhip_ctx *c, int32_t n_peers, const int32_t *peer_r
   return fast_rccl_set_ghosts(c, n_peers, peer_ranks, n_send_p, send_p, n_recv_p, recv_p, n_send_e, send_e, n_recv_e, recv_e);
 }
 int mpmhip_rccl_steps(mpmhip_ctx *c, float dt, int32_t n, int64_t step_index, int32_t rebin_interval, const float *mesh_x,
-                      const float *mesh_v, const float *joint_verts_v, const float *joint_faces_v) {
+                      const float *mesh_v, const float *joint_traditional_v, int32_t n_joint_t, const float *joint_verts_v,
+                      const float *joint_faces_v) {
   CHECK_CTX(c);
   if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
   if (!c->st_bound || !c->md_bound) return fail(c, MPMHIP_ERR_STATE, "step: state/model not bound");
   if ((mesh_x || mesh_v) && !c->mesh_points) return fail(c, MPMHIP_ERR_STATE, "step: mesh_x/mesh_v given but no body mesh");
   c->fast_dt = dt;
-  int rc = fast_rccl_steps(c, dt, n, step_index, rebin_interval, mesh_x, mesh_v, joint_verts_v, joint_faces_v);
+  int rc = fast_rccl_steps(c, dt, n, step_index, rebin_interval, mesh_x, mesh_v, joint_traditional_v,
+                           joint_traditional_v ? n_joint_t : 0, joint_verts_v, joint_faces_v);
   if (rc) return rc;
   if (n > 0 && (mesh_x || mesh_v)) {
     size_t nm = (size_t)c->num_mesh_v * 3;

@@ -183,7 +183,7 @@ int fast_rccl_set_ghosts(mpmhip_ctx *ctx, int n, const int32_t *ranks, const int
                          const int32_t *nrp, const int32_t *const *rp, const int32_t *nse, const int32_t *const *se,
                          const int32_t *nre, const int32_t *const *re);
 int fast_rccl_steps(mpmhip_ctx *ctx, float dt, int n, int64_t step_index, int rebin_interval, const float *mesh_x,
-                    const float *mesh_v, const float *jv, const float *jf);
+                    const float *mesh_v, const float *jt, int n_jt, const float *jv, const float *jf);
 
 // shared small kernels (common.hip)
 int launch_pre_ops(mpmhip_ctx *ctx, float dt, float *v, const float *x, const float *mass, int n);

@@ -2682,7 +2682,7 @@ static int rccl_exchange(mpmhip_ctx *c, bool halo) {
 }
 
 int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebin_interval, const float *mesh_x,
-                    const float *mesh_v, const float *jv, const float *jf) {
+                    const float *mesh_v, const float *jt, int n_jt, const float *jv, const float *jf) {
   FastState *f = c->fast;
   if (!f->rccl.comm) return fail(c, MPMHIP_ERR_STATE, "rccl_steps: call mpmhip_rccl_init first");
   // rebin_interval > 0: every rank re-sorts at substeps that are multiples of it.  <= 0: when any rank's early-warning
@@ -2693,7 +2693,7 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
   int rc;
   for (int k = 0; k < n; ++k) {
     int64_t idx = step_index + k;
-    StepArgs a{dt, mesh_x, mesh_v, (float)((double)dt * (double)idx), true, nullptr, 0, jv, jf};
+    StepArgs a{dt, mesh_x, mesh_v, (float)((double)dt * (double)idx), true, jt, jt ? n_jt : 0, jv, jf};
     c->cur_pts = a.mesh_x ? a.mesh_x : c->mesh_points;
     c->cur_vel = a.mesh_v ? a.mesh_v : c->mesh_vel;
     c->cur_f = (a.mesh_x && a.mesh_v) ? a.mesh_f : 0.0f;

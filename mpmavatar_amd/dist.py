@@ -2,9 +2,13 @@
 which is single-GPU).
 
 Decomposition
-  * static ownership: vertices and traditional particles are assigned to ranks by the quantile slab of their
-    initial x coordinate, an element to the owner of its first vertex.  Ownership never migrates, so the ghost
-    lists below are built once (cloth keeps its neighbourhood; spatial overlap of ranks only widens the halo).
+  * ownership: vertices and traditional particles are assigned to ranks by the quantile slab of their x coordinate at
+    the last (re-)partition, an element to the owner of its first vertex.  Between re-partitions ownership is fixed (the
+    ghost lists below are built once per partition; particles that wander into a neighbour's slab only widen the halo).
+    MIGRATION: ``maybe_repartition`` (called at the start of every ``run``) counts the owned particles that have left
+    their slab and, when more than ``migrate_fraction`` of them have, gathers the state of all ranks, cuts new slabs at the
+    current positions and rebuilds every rank's shard -- a stop-the-world step that costs about as much as the
+    initial build and is needed every few thousand substeps at most.
   * ghosts: a rank also holds (a) every element that touches one of its vertices (so vertex forces are complete
     without an exchange) and (b) every vertex of its local elements.  Ghost copies carry particle_selection == 2:
     stress / element finalise run on them, p2g / g2p do not.
@@ -52,6 +56,7 @@ class Shard:
     recv_e: Dict[int, np.ndarray] = field(default_factory=dict)
     send_p_gid: Dict[int, np.ndarray] = field(default_factory=dict)  # the same lists as global ids (tests)
     recv_p_gid: Dict[int, np.ndarray] = field(default_factory=dict)
+    cuts: np.ndarray = None           # the world-1 slab boundaries (x) of this partition
 
 
 def _owners(sc: Scene, world: int):
@@ -62,13 +67,13 @@ def _owners(sc: Scene, world: int):
     owner_v = np.searchsorted(cuts, xv, side="right").astype(np.int32)
     owner_t = np.searchsorted(cuts, xt, side="right").astype(np.int32)
     owner_e = owner_v[sc.faces[:, 0]] if n_e else np.zeros(0, np.int32)
-    return owner_e, owner_t, owner_v
+    return owner_e, owner_t, owner_v, np.asarray(cuts, np.float64)
 
 
 def partition(sc: Scene, world: int) -> List[Shard]:
     """Deterministic: every rank computes the full partition from the same Scene, no communication."""
     n_e, n_t, n_v = sc.n_elements, sc.n_traditional, sc.n_vertices
-    owner_e, owner_t, owner_v = _owners(sc, world)
+    owner_e, owner_t, owner_v, cuts = _owners(sc, world)
     faces = sc.faces.astype(np.int64)
     shards = []
     for r in range(world):
@@ -98,9 +103,9 @@ def partition(sc: Scene, world: int) -> List[Shard]:
         local = replace(sc, name=f"{sc.name}[{r}/{world}]", n_elements=int(el.size), n_traditional=int(own_t.size),
                         n_vertices=int(vl.size), x=np.ascontiguousarray(x, np.float32), v=np.ascontiguousarray(v, np.float32),
                         vol=np.ascontiguousarray(vol, np.float32), faces=f_loc, d=sc.d[el], R_inv=sc.R_inv[el],
-                        num_joint_v=njv, num_joint_f=njf, joint_verts_v=jv, joint_faces_v=jf, selection=sel,
+                        num_joint_v=njv, num_joint_f=njf, joint_verts_v=jv, joint_faces_v=jf, selection=sel, joint_t_hold=0,
                         has_mover=(sc.num_joint_v > 0 or sc.num_joint_f > 0) if sc.has_mover is None else sc.has_mover)
-        shards.append(Shard(r, world, local, own_e, ghost_e, own_t, own_v, ghost_v))
+        shards.append(Shard(r, world, local, own_e, ghost_e, own_t, own_v, ghost_v, cuts=cuts))
     # ghost exchange lists, ordered by global id on both sides
     for r, sh in enumerate(shards):
         off_v = sh.scene.n_elements + sh.scene.n_traditional
@@ -140,24 +145,28 @@ class ShardedSim:
     peers: list = field(default_factory=list)
     keep: list = field(default_factory=list)
     static: dict = field(default_factory=dict)
+    global_scene: Scene = None         # the unsharded scene this shard was cut from (positions as of the last partition)
+    migrate_fraction: float = 0.10     # re-partition when more than this fraction of the particles left their slab (0: never)
+    migrations: int = 0
 
 
-def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int = 0) -> ShardedSim:
+def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int = 0, _carry: dict = None) -> ShardedSim:
+    """Collective.  ``_carry`` (re-partition only): per-particle state in GLOBAL order to continue from, see repartition()."""
+    import os
     import torch
     import torch.distributed as dist
     from . import harness
-    from . import _lib as L
-    if getattr(sc, "joint_t_hold", 0) > 0:
-        raise NotImplementedError("staged joint_traditional_v (held trailing particles) is not supported by the sharded driver")
     shard = partition(sc, world)[rank]
     sim = harness.build_solver(shard.scene, device, mode="fast")
     sv = sim.solver
+    if _carry is not None:
+        _apply_carry(sim, shard, sc, _carry)
     sv._bind(sim.model, sim.state)
     sv._call("mpmhip_dist_enable")
-    import os
     ghost_g2p = os.environ.get("MPMHIP_DIST_GHOST_G2P", "1") != "0"
     sv._call("mpmhip_dist_set_ghost_mode", 1 if ghost_g2p else 0)
     ss = ShardedSim(shard, sim, dist.get_backend(), int(rebin_interval), ghost_g2p=ghost_g2p)
+    ss.global_scene = sc
     dev = torch.device(device)
     i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.int32), device=dev)
     for q in sorted(set(shard.send_p) | set(shard.recv_p)):
@@ -169,7 +178,6 @@ def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int 
         ss.static[q]["gr"] = torch.zeros(max(n_r, 1), dtype=torch.float32, device=dev)
     nb = sv._lib.mpmhip_dist_num_blocks(sv._ctx)
     ss.static["map"] = torch.zeros(nb, dtype=torch.uint8, device=dev)
-    import os
     want = os.environ.get("MPMHIP_DIST_TRANSPORT", "rccl" if ss.backend == "nccl" else "torch")
     if want == "rccl":
         # every rank must end up on the same transport: agree on success before switching
@@ -184,6 +192,142 @@ def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int 
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ss.transport = "rccl" if int(flag.item()) == 1 else "torch"
     return ss
+
+
+# --------------------------------------------------------------------------------------------- migration
+_CARRY_FIELDS = ("particle_x", "particle_v", "particle_C", "particle_d", "particle_F", "particle_F_trial", "particle_stress")
+_CARRY_MODEL = ("mu", "lam", "yield_stress")
+
+
+def local_to_global_rows(shard: Shard, sc: Scene):
+    """Global particle index of every OWNED local particle, and the local rows they sit in: (rows_local, ids_global) for the
+    all-particle arrays (x, v, C, model arrays) and for the element+traditional ones (F, F_trial, stress)."""
+    ne_g, nt_g = sc.n_elements, sc.n_traditional
+    ne_l = shard.own_e.size + shard.ghost_e.size
+    nt_l = shard.own_t.size
+    rows_e = np.arange(shard.own_e.size)
+    rows_t = ne_l + np.arange(nt_l)
+    rows_v = ne_l + nt_l + np.arange(shard.own_v.size)
+    all_rows = np.concatenate([rows_e, rows_t, rows_v])
+    all_ids = np.concatenate([shard.own_e, ne_g + shard.own_t, ne_g + nt_g + shard.own_v])
+    nv_rows = np.concatenate([rows_e, rows_t])
+    nv_ids = np.concatenate([shard.own_e, ne_g + shard.own_t])
+    return all_rows, all_ids, nv_rows, nv_ids
+
+
+def owned_slices(local: dict, shard: Shard, sc: Scene) -> dict:
+    """The rows of a rank's local arrays (local particle order) that belong to particles it OWNS, with their global ids."""
+    all_rows, all_ids, nv_rows, nv_ids = local_to_global_rows(shard, sc)
+    n_loc = shard.scene.n_particles
+    out = {"all_ids": all_ids, "nv_ids": nv_ids, "e_ids": shard.own_e}
+    for f, a in local.items():
+        if f == "particle_d":
+            out[f] = a[:shard.own_e.size]
+        elif f in _CARRY_MODEL or f in ("particle_x", "particle_v", "particle_C"):
+            assert a.shape[0] == n_loc, (f, a.shape, n_loc)
+            out[f] = a[all_rows]
+        else:
+            out[f] = a[nv_rows]
+    return out
+
+
+def assemble_global(parts, sc: Scene) -> dict:
+    """Per-rank owned slices -> arrays in the global (unsharded) particle order."""
+    n_p, n_nv, n_e = sc.n_particles, sc.n_elements + sc.n_traditional, sc.n_elements
+    out = {}
+    for f in _CARRY_FIELDS + _CARRY_MODEL:
+        if f not in parts[0]:
+            continue
+        whole = f in _CARRY_MODEL or f in ("particle_x", "particle_v", "particle_C")
+        n = n_p if whole else (n_e if f == "particle_d" else n_nv)
+        g = np.zeros((n,) + parts[0][f].shape[1:], np.float32)
+        filled = np.zeros(n, bool)
+        for p in parts:
+            ids = p["all_ids"] if whole else (p["e_ids"] if f == "particle_d" else p["nv_ids"])
+            g[ids] = p[f]
+            filled[ids] = True
+        assert filled.all(), f"{f}: {int((~filled).sum())} particles have no owner"
+        out[f] = g
+    return out
+
+
+def gather_global_state(ss: "ShardedSim") -> dict:
+    """Collective: the current state of every particle, assembled from its owner, in the global (unsharded) order."""
+    import torch.distributed as dist
+    st, md, sh, sc = ss.sim.state, ss.sim.model, ss.shard, ss.global_scene
+    local = {f: getattr(st, f).detach().cpu().numpy() for f in _CARRY_FIELDS}
+    local.update({f: getattr(md, f).detach().cpu().numpy() for f in _CARRY_MODEL})
+    parts = [None] * sh.world
+    dist.all_gather_object(parts, owned_slices(local, sh, sc))
+    return assemble_global(parts, sc)
+
+
+def _apply_carry(sim, shard: Shard, sc: Scene, carry: dict):
+    """Write the carried state of this rank's (owned and ghost) particles into the freshly built local solver."""
+    import torch
+    st, md = sim.state, sim.model
+    ne_g, nt_g = sc.n_elements, sc.n_traditional
+    el = np.concatenate([shard.own_e, shard.ghost_e])
+    vl = np.concatenate([shard.own_v, shard.ghost_v])
+    all_ids = np.concatenate([el, ne_g + shard.own_t, ne_g + nt_g + vl])
+    nv_ids = np.concatenate([el, ne_g + shard.own_t])
+    dev = st.particle_x.device
+    put = lambda dst, a: dst.copy_(torch.as_tensor(np.ascontiguousarray(a, np.float32), device=dev).reshape(dst.shape)) if dst.numel() else None
+    for f in ("particle_C",):
+        put(getattr(st, f), carry[f][all_ids])
+    for f in ("particle_F", "particle_F_trial", "particle_stress"):
+        put(getattr(st, f), carry[f][nv_ids])
+    for f in _CARRY_MODEL:
+        put(getattr(md, f), carry[f][all_ids])
+    sim.solver.time = carry["time"]
+
+
+def slab_leavers(ss: "ShardedSim") -> float:
+    """Collective: fraction of all vertices / traditional particles that sit outside the x-slab of the rank that owns them."""
+    import torch
+    import torch.distributed as dist
+    sh, sc = ss.shard, ss.global_scene
+    x = ss.sim.state.particle_x.detach()[:, 0].cpu().numpy()
+    ne_l = sh.own_e.size + sh.ghost_e.size
+    xs = np.concatenate([x[ne_l:ne_l + sh.own_t.size], x[ne_l + sh.own_t.size:ne_l + sh.own_t.size + sh.own_v.size]])
+    lo = -np.inf if sh.rank == 0 else sh.cuts[sh.rank - 1]
+    hi = np.inf if sh.rank == sh.world - 1 else sh.cuts[sh.rank]
+    t = torch.tensor([float(((xs < lo) | (xs >= hi)).sum()), float(xs.size)], dtype=torch.float64)
+    if sh.world > 1:
+        dist.all_reduce(t)
+    return float(t[0] / max(t[1], 1.0))
+
+
+def repartition(ss: "ShardedSim") -> "ShardedSim":
+    """Collective: new slabs at the particles' CURRENT positions; every rank rebuilds its shard and continues the same run
+    (state, solver time and substep count carried over).  Returns the new ShardedSim (the old one is released)."""
+    sc = ss.global_scene
+    if any(kind == "velocity_cuboid" for kind, _ in sc.bcs):
+        raise NotImplementedError("re-partition with a moving velocity cuboid (its host-side position is not carried over)")
+    carry = gather_global_state(ss)
+    carry["time"] = ss.sim.solver.time
+    new_sc = replace(sc, x=carry["particle_x"], v=carry["particle_v"], d=carry["particle_d"])
+    dev = str(ss.sim.solver.device)
+    keep = dict(steps_done=ss.steps_done, resorts=ss.resorts, rebin_interval=ss.rebin_interval,
+                migrate_fraction=ss.migrate_fraction, migrations=ss.migrations + 1)
+    rank, world = ss.shard.rank, ss.shard.world
+    del ss
+    new = build_sharded(new_sc, dev, rank, world, rebin_interval=keep["rebin_interval"], _carry=carry)
+    new.steps_done, new.resorts = keep["steps_done"], keep["resorts"]
+    new.migrate_fraction, new.migrations = keep["migrate_fraction"], keep["migrations"]
+    new.sim.steps_done = keep["steps_done"]
+    return new
+
+
+def maybe_repartition(ss: "ShardedSim") -> "ShardedSim":
+    import os
+    if ss.migrate_fraction <= 0 or ss.shard.world == 1 or ss.steps_done == 0:
+        return ss
+    frac = slab_leavers(ss)
+    if os.environ.get("MPMHIP_VERBOSE"):
+        print(f"[mpmavatar_amd.dist] rank {ss.shard.rank}: substep {ss.steps_done}: {100 * frac:.1f} % of the particles are outside "
+              f"their owner's slab" + (" -> re-partition" if frac > ss.migrate_fraction else ""), flush=True)
+    return repartition(ss) if frac > ss.migrate_fraction else ss
 
 
 def _init_rccl(ss: ShardedSim, rank: int, world: int):
@@ -311,8 +455,20 @@ def _any_rank_drifting(ss: ShardedSim) -> bool:
     return bool(int(t.item()))
 
 
+def _held_local(ss: ShardedSim, step: int) -> int:
+    """This rank's share of the traditional particles the mover still holds at substep `step` (run_demo.py:524: the last
+    joint_t_count(step) traditional particles in the global order; owned ids are ascending, so the share is a suffix)."""
+    sc, sh = ss.global_scene, ss.shard
+    if sc.joint_t_hold <= 0:
+        return -1
+    return int((sh.own_t >= sc.n_traditional - sc.joint_t_count(step)).sum())
+
+
 def run(ss: ShardedSim, n_steps: int):
-    """Advance n substeps on every rank (collective)."""
+    """Advance n substeps on every rank (collective).  NOTE: call as ``ss = run(ss, n)`` when migration is enabled -- a
+    re-partition replaces the ShardedSim (the argument stays valid otherwise and is returned)."""
+    import torch
+    ss = maybe_repartition(ss)
     sim, sv, sc = ss.sim, ss.sim.solver, ss.sim.scene
     dp = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
     jv, jf = sim.joint_verts_v, sim.joint_faces_v
@@ -320,17 +476,30 @@ def run(ss: ShardedSim, n_steps: int):
     if sv._host_dt != sc.dt:  # MPMWARP.time advances by the Python float (mpm_solver.py:536)
         sv._call("mpmhip_set_host_dt", float(sc.dt))
         sv._host_dt = sc.dt
+    held = lambda step: _held_local(ss, step)
+    jt_buf = None
+    if ss.global_scene.joint_t_hold > 0:
+        jt_buf = torch.zeros((max(ss.shard.own_t.size, 1), 3), dtype=torch.float32, device=sv.device)
+        ss.keep_jt = jt_buf
     if ss.transport == "rccl":
         jvp = None if jv is None else (dp(jv) or dummy)
         jfp = None if jf is None else (dp(jf) or dummy)
-        sv._call("mpmhip_rccl_steps", float(sc.dt), int(n_steps), int(ss.steps_done), int(ss.rebin_interval),
-                 dp(sim.mesh_x0), dp(sim.mesh_v), jvp, jfp)
-        ss.steps_done += n_steps
-        return
+        k = 0
+        while k < n_steps:  # runs of substeps over which the number of held particles does not change
+            n = n_steps - k
+            h = held(ss.steps_done)
+            if h >= 0:
+                n = next((j for j in range(1, n) if held(ss.steps_done + j) != h), n)
+            sv._call("mpmhip_rccl_steps", float(sc.dt), int(n), int(ss.steps_done), int(ss.rebin_interval),
+                     dp(sim.mesh_x0), dp(sim.mesh_v), jt_buf.data_ptr() if h > 0 else None, max(h, 0), jvp, jfp)
+            ss.steps_done += n
+            k += n
+        return ss
     adaptive = ss.rebin_interval <= 0   # re-sort when any rank's drift flag asks for it (polled every 16 substeps)
     cap = -ss.rebin_interval if ss.rebin_interval < 0 else (256 if ss.rebin_interval == 0 else ss.rebin_interval)
     for _ in range(n_steps):
-        due = (ss.resort_now or ss.since >= cap or not ss.sorted_once) if adaptive else ss.steps_done % cap == 0
+        due = (ss.resort_now or ss.since >= cap) if adaptive else ss.steps_done % cap == 0
+        due = due or not ss.sorted_once   # a fresh shard (initial build or re-partition) has no particle order yet
         if due:
             if ss.ghost_g2p and ss.steps_done > 0 and ss.peers:  # owners -> copies before the re-sort
                 sv._call("mpmhip_dist_ghost_pack")
@@ -342,7 +511,9 @@ def run(ss: ShardedSim, n_steps: int):
         adv = float(np.float32(sc.dt * ss.steps_done))
         jvp = None if jv is None else (dp(jv) or dummy)
         jfp = None if jf is None else (dp(jf) or dummy)
-        sv._call("mpmhip_dist_step_begin", float(sc.dt), dp(sim.mesh_x0), dp(sim.mesh_v), adv, None, 0, jvp, jfp)
+        h = held(ss.steps_done)
+        sv._call("mpmhip_dist_step_begin", float(sc.dt), dp(sim.mesh_x0), dp(sim.mesh_v), adv,
+                 jt_buf.data_ptr() if h > 0 else None, max(h, 0), jvp, jfp)
         _exchange(ss, "halo")
         sv._call("mpmhip_dist_step_mid")
         if not ss.ghost_g2p:
@@ -352,6 +523,7 @@ def run(ss: ShardedSim, n_steps: int):
         ss.since += 1
         if adaptive and ss.since % 16 == 0:
             ss.resort_now = _any_rank_drifting(ss)
+    return ss
 
 
 def gather_positions(ss: ShardedSim):

@@ -29,7 +29,15 @@ def _fast_cube():
     return sc
 
 
-SCENES = {"garment": scenes.small_garment, "sheet": scenes.small_sheet, "cube": scenes.small_cube, "fastcube": _fast_cube,
+def _crossing_cube():
+    """A cube thrown along x: within 150 substeps a third of it has crossed the cut between the two slabs."""
+    sc = scenes.small_cube()
+    sc.v = (sc.v + np.array([[8.0, 0.0, 0.0]], np.float32)).astype(np.float32)
+    return sc
+
+
+SCENES = {"crossing": _crossing_cube, "demohold": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=(10, 5, 64)),
+          "garment": scenes.small_garment, "sheet": scenes.small_sheet, "cube": scenes.small_cube, "fastcube": _fast_cube,
           "demo": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=False)}
 
 
@@ -80,9 +88,14 @@ def main():
         dev = f"cuda:{rank}" if torch.cuda.device_count() >= world else "cuda:0"
         torch.cuda.set_device(dev)
         ss = mdist.build_sharded(sc, dev, rank, world, rebin_interval=int(os.environ.get("MPMHIP_TEST_REBIN", "8")))
-        mdist.run(ss, steps)
+        ss.migrate_fraction = float(os.environ.get("MPMHIP_TEST_MIGRATE", "0"))
+        chunk = int(os.environ.get("MPMHIP_TEST_RUN_CHUNK", str(steps)))
+        for k0 in range(0, steps, chunk):  # migration is checked at the start of every run() call
+            ss = mdist.run(ss, min(chunk, steps - k0))
         if os.environ.get("MPMHIP_DIST_TRANSPORT") == "rccl" and world > 1 and torch.cuda.device_count() >= world:
             ok &= ss.transport == "rccl"   # the test asked for the in-library loop: falling back silently is a failure
+        if float(os.environ.get("MPMHIP_TEST_MIGRATE", "0")) > 0:
+            print(f"dist[{scene_name}] rank {rank}: {ss.migrations} re-partitions", flush=True)
         if ss.transport == "torch":
             print(f"dist[{scene_name}] rank {rank}: {ss.resorts} collective re-sorts in {steps} substeps", flush=True)
             st = ss.sim.solver.stats()

@@ -113,3 +113,24 @@ def test_in_library_rccl_transport_two_ranks(scene, steps):
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "max rel dx" in r.stdout
+
+
+@pytest.mark.gpu
+def test_sharded_staged_sand_release():
+    """run_demo.py:524 in the sharded driver: each rank holds its share (a suffix of its owned traditional particles) of the
+    sand the mover still pins, and lets go of it on the global schedule.  Must match the single context, which is checked
+    against the oracle in test_gpu_parity.py::test_staged_sand_release."""
+    out = _launch(2, "gpu", "demohold", 60)
+    assert "max rel dx" in out
+
+
+@pytest.mark.gpu
+def test_sharded_particle_migration():
+    """A cube thrown along x: more than 10 % of the particles leave the slab of the rank that owns them, the ranks gather
+    their state, cut new slabs at the current positions and rebuild their shards (mpmavatar_amd.dist.repartition) -- and the
+    run continues on the same trajectory as a single context."""
+    import re
+    out = _launch(2, "gpu", "crossing", 150, extra_env={"MPMHIP_TEST_MIGRATE": "0.1", "MPMHIP_TEST_RUN_CHUNK": "30"})
+    assert "max rel dx" in out
+    n = [int(x) for x in re.findall(r"rank \d+: (\d+) re-partitions", out)]
+    assert len(n) == 2 and n[0] == n[1] >= 1, out[-2000:]
