@@ -156,6 +156,8 @@ def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int 
     import torch
     import torch.distributed as dist
     from . import harness
+    if getattr(sc, "mesh_sway", None) is not None:
+        raise NotImplementedError("a body posed per frame (Scene.mesh_sway) is not supported by the sharded driver")
     shard = partition(sc, world)[rank]
     sim = harness.build_solver(shard.scene, device, mode="fast")
     sv = sim.solver

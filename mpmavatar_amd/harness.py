@@ -77,15 +77,23 @@ def run(sim: Sim, n_steps: int, fused: bool = False):
     sc, sv = sim.scene, sim.solver
     dev = sv.device  # (not via sim.state.particle_x: reading a state field pulls it back and forces a re-import)
 
+    t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a, np.float32), device=dev).reshape(-1, 3)
+
     def kwargs(step):
         n_jt = sc.joint_t_count(step)
         jt = torch.zeros((n_jt, 3), dtype=torch.float32, device=dev) if sc.joint_t_hold > 0 else None
+        if sc.mesh_sway is not None and sc.joint_verts_v is not None:   # joints ride on the swaying body
+            jv, jf = sc.joints_at(step)
+            return dict(joint_traditional_v=jt, joint_verts_v=t(jv), joint_faces_v=t(jf))
         return dict(joint_traditional_v=jt, joint_verts_v=sim.joint_verts_v, joint_faces_v=sim.joint_faces_v)
 
     def mesh(step):
         if sim.mesh_x0 is None:
-            return None
-        return sim.mesh_x0 + np.float32(sc.dt * step) * sim.mesh_v
+            return None, None
+        if sc.mesh_sway is not None:
+            mx, mv = sc.body_at(step)
+            return t(mx), t(mv)
+        return sim.mesh_x0 + np.float32(sc.dt * step) * sim.mesh_v, sim.mesh_v
 
     end = sim.steps_done + n_steps
     while sim.steps_done < end:
@@ -96,9 +104,14 @@ def run(sim: Sim, n_steps: int, fused: bool = False):
             if sc.joint_t_hold > 0:  # stop the fused run at the next change of the held count
                 c0 = sc.joint_t_count(k0)
                 n = next((j for j in range(1, n) if sc.joint_t_count(k0 + j) != c0), n)
-            sv.p2g2p_n(sim.model, sim.state, sc.dt, n, mesh_x=mesh(k0), mesh_v=sim.mesh_v, **kwargs(k0))
+            f0, spf = sc.frame_of(k0)
+            if spf is not None:      # ... and at the next pose of a swaying body (the fused call advects x + k dt v)
+                n = min(n, f0 + spf - k0)
+            mx, mv = mesh(k0)
+            sv.p2g2p_n(sim.model, sim.state, sc.dt, n, mesh_x=mx, mesh_v=mv, **kwargs(k0))
         else:
-            sv.p2g2p(sim.model, sim.state, sc.dt, mesh_x=mesh(k0), mesh_v=sim.mesh_v, **kwargs(k0))
+            mx, mv = mesh(k0)
+            sv.p2g2p(sim.model, sim.state, sc.dt, mesh_x=mx, mesh_v=mv, **kwargs(k0))
         sim.steps_done += n
 
 

@@ -55,6 +55,10 @@ class Scene:
     joint_t_start: int = 0
     joint_t_every: int = 1
     joint_t_rate: int = 0
+    # swaying body (velocity amplitude * sin(2 pi f t) along x): (amplitude m/s, frequency Hz, substeps per frame).
+    # Like the reference drivers (train_material_params.py:616-626) the body is posed once per FRAME and moves with the constant
+    # finite-difference velocity to the next pose inside it; joints attached to the body get the same velocity.
+    mesh_sway: Optional[tuple] = None
 
     def joint_t_count(self, step: int) -> int:
         """Length of joint_traditional_v at this substep (max(n_t - max(i - 100, 0) * 1000, 0) per frame in the reference)."""
@@ -66,6 +70,40 @@ class Scene:
     @property
     def n_particles(self):
         return self.n_elements + self.n_traditional + self.n_vertices
+
+    def frame_of(self, step: int):
+        """(first substep of the frame that contains `step`, substeps per frame); (0, None) for a body in uniform motion."""
+        if self.mesh_sway is None:
+            return 0, None
+        spf = int(self.mesh_sway[2])
+        return (step // spf) * spf, spf
+
+    def _sway_offset(self, t: float) -> float:
+        amp, freq = float(self.mesh_sway[0]), float(self.mesh_sway[1])
+        return amp / (2.0 * np.pi * freq) * (1.0 - np.cos(2.0 * np.pi * freq * t))   # integral of amp sin(2 pi f t)
+
+    def body_at(self, step: int):
+        """(mesh_x, mesh_v) a caller hands to p2g2p at substep `step`, or (None, None) without a body mesh."""
+        if self.mesh_vertices is None:
+            return None, None
+        if self.mesh_sway is None:
+            return (self.mesh_vertices + np.float32(self.dt * step) * self.mesh_v).astype(np.float32), self.mesh_v
+        f0, spf = self.frame_of(step)
+        x0, x1 = self._sway_offset(f0 * self.dt), self._sway_offset((f0 + spf) * self.dt)
+        v = np.zeros_like(self.mesh_vertices)
+        v[:, 0] = np.float32((x1 - x0) / (spf * self.dt))
+        base = self.mesh_vertices.copy()
+        base[:, 0] += np.float32(x0)
+        return (base + np.float32(self.dt * (step - f0)) * v).astype(np.float32), v
+
+    def joints_at(self, step: int):
+        """(joint_verts_v, joint_faces_v) at substep `step`: the scene's constant arrays, or the swaying body's velocity."""
+        if self.joint_verts_v is None or self.mesh_sway is None:
+            return self.joint_verts_v, self.joint_faces_v
+        _, v = self.body_at(step)
+        vx = v[0]
+        return (np.tile(vx[None], (self.joint_verts_v.shape[0], 1)).astype(np.float32),
+                np.tile(vx[None], (np.asarray(self.joint_faces_v).reshape(-1, 3).shape[0], 1)).astype(np.float32))
 
 
 def _cloth_scene(name, verts, faces, n_grid, **kw) -> Scene:
@@ -124,13 +162,14 @@ def block(n=80, n_grid=256, spacing=None, n_steps=200, seed=2, material="jelly")
 
 
 def garment_cylinder(n_theta=200, n_h=200, n_grid=128, aniso=True, collider_subdiv=5, n_steps=1000,
-                     joint_rows=2, name=None) -> Scene:
+                     joint_rows=2, name=None, sway=None) -> Scene:
     """S2/S3 stand-ins for the Actor01 garment (BASELINE configs 2 and 3).
 
     aniso=False: every mesh point is a traditional fixed-corotated ('jelly') particle (S2).
     aniso=True : elements + vertices with the anisotropic cloth model, a capsule body collider
                  (friction 0.5) moving sideways, and the top ``joint_rows`` rows attached to the body
-                 through the particle mover (S3).
+                 through the particle mover (S3).  sway = (amplitude, frequency, substeps per frame): the body
+                 velocity is amplitude * sin(2 pi f t) along x (per-frame poses); None: uniform 0.3 m/s.
     """
     verts, faces = garment.cylinder(n_theta, n_h, 0.25, 0.8, (1.0, 1.0, 1.0))
     if not aniso:
@@ -150,7 +189,7 @@ def garment_cylinder(n_theta=200, n_h=200, n_grid=128, aniso=True, collider_subd
     return _cloth_scene(name or f"garment-{faces.shape[0] + verts.shape[0]}-aniso", verts, faces, n_grid,
                         mesh_vertices=mv, mesh_faces=mf, mesh_v=mesh_v, mesh_friction=0.5, num_joint_v=njv,
                         num_joint_f=njf, joint_verts_v=jv, joint_faces_v=jf.astype(np.float32),
-                        bcs=[("bounding_box", {})], n_steps=n_steps)
+                        bcs=[("bounding_box", {})], n_steps=n_steps, mesh_sway=sway)
 
 
 def sheet(n=408, n_grid=256, collider_subdiv=5, n_steps=1000, seed=1, name=None, y=1.2, span=(0.2, 1.8),
@@ -217,7 +256,8 @@ def small_garment(n_theta=32, n_h=24, n_grid=48, n_steps=200):
 REGISTRY = {
     "cube-8k": lambda: cube(),
     "garment-120k-iso": lambda: garment_cylinder(aniso=False),
-    "garment-120k-aniso": lambda: garment_cylinder(aniso=True),
+    # S3: the body sways with 0.5 sin(2 pi t) m/s, posed every 400 substeps like the reference's frames
+    "garment-120k-aniso": lambda: garment_cylinder(aniso=True, sway=(0.5, 1.0, 400)),
     "sheet-500k": lambda: sheet(),
     "block-512k": lambda: block(),
     "demo-mix": lambda: demo_mix(),

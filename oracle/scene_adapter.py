@@ -47,10 +47,10 @@ def run_scene(sim, sc, n_steps=None, step_fn=None, k0=0):
     for k in range(n):
         kw = {}
         if sc.mesh_vertices is not None:
-            kw["mesh_x"] = (sc.mesh_vertices + np.float32(sc.dt * (k0 + k)) * sc.mesh_v).astype(np.float32)
-            kw["mesh_v"] = sc.mesh_v
+            kw["mesh_x"], kw["mesh_v"] = sc.body_at(k0 + k) if hasattr(sc, "body_at") else (
+                (sc.mesh_vertices + np.float32(sc.dt * (k0 + k)) * sc.mesh_v).astype(np.float32), sc.mesh_v)
         if sc.joint_verts_v is not None:
-            kw["joint_verts_v"], kw["joint_faces_v"] = sc.joint_verts_v, sc.joint_faces_v
+            kw["joint_verts_v"], kw["joint_faces_v"] = sc.joints_at(k0 + k) if hasattr(sc, "joints_at") else (sc.joint_verts_v, sc.joint_faces_v)
         if getattr(sc, "joint_t_hold", 0) > 0:  # staged sand release, run_demo.py:524
             kw["joint_traditional_v"] = np.zeros((sc.joint_t_count(k0 + k), 3), np.float32)
         fn(sc.dt, **kw)

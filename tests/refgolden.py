@@ -67,11 +67,12 @@ def step_inputs(sc, step):
     """p2g2p arguments at substep `step` (NumPy), as oracle.scene_adapter.run_scene builds them."""
     kw = {}
     if sc.mesh_vertices is not None:
-        kw["mesh_x"] = (sc.mesh_vertices + np.float32(sc.dt * step) * sc.mesh_v).astype(np.float32)
-        kw["mesh_v"] = np.ascontiguousarray(sc.mesh_v, np.float32)
+        mx, mv = sc.body_at(step)
+        kw["mesh_x"], kw["mesh_v"] = np.ascontiguousarray(mx, np.float32), np.ascontiguousarray(mv, np.float32)
     if sc.joint_verts_v is not None:
-        kw["joint_verts_v"] = np.ascontiguousarray(sc.joint_verts_v, np.float32)
-        kw["joint_faces_v"] = np.ascontiguousarray(sc.joint_faces_v, np.float32).reshape(-1, 3)
+        jv, jf = sc.joints_at(step)
+        kw["joint_verts_v"] = np.ascontiguousarray(jv, np.float32)
+        kw["joint_faces_v"] = np.ascontiguousarray(jf, np.float32).reshape(-1, 3)
     if sc.joint_t_hold > 0:
         kw["joint_traditional_v"] = np.zeros((sc.joint_t_count(step), 3), np.float32)
     return kw

@@ -202,3 +202,24 @@ def test_several_mesh_colliders_and_movers(mode, oracle_lib):
     harness.run(sim, 40, fused=(mode == "fast"))
     assert rel(sim.state.particle_x.cpu().numpy(), o.x) < 1e-5
     assert rel(sim.state.particle_v.cpu().numpy(), o.v) < 2e-3   # cloth at rest: R22 = 1 sensitivity, see module docstring
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_swaying_body_posed_per_frame(mode, oracle_lib):
+    """the body sways with 0.5 sin(2 pi t) m/s.  Like the reference drivers the scene poses it once per frame
+    and moves it with the finite-difference velocity inside the frame (train_material_params.py:616-626); the joints ride
+    on it.  Single-step and fused driving (split at the frame boundaries) against the oracle across three frames."""
+    from mpmavatar_amd import harness
+    from oracle.scene_adapter import oracle_from_scene, run_scene
+    mk = lambda: scenes.garment_cylinder(n_theta=32, n_h=24, n_grid=48, collider_subdiv=2, name="garment-sway", sway=(0.5, 2.0, 20))
+    sc = mk()
+    assert abs(sc.body_at(45)[1][0, 0] - sc.body_at(5)[1][0, 0]) > 1e-3          # the velocity really changes from frame to frame
+    o = oracle_from_scene(sc)
+    run_scene(o, sc, 65)
+    a = harness.build_solver(mk(), "cuda:0", mode=mode)
+    harness.run(a, 65, fused=False)
+    b = harness.build_solver(mk(), "cuda:0", mode=mode)
+    harness.run(b, 65, fused=True)
+    xa, xb = a.state.particle_x.cpu().numpy(), b.state.particle_x.cpu().numpy()
+    assert rel(xa, o.x) < 1e-5 and rel(xb, xa) < 1e-6
+    assert rel(a.state.particle_v.cpu().numpy(), o.v) < 5e-3   # cloth at rest on the R22 = 1 discontinuity, see module docstring
