@@ -290,12 +290,22 @@ __global__ void k_mark_blocks(const SortKey *keys, int n, int blk_bits, int *pb_
   if (!key_inactive(k, blk_bits)) pb_flag[key_block(k, blk_bits)] = 1;
 }
 
-__global__ void k_compact(const int *flag, const int *index, int n, int *list) {
+// rc: re-sort counts kept on the device so that the table kernels can be enqueued back to back without a host round trip
+// (the host reads them once, at the end): [0] particle blocks, [1] active blocks, [2] chunks, [3] chunks incl. ghost copies,
+// [4] any ghost copy, [5] capacity overflow bits (1 plist / ranges, 2 alist, 4 chunk records, 8 face bins), [6] face bins
+enum { RC_NP = 0, RC_NA = 1, RC_NCH = 2, RC_NCHG = 3, RC_GHOST = 4, RC_OVER = 5, RC_NFB = 6, RC_N = 8 };
+__global__ void k_flag_total(const int *flag, const int *index, int n, int *rc, int slot, int cap, int over_bit) {
+  int tot = index[n - 1] + flag[n - 1];
+  rc[slot] = tot;
+  if (tot > cap) atomicOr(rc + RC_OVER, over_bit);
+}
+__global__ void k_compact(const int *flag, const int *index, int n, int *list, int cap) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < n && flag[b]) list[index[b]] = b;
+  if (b < n && flag[b] && index[b] < cap) list[index[b]] = b;
 }
 
 // ranges[(cls*2+0)*n_P + slot] = first sorted index, [(cls*2+1)*n_P + slot] = one past the last
+// n_P here is the STRIDE of the table (its capacity), not the number of particle blocks
 __global__ void k_ranges(const SortKey *keys, Dims d, int blk_bits, const int *pb_index, int n_P, int *ranges) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= d.n_p) return;
@@ -304,16 +314,17 @@ __global__ void k_ranges(const SortKey *keys, Dims d, int blk_bits, const int *p
   int cls = s < d.n_e ? 0 : (s < d.n_nv ? 1 : 2);
   int c0 = cls == 0 ? 0 : (cls == 1 ? d.n_e : d.n_nv), c1 = cls == 0 ? d.n_e : (cls == 1 ? d.n_nv : d.n_p);
   int slot = pb_index[key_block(k, blk_bits)];
+  if (slot >= n_P) return;  // capacity overflow: flagged by k_flag_total, the host grows the tables and repeats
   int row = key_state(k, blk_bits) == 0 ? cls * 2 : (cls == 0 ? 6 : 8);  // ghosts: elements, vertices only
   int cb = kf_cell(blk_bits);
   if (s == c0 || (keys[s - 1] >> cb) != (k >> cb)) ranges[(row + 0) * n_P + slot] = s;
   if (s == c1 - 1 || (keys[s + 1] >> cb) != (k >> cb)) ranges[(row + 1) * n_P + slot] = s + 1;
 }
 
-__global__ void k_dilate(const int *plist, int n_P, int NB, int *ab_flag) {
+__global__ void k_dilate(const int *plist, const int *rc, int cap_P, int NB, int *ab_flag) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int p = t / 27, nb = t % 27;
-  if (p >= n_P) return;
+  if (p >= min(rc[RC_NP], cap_P)) return;
   int b = plist[p];
   int bz = b % NB, by = (b / NB) % NB, bx = b / (NB * NB);
   int x = bx + nb / 9 - 1, y = by + (nb / 3) % 3 - 1, z = bz + nb % 3 - 1;
@@ -563,6 +574,49 @@ struct ChunkRec {
   }
 };
 
+// Chunk records of all particle blocks, built on the device (one workgroup: a few thousand blocks at most): block p
+// contributes ceil(particles / CHUNK) records to the p2g list and ceil((particles + ghost copies) / CHUNK) to the g2p list,
+// in block order (neighbouring records = neighbouring tiles, what the XCD mapping wants).
+__global__ __launch_bounds__(1024) void k_build_chunks(const int *plist, const int *ranges, int stride, int *rc, ChunkRec *recs,
+                                                       ChunkRec *recs_g, int cap) {
+  __shared__ int sc[1024], sg[1024];
+  __shared__ int any_ghost;
+  const int t = threadIdx.x, n_P = min(rc[RC_NP], stride);
+  const int per = (n_P + 1023) / 1024, p0 = min(t * per, n_P), p1 = min(p0 + per, n_P);
+  auto R = [&](int k, int p) { return ranges[(size_t)k * stride + p]; };
+  int c = 0, cg = 0, gh = 0;
+  for (int p = p0; p < p1; ++p) {
+    int tot = (R(1, p) - R(0, p)) + (R(3, p) - R(2, p)) + (R(5, p) - R(4, p));
+    int g = (R(7, p) - R(6, p)) + (R(9, p) - R(8, p));
+    c += (tot + CHUNK - 1) / CHUNK;
+    cg += (tot + g + CHUNK - 1) / CHUNK;
+    gh |= g > 0;
+  }
+  if (t == 0) any_ghost = 0;
+  sc[t] = c; sg[t] = cg;
+  __syncthreads();
+  if (gh) any_ghost = 1;
+  for (int o = 1; o < 1024; o <<= 1) {  // inclusive scan
+    int a = t >= o ? sc[t - o] : 0, b = t >= o ? sg[t - o] : 0;
+    __syncthreads();
+    sc[t] += a; sg[t] += b;
+    __syncthreads();
+  }
+  int o = sc[t] - c, og = sg[t] - cg;
+  for (int p = p0; p < p1; ++p) {
+    ChunkRec r{plist[p], 0, R(0, p), R(1, p) - R(0, p), R(2, p), R(3, p) - R(2, p), R(4, p), R(5, p) - R(4, p), 0, 0, 0, 0};
+    int tot = r.ne + r.nt + r.nv;
+    for (int k = 0; k * CHUNK < tot; ++k, ++o) { r.chunk = k; if (o < cap) recs[o] = r; }
+    r.ge0 = R(6, p); r.gne = R(7, p) - R(6, p); r.gv0 = R(8, p); r.gnv = R(9, p) - R(8, p);
+    tot += r.gne + r.gnv;
+    for (int k = 0; k * CHUNK < tot; ++k, ++og) { r.chunk = k; if (og < cap) recs_g[og] = r; }
+  }
+  if (t == 1023) {
+    rc[RC_NCH] = sc[t]; rc[RC_NCHG] = sg[t]; rc[RC_GHOST] = any_ghost;
+    if (sc[t] > cap || sg[t] > cap) atomicOr(rc + RC_OVER, 4);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // body-face splat (compute_mesh, mpm_solver.py:829-880) and joint splat (:677-788) into active blocks
 // ------------------------------------------------------------------------------------------------
@@ -611,12 +665,19 @@ __global__ void k_face_bins(const unsigned *skeys, int n_f, int *fb_start, int *
 
 // non-empty face bins that lie on the active list (order irrelevant), as self-contained records
 struct FaceBin { int blk, start, cnt, pad; };
-__global__ void k_fbin_compact(const int *alist, int n_A, const int *fb_start, const int *fb_cnt, FaceBin *list, int *counter) {
+__global__ void k_fbin_compact(const int *alist, const int *rc, int cap_A, const int *fb_start, const int *fb_cnt, FaceBin *list,
+                               int cap_fbins) {
+  const int n_A = min(rc[RC_NA], cap_A);
+  int *counter = const_cast<int *>(rc) + RC_NFB;
   int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n_A) return;
   int blk = alist[a];
   int cnt = fb_cnt[blk];
-  if (cnt > 0) list[atomicAdd(counter, 1)] = FaceBin{blk, fb_start[blk], cnt, 0};
+  if (cnt > 0) {
+    int i = atomicAdd(counter, 1);
+    if (i < cap_fbins) list[i] = FaceBin{blk, fb_start[blk], cnt, 0};
+    else atomicOr(const_cast<int *>(rc) + RC_OVER, 8);
+  }
 }
 // vertex ids of the faces in bin order (one indirection less per substep)
 __global__ void k_face_sorted_idx(const int32_t *idx, const int *order, int n_f, int *fidx) {
@@ -1782,7 +1843,9 @@ struct FastState {
   ChunkRec *chunks = nullptr, *chunks_g = nullptr;  // p2g list, g2p list (= p2g list unless there are ghost copies)
   int n_chunks_g = 0;
   bool ghost_g2p = false;  // multi-GPU: ghost copies (selection == 2) gather for themselves
-  int cap_P = 0, cap_A = 0, cap_chunks = 0, cap_R = 0;
+  int cap_P = 0, cap_A = 0, cap_chunks = 0, cap_R = 0;  // cap_P: capacity the block tables are built with (grows on demand)
+  int alloc_P = 0;     // allocated entries of plist
+  int *rcnt = nullptr; // device: counts of the last re-sort (RC_*)
   int64_t stat_steps = 0;
   int n_P = 0, n_A = 0, n_chunks = 0;
   int *h_pin = nullptr;  // pinned host scratch
@@ -1887,6 +1950,18 @@ int scan_flags(mpmhip_ctx *c, const int *flag, int *index, int n, int *total) {
 }
 
 // the same scan without the wait: the two addends of the total land in h_pin[slot], h_pin[slot + 1] once the stream gets there
+int scan_flags_dev(mpmhip_ctx *c, const int *flag, int *index, int n) {  // exclusive scan, nothing read back
+  FastState *f = c->fast;
+  size_t need = 0;
+  MPM_HIP_CHECK(c, rocprim::exclusive_scan(nullptr, need, flag, index, 0, (size_t)n, rocprim::plus<int>(), c->stream));
+  if (need > f->scan_tmp_bytes) {
+    MPM_HIP_CHECK(c, hipMalloc(&f->scan_tmp, need));
+    f->allocs.push_back(f->scan_tmp);
+    f->scan_tmp_bytes = need;
+  }
+  MPM_HIP_CHECK(c, rocprim::exclusive_scan(f->scan_tmp, need, flag, index, 0, (size_t)n, rocprim::plus<int>(), c->stream));
+  return MPMHIP_OK;
+}
 int scan_flags_async(mpmhip_ctx *c, const int *flag, int *index, int n, int slot) {
   FastState *f = c->fast;
   size_t need = 0;
@@ -2004,71 +2079,10 @@ int rebin(mpmhip_ctx *c) {
     hipLaunchKernelGGL(k_adj_sorted, nblk(d.n_v), TPB, 0, s, f->adj_o, f->adj_s, f->perm[cur], f->inv, f->adj_K, d);
   const SortKey *skeys = f->keys[1];
   int nb = (int)f->nblocks;
-  MPM_HIP_CHECK(c, hipMemsetAsync(f->pb_flag, 0, f->nblocks * sizeof(int), s));
-  MPM_HIP_CHECK(c, hipMemsetAsync(f->ab_flag, 0, f->nblocks * sizeof(int), s));
-  hipLaunchKernelGGL(k_mark_blocks, nblk(d.n_p), TPB, 0, s, skeys, d.n_p, f->blk_bits, f->pb_flag);
-  int rc = scan_flags(c, f->pb_flag, f->pb_index, nb, &f->n_P);
-  if (rc) return rc;
-  if ((rc = ensure_cap(c, &f->plist, &f->cap_P, f->n_P, 1))) return rc;
-  if ((rc = ensure_cap(c, &f->ranges, &f->cap_R, f->n_P, 10))) return rc;
-  MPM_HIP_CHECK(c, hipMemsetAsync(f->ranges, 0, (size_t)f->n_P * 10 * sizeof(int), s));
-  hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, f->pb_flag, f->pb_index, nb, f->plist);
-  hipLaunchKernelGGL(k_ranges, nblk(d.n_p), TPB, 0, s, skeys, d, f->blk_bits, f->pb_index, f->n_P, f->ranges);
-  hipLaunchKernelGGL(k_dilate, nblk((size_t)f->n_P * 27), TPB, 0, s, f->plist, f->n_P, d.NB, f->ab_flag);
-  // active-block count, block ranges and block ids come back in ONE wait (the list is sized by its upper bound)
-  if ((rc = scan_flags_async(c, f->ab_flag, f->ab_index, nb, 2))) return rc;
-  if ((rc = ensure_cap(c, &f->alist, &f->cap_A, (int)std::min<long long>((long long)nb, 27LL * f->n_P), 1))) return rc;
-  hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, f->ab_flag, f->ab_index, nb, f->alist);
-  // chunk records on the host from the compact ranges
-  if (!f->h_ranges.resize((size_t)f->n_P * 10) || !f->h_plist.resize((size_t)f->n_P))
-    return fail(c, MPMHIP_ERR_HIP, "re-sort: pinned host staging");
-  MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_ranges.data(), f->ranges, (size_t)f->n_P * 10 * sizeof(int), hipMemcpyDeviceToHost, s));
-  MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_plist.data(), f->plist, (size_t)f->n_P * sizeof(int), hipMemcpyDeviceToHost, s));
-  MPM_HIP_CHECK(c, hipStreamSynchronize(s));
-  f->n_A = f->h_pin[2] + f->h_pin[3];
-  // two lists: p2g walks the simulated particles of a block, g2p those plus the ghost copies (identical without ghosts)
-  f->h_chunks.clear();
-  f->h_chunks_g.clear();
-  {  // every block contributes at most tot / CHUNK + 1 records
-    size_t bound = (size_t)f->n_P + (size_t)d.n_p / CHUNK + 8;
-    if (!f->h_chunks.reserve(bound) || !f->h_chunks_g.reserve(bound)) return fail(c, MPMHIP_ERR_HIP, "re-sort: pinned host staging");
-  }
-  bool any_ghost = false;
-  for (int p = 0; p < f->n_P; ++p) {
-    auto R = [&](int k) { return f->h_ranges[(size_t)k * f->n_P + p]; };
-    ChunkRec r{f->h_plist[p], 0, R(0), R(1) - R(0), R(2), R(3) - R(2), R(4), R(5) - R(4), 0, 0, 0, 0};
-    int tot = r.ne + r.nt + r.nv;  // the classes of a block are packed back to back
-    for (int k = 0; k * CHUNK < tot; ++k) { r.chunk = k; f->h_chunks.push_back(r); }
-    r.ge0 = R(6); r.gne = R(7) - R(6); r.gv0 = R(8); r.gnv = R(9) - R(8);
-    any_ghost = any_ghost || r.gne + r.gnv > 0;
-    tot += r.gne + r.gnv;
-    for (int k = 0; k * CHUNK < tot; ++k) { r.chunk = k; f->h_chunks_g.push_back(r); }
-  }
-  if (getenv("MPMHIP_VERBOSE")) {  // occupancy of the chunks (particles per chunk) after this re-sort
-    int hist[5] = {0, 0, 0, 0, 0};
-    for (auto &r : f->h_chunks) {
-      int tot = r.ne + r.nt + r.nv, n = std::min(CHUNK, tot - r.chunk * CHUNK);
-      hist[n <= 32 ? 0 : n <= 64 ? 1 : n <= 128 ? 2 : n < 256 ? 3 : 4]++;
-    }
-    fprintf(stderr, "[mpmhip] re-sort %ld: %d particle blocks, %d active blocks, %zu chunks (<=32: %d, <=64: %d, <=128: %d, <256: %d, full: %d), lead %.1f\n",
-            (long)f->rebins, f->n_P, f->n_A, f->h_chunks.size(), hist[0], hist[1], hist[2], hist[3], hist[4], f->lead_steps);
-  }
-  f->n_chunks = (int)f->h_chunks.size();
-  f->n_chunks_g = any_ghost ? (int)f->h_chunks_g.size() : f->n_chunks;
-  int need_recs = f->n_chunks + (any_ghost ? f->n_chunks_g : 0);
-  if (need_recs > f->cap_chunks) {
-    int cap = need_recs + need_recs / 4 + 64;
-    if ((rc = dalloc(c, &f->chunks, (size_t)cap, false))) return rc;
-    f->cap_chunks = cap;
-  }
-  f->chunks_g = any_ghost ? f->chunks + f->n_chunks : f->chunks;
-  if (f->n_chunks)
-    MPM_HIP_CHECK(c, hipMemcpyAsync(f->chunks, f->h_chunks.data(), f->h_chunks.size() * sizeof(ChunkRec), hipMemcpyHostToDevice, s));
-  if (any_ghost)
-    MPM_HIP_CHECK(c, hipMemcpyAsync(f->chunks + f->n_chunks, f->h_chunks_g.data(), f->h_chunks_g.size() * sizeof(ChunkRec),
-                                    hipMemcpyHostToDevice, s));
-  if (!c->colliders.empty() && c->num_mesh_f) {
-    int nf = c->num_mesh_f;
+  int rc;
+  const bool with_faces = !c->colliders.empty() && c->num_mesh_f;
+  const int nf = c->num_mesh_f;
+  if (with_faces) {  // body faces: sort by block, per-block ranges (independent of the particle tables)
     hipLaunchKernelGGL(k_face_keys, nblk(nf), TPB, 0, s, c->cur_pts, c->cur_vel, c->cur_f, c->mesh_idx, nf, d, f->fkeys[0], f->fiota);
     size_t need2 = 0;
     MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(nullptr, need2, f->fkeys[0], f->fkeys[1], f->fiota, f->forder, (size_t)nf, 0u,
@@ -2082,19 +2096,78 @@ int rebin(mpmhip_ctx *c) {
                                                0u, (unsigned)f->blk_bits_plain, s));
     MPM_HIP_CHECK(c, hipMemsetAsync(f->fb_cnt, 0, f->nblocks * sizeof(int), s));
     hipLaunchKernelGGL(k_face_bins, nblk(nf), TPB, 0, s, f->fkeys[1], nf, f->fb_start, f->fb_cnt);
-    if (std::min(nf, f->n_A) > f->cap_fbins) {
-      int cap = std::min(nf, f->n_A) * 2 + 64;
-      if ((rc = dalloc(c, &f->fbins, (size_t)cap, false))) return rc;
-      f->cap_fbins = cap;
-    }
     hipLaunchKernelGGL(k_face_sorted_idx, nblk(nf), TPB, 0, s, c->mesh_idx, f->forder, nf, f->fidx);
-    int *cnt = f->g.counters + 5;
-    MPM_HIP_CHECK(c, hipMemsetAsync(cnt, 0, sizeof(int), s));
-    if (f->n_A) hipLaunchKernelGGL(k_fbin_compact, nblk(f->n_A), TPB, 0, s, f->alist, f->n_A, f->fb_start, f->fb_cnt, f->fbins, cnt);
-    MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 20, cnt, sizeof(int), hipMemcpyDeviceToHost, s));
-    MPM_HIP_CHECK(c, hipStreamSynchronize(s));
-    f->n_fbins = f->h_pin[20];
-    f->faces_binned = true;
+  }
+  // Block tables, chunk records and face bins: every kernel takes its counts from the device array f->rcnt and its array
+  // sizes from CAPACITIES, so the whole sequence is enqueued without a host round trip; the host reads the counts once, at
+  // the end.  A capacity that turns out too small (first re-sort of a scene, or a scene that spreads out quickly) is
+  // grown and the tables are built again.
+  if (f->cap_P == 0) f->cap_P = (int)std::min<long long>((long long)nb, std::max<long long>(1024, (long long)d.n_p / 16));
+  for (int attempt = 0;; ++attempt) {
+    if (attempt > 8) return fail(c, MPMHIP_ERR_HIP, "re-sort: table capacities do not converge");
+    const int cap_P = f->cap_P;
+    const int cap_A = (int)std::min<long long>((long long)nb, 27LL * cap_P);
+    const int cap_ch = cap_P + d.n_p / CHUNK + 8;
+    const int cap_fb = with_faces ? std::min(nf, cap_A) : 0;
+    int dummy = 0;
+    if ((rc = ensure_cap(c, &f->plist, &f->alloc_P, cap_P, 1))) return rc;
+    if ((rc = ensure_cap(c, &f->ranges, &f->cap_R, cap_P, 10))) return rc;
+    if ((rc = ensure_cap(c, &f->alist, &f->cap_A, cap_A, 1))) return rc;
+    if (2 * cap_ch > f->cap_chunks) {
+      if ((rc = dalloc(c, &f->chunks, (size_t)2 * cap_ch, false))) return rc;
+      f->cap_chunks = 2 * cap_ch;
+    }
+    if (cap_fb > f->cap_fbins) {
+      if ((rc = dalloc(c, &f->fbins, (size_t)cap_fb + 64, false))) return rc;
+      f->cap_fbins = cap_fb + 64;
+    }
+    (void)dummy;
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->rcnt, 0, RC_N * sizeof(int), s));
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->pb_flag, 0, f->nblocks * sizeof(int), s));
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->ab_flag, 0, f->nblocks * sizeof(int), s));
+    hipLaunchKernelGGL(k_mark_blocks, nblk(d.n_p), TPB, 0, s, skeys, d.n_p, f->blk_bits, f->pb_flag);
+    if ((rc = scan_flags_dev(c, f->pb_flag, f->pb_index, nb))) return rc;
+    hipLaunchKernelGGL(k_flag_total, 1, 1, 0, s, f->pb_flag, f->pb_index, nb, f->rcnt, (int)RC_NP, cap_P, 1);
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->ranges, 0, (size_t)cap_P * 10 * sizeof(int), s));
+    hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, f->pb_flag, f->pb_index, nb, f->plist, cap_P);
+    hipLaunchKernelGGL(k_ranges, nblk(d.n_p), TPB, 0, s, skeys, d, f->blk_bits, f->pb_index, cap_P, f->ranges);
+    hipLaunchKernelGGL(k_dilate, nblk((size_t)cap_P * 27), TPB, 0, s, f->plist, f->rcnt, cap_P, d.NB, f->ab_flag);
+    if ((rc = scan_flags_dev(c, f->ab_flag, f->ab_index, nb))) return rc;
+    hipLaunchKernelGGL(k_flag_total, 1, 1, 0, s, f->ab_flag, f->ab_index, nb, f->rcnt, (int)RC_NA, cap_A, 2);
+    hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, f->ab_flag, f->ab_index, nb, f->alist, cap_A);
+    hipLaunchKernelGGL(k_build_chunks, 1, 1024, 0, s, f->plist, f->ranges, cap_P, f->rcnt, f->chunks, f->chunks + cap_ch, cap_ch);
+    if (with_faces)
+      hipLaunchKernelGGL(k_fbin_compact, nblk(cap_A), TPB, 0, s, f->alist, f->rcnt, cap_A, f->fb_start, f->fb_cnt, f->fbins, cap_fb);
+    MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 32, f->rcnt, RC_N * sizeof(int), hipMemcpyDeviceToHost, s));
+    MPM_HIP_CHECK(c, hipStreamSynchronize(s));  // the one wait of a re-sort
+    const int *h = f->h_pin + 32;
+    if (h[RC_OVER]) {  // grow what was too small and build the tables again (the sorted particles stay as they are)
+      f->cap_P = std::max(f->cap_P, std::min(nb, std::max(h[RC_NP], (h[RC_NCH] - d.n_p / CHUNK)) * 2 + 1024));
+      if (h[RC_OVER] & ~1) f->cap_P = std::min(nb, f->cap_P * 2);
+      continue;
+    }
+    f->n_P = h[RC_NP];
+    f->n_A = h[RC_NA];
+    f->n_chunks = h[RC_NCH];
+    const bool any_ghost = h[RC_GHOST] != 0;
+    f->n_chunks_g = any_ghost ? h[RC_NCHG] : f->n_chunks;
+    f->chunks_g = any_ghost ? f->chunks + cap_ch : f->chunks;
+    f->n_fbins = with_faces ? h[RC_NFB] : 0;
+    if (with_faces) f->faces_binned = true;
+    // next time: room for twice what this re-sort needed
+    f->cap_P = std::min(nb, std::max(1024, 2 * f->n_P));
+    break;
+  }
+  if (getenv("MPMHIP_VERBOSE")) {  // occupancy of the chunks (particles per chunk) after this re-sort
+    std::vector<ChunkRec> hc((size_t)f->n_chunks);
+    if (f->n_chunks) MPM_HIP_CHECK(c, hipMemcpy(hc.data(), f->chunks, hc.size() * sizeof(ChunkRec), hipMemcpyDeviceToHost));
+    int hist[5] = {0, 0, 0, 0, 0};
+    for (auto &r : hc) {
+      int tot = r.ne + r.nt + r.nv, n = std::min(CHUNK, tot - r.chunk * CHUNK);
+      hist[n <= 32 ? 0 : n <= 64 ? 1 : n <= 128 ? 2 : n < 256 ? 3 : 4]++;
+    }
+    fprintf(stderr, "[mpmhip] re-sort %ld: %d particle blocks, %d active blocks, %zu chunks (<=32: %d, <=64: %d, <=128: %d, <256: %d, full: %d), lead %.1f\n",
+            (long)f->rebins, f->n_P, f->n_A, hc.size(), hist[0], hist[1], hist[2], hist[3], hist[4], f->lead_steps);
   }
   MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + 6, 0, sizeof(int), s));
   f->h_pin[24] = 0;
@@ -2147,6 +2220,7 @@ int fast_init(mpmhip_ctx *c) {
   select_buffer(f, 0);
   if ((rc = dalloc(c, &f->g.vout, f->nblocks * GCH_VOUT * 64))) return rc;
   if ((rc = dalloc(c, &f->g.counters, 16))) return rc;
+  if ((rc = dalloc(c, &f->rcnt, (size_t)RC_N))) return rc;
   if ((rc = dalloc(c, &f->pb_flag, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->pb_index, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->ab_flag, f->nblocks))) return rc;
@@ -2651,7 +2725,7 @@ static int rccl_rebin(mpmhip_ctx *c) {
       if ((rc = dalloc(c, &p.halo_recv, (size_t)cap * 8 * 64, false))) return rc;
       p.cap_blocks = cap;
     }
-    if (p.n_blocks) hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, p.flag, p.index, nb, p.blocks);
+    if (p.n_blocks) hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, p.flag, p.index, nb, p.blocks, p.cap_blocks);
     DistPeer q;
     q.n_blocks = p.n_blocks; q.blocks = p.blocks; q.halo_send = p.halo_send; q.halo_recv = p.halo_recv;
     q.n_send_p = p.n_send_p; q.n_recv_p = p.n_recv_p; q.n_send_e = p.n_send_e; q.n_recv_e = p.n_recv_e;

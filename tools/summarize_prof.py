@@ -1,52 +1,72 @@
 #!/usr/bin/env python
-"""Condense rocprofv3 outputs under gpurun_out/prof into small tracked summaries under profiles/.
+"""Condense the rocprofv3 outputs of tools/gpu/profile_scene.sh into small tracked summaries under profiles/.
 
-usage: python tools/summarize_prof.py <tag>      (e.g. r01b)
+usage: python tools/summarize_prof.py <tag> [scene ...]      (e.g. r02a sheet-500k garment-120k-aniso)
+writes profiles/<tag>_<scene>_rocprof_summary.md, profiles/<tag>_<scene>_bench.json and, for the headline scene,
+profiles/<tag>_pmc.json (per-launch HBM traffic per kernel, read by bench.py's roofline.traffic).
 """
-import csv, glob, json, os, re, sys, collections
+import collections, csv, glob, json, os, re, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = "gpurun_out/prof"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+scenes = sys.argv[2:] or ["sheet-500k"]
 os.makedirs("profiles", exist_ok=True)
-out = []
-rows = list(csv.DictReader(open(f"{src}/fast_kernel_stats.csv")))
-out.append(f"# rocprofv3 --kernel-trace --stats  (bench.py --steps 200 --warmup 40, sheet-500k, fast mode) [{tag}]\n")
-out.append("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|")
-for r in rows[:16]:
-    m = re.search(r"\b(k_\w+(?:<[^>]*>)?)\(", r["Name"])
-    name = m.group(1) if m else re.sub(r"[<(].*", "", r["Name"])
-    out.append(f"| {name[:60]} | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |")
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob(f"{src}/pmc_*/pmc_counter_collection.csv")):
-    for row in csv.DictReader(open(f)):
-        m = re.search(r"\b(k_\w+(?:<[^>]*>)?)\(", row["Kernel_Name"])
-        if m:
-            agg[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
-if agg:
-    out.append("\n# PMC passes (separate runs, --kernel-trace --pmc ...), averages per launch\n")
-    out.append("FETCH_SIZE / WRITE_SIZE are in KiB as reported; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x "
-               "(MI355X_MICROARCH.md, HBM section), so `hbm_read_MB` below is 2 x FETCH_SIZE.\n")
-    out.append("| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | hbm_read_MB (2x) | hbm_write_MB | L2 hit % | VALU insts | LDS insts | wave-cycles | wait-any |")
-    out.append("|---|---|---|---|---|---|---|---|---|---|")
-    for k, v in agg.items():
-        a = {c: sum(x) / len(x) for c, x in v.items()}
-        if "FETCH_SIZE" not in a:
-            continue
-        hit = a.get("TCC_HIT_sum", 0); miss = a.get("TCC_MISS_sum", 0)
-        out.append(f"| {k} | {a.get('FETCH_SIZE',0):.0f} | {a.get('WRITE_SIZE',0):.0f} | {2*a.get('FETCH_SIZE',0)/1024:.1f} | {a.get('WRITE_SIZE',0)/1024:.1f} | "
-                   f"{100*hit/max(hit+miss,1):.0f} | {a.get('SQ_INSTS_VALU',0):.0f} | {a.get('SQ_INSTS_LDS',0):.0f} | {a.get('SQ_WAVE_CYCLES',0):.0f} | {a.get('SQ_WAIT_ANY',0):.0f} |")
-pmc = {k: {c: sum(x) / len(x) for c, x in v.items()} for k, v in agg.items() if "FETCH_SIZE" in v}
-if pmc:
-    # machine-readable per-launch HBM traffic for bench.py's roofline.traffic (bytes; reads = 2 x FETCH_SIZE KiB, see above)
-    json.dump({"tag": tag, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), sheet-500k fast mode",
-               "kernels": {k: {"hbm_read_bytes": 2 * a.get("FETCH_SIZE", 0) * 1024, "hbm_write_bytes": a.get("WRITE_SIZE", 0) * 1024,
-                               "launches_sampled": len(agg[k]["FETCH_SIZE"])} for k, a in pmc.items()}},
-              open(f"profiles/{tag}_pmc.json", "w"), indent=1)
-open(f"profiles/{tag}_rocprof_summary.md", "w").write("\n".join(out) + "\n")
-for name in ("bench_fast.json", "bench_baseline.json"):
-    p = f"gpurun_out/{name}"
+
+
+def kname(full):
+    m = re.search(r"\b(k_\w+(?:<[^>]*>)?)\(", full)
+    return m.group(1) if m else re.sub(r"[<(].*", "", full)[:48]
+
+
+for scene in scenes:
+    src = f"gpurun_out/prof_{tag}_{scene}"
+    out = []
+    st = glob.glob(f"{src}/**/fast_kernel_stats.csv", recursive=True)
+    rows = list(csv.DictReader(open(st[0]))) if st else []
+    out.append(f"# rocprofv3 --kernel-trace --stats -- python bench.py --scene {scene} --steps 200 --warmup 40 --no-kernels --advance 0   [{tag}]\n")
+    out.append("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|")
+    for r in rows[:14]:
+        out.append(f"| {kname(r['Name'])} | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |")
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in sorted(glob.glob(f"{src}/pmc_*/**/pmc_counter_collection.csv", recursive=True)):
+        for row in csv.DictReader(open(f)):
+            k = kname(row["Kernel_Name"])
+            if k.startswith("k_"):
+                agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    hot = [kname(r["Name"]) for r in rows[:6]]
+    if agg:
+        out.append("\n# PMC passes (each its own run: rocprofv3 --kernel-trace --pmc <set>), averages per launch\n")
+        out.append("FETCH_SIZE / WRITE_SIZE are KiB as reported; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x "
+                   "(MI355X_MICROARCH.md, HBM section): hbm_read_MB = 2 x FETCH_SIZE.  SQ_* cycle counters are quad-cycles summed over waves.\n")
+        out.append("| kernel | hbm_read_MB (2x) | hbm_write_MB | L2 hit % | waves | VALU / wave | LDS / wave | VMEM rd+wr / wave | VALU busy % of wave time | wait-any % | LDS bank conflict % |")
+        out.append("|---|---|---|---|---|---|---|---|---|---|---|")
+        for k, v in agg.items():
+            a = {c: sum(x) / len(x) for c, x in v.items()}
+            if "FETCH_SIZE" not in a or (hot and k not in hot and a.get("SQ_WAVES", 0) < 500):
+                continue
+            w = max(a.get("SQ_WAVES", 0), 1)
+            wc = max(a.get("SQ_WAVE_CYCLES", 0), 1)
+            hit, miss = a.get("TCC_HIT_sum", 0), a.get("TCC_MISS_sum", 0)
+            out.append(f"| {k} | {2*a.get('FETCH_SIZE',0)/1024:.1f} | {a.get('WRITE_SIZE',0)/1024:.1f} | {100*hit/max(hit+miss,1):.0f} | {w:.0f} | "
+                       f"{a.get('SQ_INSTS_VALU',0)/w:.0f} | {a.get('SQ_INSTS_LDS',0)/w:.0f} | {(a.get('SQ_INSTS_VMEM_RD',0)+a.get('SQ_INSTS_VMEM_WR',0))/w:.0f} | "
+                       f"{100*a.get('SQ_ACTIVE_INST_VALU',0)/wc:.0f} | {100*a.get('SQ_WAIT_ANY',0)/wc:.0f} | {100*a.get('SQ_LDS_BANK_CONFLICT',0)/max(a.get('SQ_ACTIVE_INST_LDS',1),1):.0f} |")
+        if scene == "sheet-500k":
+            pmc = {k: {c: sum(x) / len(x) for c, x in v.items()} for k, v in agg.items() if "FETCH_SIZE" in v}
+            json.dump({"tag": tag, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), sheet-500k fast mode",
+                       "kernels": {k: {"hbm_read_bytes": 2 * a.get("FETCH_SIZE", 0) * 1024, "hbm_write_bytes": a.get("WRITE_SIZE", 0) * 1024,
+                                       "launches_sampled": len(agg[k]["FETCH_SIZE"])} for k, a in pmc.items()}},
+                      open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+    p = f"{src}/bench_fast.json"
     if os.path.exists(p):
         line = [l for l in open(p) if l.startswith("{")]
         if line:
-            open(f"profiles/{tag}_{name}", "w").write(json.dumps(json.loads(line[-1]), indent=1) + "\n")
-print(open(f"profiles/{tag}_rocprof_summary.md").read())
+            o = json.loads(line[-1])
+            json.dump(o, open(f"profiles/{tag}_{scene}_bench.json", "w"), indent=1)
+            out.append(f"\n# bench.py --scene {scene} --steps 400 --warmup 40\n")
+            out.append(f"value {o['value']:.0f} substeps/s ({o['ms_per_step']*1e3:.1f} us/substep), whole-substep fraction of 8 TB/s (algorithmic bytes) "
+                       f"{o.get('substep_frac_of_hbm_peak', float('nan')):.3f}; after {o.get('draped', {}).get('advance', 0)} more substeps: "
+                       f"{o.get('value_draped', float('nan')):.0f} substeps/s, {o.get('draped', {}).get('rebins_in_window')} re-sorts in the window\n")
+            out.append("| launch of the timed loop (HIP events) | us | algorithmic MB | frac of 8 TB/s |\n|---|---|---|---|")
+            for k in o.get("kernels", []):
+                out.append(f"| {k['name']} | {k['ms']*1e3:.1f} | {k.get('alg_bytes', 0)/1e6:.1f} | {k.get('frac', float('nan')):.3f} |")
+    open(f"profiles/{tag}_{scene}_rocprof_summary.md", "w").write("\n".join(out) + "\n")
+    print(open(f"profiles/{tag}_{scene}_rocprof_summary.md").read())
