@@ -1519,7 +1519,10 @@ __global__ __launch_bounds__(PT) void k_g2p(Bufs b, const ChunkRec *recs, int n_
     // lanes without a particle in the tile margin gather from the tile corner (in range, result unused)
     bool fit = valid && !escaped;
     V3 xg = fit ? x : v3((float)(ox + 2) * d.dx, (float)(oy + 2) * d.dx, (float)(oz + 2) * d.dx);
-    if (!TWO_PASS) {
+    // a wavefront without a single particle (the tail of a chunk: a flat sheet fills ~184 of the 256 lanes) has helped to
+    // stage the tile and is done: the gather is ~600 VALU instructions per wavefront and the kernel is bound by VALU issue
+    if (!__any(fit)) {
+    } else if (!TWO_PASS) {
       G2PResult r = g2p_gather(tile, ox, oy, oz, xg, d);
       if (fit) g2p_write(b, cls, s, x, d3, r, ox, oy, oz, d, dt, g);
     } else {
@@ -2403,7 +2406,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   }
   sa.n_extra = (sa.n_fbins + sa.n_mov_wg + 7) & ~7;
   sa.z_first = sa.n_extra + (int)xcd_grid(f->n_chunks);
-  {
+  if (d.n_e || (d.n_t && !trad_fused)) {  // (no empty event bracket when the stress update rides in p2g)
     ScopedPhase ph(c, "compute_stress_from_F_trial");
     if (d.n_e) {
       if (f->elem_pending)

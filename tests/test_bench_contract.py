@@ -30,11 +30,14 @@ def _check(o, n_gpus=1, with_cpu=True):
 
 
 def test_committed_bench_line_follows_the_contract():
-    lines = [l for l in open(os.path.join(ROOT, "profiles", "r01i_bench_fast.json")).read().splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    o = json.loads(lines[0])
+    o = json.load(open(os.path.join(ROOT, "profiles", "r02b_sheet-500k_bench.json")))
     _check(o)
     assert o["config"]["workload"] == "sheet-500k" and o["config"]["n_particles"] == 497762 and o["config"]["n_grid"] == 256
+    # round 2: the roofline's kernel is one of the launches of the timed (fused) loop, and the steady state is reported
+    assert o["kernels_mode"] == "fused-loop" and o["roofline"]["kernel"] in {k["name"] for k in o["kernels"]}
+    assert o["phases_mode"].startswith("per-phase") and {p["name"] for p in o["phases"]} >= {"p2g", "g2p_v", "g2p_e", "grid_update"}
+    assert 0 < o["value_draped"] < o["value"] and o["draped"]["advance"] == 2000 and o["draped"]["rebins_in_window"] >= 1
+    assert o["roofline"]["traffic"] > 0 and o["roofline"]["traffic_source"].startswith("profiles/")
 
 
 @pytest.mark.gpu

@@ -32,9 +32,16 @@ print("ok")
 '''
 
 
-def test_reference_import_lines_resolve_unchanged():
+def test_reference_import_lines_resolve_unchanged(tmp_path):
+    """Run from a directory laid out like the reference's root: a ``warp_mpm/`` directory WITHOUT ``__init__.py`` holding its
+    own mpm_solver.py (a namespace package, first on sys.path as the script's cwd).  The regular package of this repository,
+    later on the path, must win."""
+    fake = tmp_path / "refroot"
+    (fake / "warp_mpm").mkdir(parents=True)
+    (fake / "warp_mpm" / "mpm_solver.py").write_text("raise ImportError('the reference Warp solver must not be imported')\n")
+    (fake / "warp_mpm" / "mpm_data_structure.py").write_text("raise ImportError('the reference Warp structs must not be imported')\n")
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "mpmavatar_amd", "compat")]))
-    r = subprocess.run([sys.executable, "-c", CHECK], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", CHECK], cwd=str(fake), env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
 
 
