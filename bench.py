@@ -273,6 +273,53 @@ def _main(out_stream):
                     k["frac"] = k["GBps"] / HBM_PEAK_GBS
                 phases.append(k)
             out["phases"], out["phases_mode"] = phases, "per-phase (un-fused launches, one sync each; not the timed loop)"
+    if sharded and not args.no_kernels:
+        # per-rank view of rank 0: its launches of the sharded loop (HIP events, same kernels as the timed region), the
+        # dominant one against the roofline with this rank's algorithmic bytes, and what the halo exchange moves
+        ss = box["ss"]
+        sv = ss.sim.solver
+        lsc = ss.shard.scene
+        owned = lsc.selection == 0 if lsc.selection is not None else None
+        st = sv.stats()
+        n_act = st["n_active_nodes"]
+        ne_o = int(owned[:lsc.n_elements].sum()) if owned is not None else lsc.n_elements
+        nv_o = int(owned[lsc.n_elements + lsc.n_traditional:].sum()) if owned is not None else lsc.n_vertices
+        nt_o = lsc.n_traditional
+        rank_bytes = {"compute_stress_from_F_trial": (188 + 60) * lsc.n_elements + 12 * lsc.n_vertices,   # ghosts run the stress update too
+                      "p2g": 100 * ne_o + 76 * nv_o + 220 * nt_o + 16 * n_act,
+                      "g2p_v": 168 * lsc.n_elements + 72 * lsc.n_vertices + 144 * nt_o + 40 * n_act}       # ghosts gather for themselves
+        sv.enable_profiling(True, fused=True)
+        sv.time_profile.clear()
+        run(min(args.steps, 100))
+        sv = box["ss"].sim.solver
+        sv._collect_profile()
+        sv.enable_profiling(False)
+        names = {"compute_stress_from_F_trial": "k_stress_elem<true>", "p2g": "k_p2g", "g2p_v": "k_g2p", "rebin": "re-sort",
+                 "halo_exchange": "ncclSend/ncclRecv group"}
+        kernels = []
+        for name, samples in sv.time_profile.items():
+            ms = sum(samples) / max(len(samples), 1)
+            k = {"name": names.get(name, name), "phase": name, "ms": ms, "launches": len(samples)}
+            if name in rank_bytes and ms > 0 and rank_bytes[name] > 0:
+                k["alg_bytes"], k["GBps"] = rank_bytes[name], rank_bytes[name] / (ms * 1e-3) / 1e9
+                k["frac"] = k["GBps"] / HBM_PEAK_GBS
+            kernels.append(k)
+        out["kernels"], out["kernels_mode"] = kernels, "fused-loop, rank 0 of %d" % world
+        with_bytes = [k for k in kernels if "alg_bytes" in k]
+        if with_bytes:
+            dom = max(with_bytes, key=lambda k: k["ms"])
+            out["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": dom["frac"], "traffic": None, "alg_bytes_per_launch": dom["alg_bytes"],
+                               "ms_per_launch": dom["ms"], "measured": "HIP events around the launch in the sharded loop, rank 0"}
+        ch = 8 if sv.particle_movers else 4
+        import ctypes
+        hb = ctypes.c_int64(0)
+        sv._call("mpmhip_dist_halo_bytes", ctypes.byref(hb))
+        halo_bytes = int(hb.value)
+        out["exchange"] = {"transport": box["ss"].transport, "halo_bytes_per_substep_sent_by_rank0": halo_bytes,
+                           "channels_per_node": ch, "peers_of_rank0": len(box["ss"].static) - 1,
+                           "halo_exchange_us": next((k["ms"] * 1e3 for k in kernels if k["phase"] == "halo_exchange"), None),
+                           "re_partitions": box["ss"].migrations}
     if args.advance > 0:
         # the steady state: after `advance` more substeps the sheet lies draped over the sphere, moves at metres per second and
         # the particle order is rebuilt every few dozen substeps; re-sorts inside the window are part of the number

@@ -249,6 +249,8 @@ int mpmhip_rccl_set_ghosts(mpmhip_ctx *ctx, int32_t n_peers, const int32_t *peer
  * the ghosts are re-synchronised before every re-sort instead.  Mesh advection factor of substep k is
  * (step_index + k) * dt.  joint_traditional_v: velocities of the LAST n_joint_t traditional particles this rank owns (the
  * staged release of run_demo.py:524; a rank's share of the held particles is a suffix of its owned ones), or NULL */
+/* bytes this rank sends per substep in the halo exchange with the current shared-block lists (measurement) */
+int mpmhip_dist_halo_bytes(mpmhip_ctx *ctx, int64_t *out);
 int mpmhip_rccl_steps(mpmhip_ctx *ctx, float dt, int32_t n, int64_t step_index, int32_t rebin_interval,
                       const float *mesh_x, const float *mesh_v, const float *joint_traditional_v, int32_t n_joint_t,
                       const float *joint_verts_v, const float *joint_faces_v);

@@ -530,6 +530,13 @@ int mpmhip_set_debug_flags(mpmhip_ctx *c, int32_t flags) {
   return fast_set_debug_flags(c, flags);
 }
 
+int mpmhip_dist_halo_bytes(mpmhip_ctx *c, int64_t *out) {
+  CHECK_CTX(c);
+  if (!fast_mode(c) || !c->fast || !out) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
+  *out = fast_dist_halo_bytes(c);
+  return MPMHIP_OK;
+}
+
 int mpmhip_debug_counter(mpmhip_ctx *c, int32_t index, int64_t *out) {
   CHECK_CTX(c);
   if (!fast_mode(c) || !c->fast) return fail(c, MPMHIP_ERR_INVALID, "debug_counter: fast mode only");

@@ -2539,6 +2539,12 @@ int fast_dist_set_ghost_mode(mpmhip_ctx *c, int ghosts_gather) {
   return MPMHIP_OK;
 }
 int fast_dist_num_blocks(const mpmhip_ctx *c) { return (int)c->fast->nblocks; }
+int64_t fast_dist_halo_bytes(const mpmhip_ctx *c) {  // bytes this rank sends per substep in the halo exchange (all peers)
+  int CH = c->movers.empty() ? 4 : 8;
+  int64_t n = 0;
+  for (auto &p : c->fast->peers) n += (int64_t)p.n_blocks * CH * 64 * 4;
+  return n;
+}
 
 int fast_dist_rebin(mpmhip_ctx *c, unsigned char *active_map) {
   FastState *f = c->fast;
@@ -2802,7 +2808,10 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
       }
     }
     if ((rc = fast_dist_phase(c, 0, a))) return rc;
-    if ((rc = rccl_exchange(c, true))) return rc;
+    {
+      ScopedPhase ph(c, "halo_exchange");  // (profiling only: the ncclSend/ncclRecv group between the pack and the add kernel)
+      if ((rc = rccl_exchange(c, true))) return rc;
+    }
     if ((rc = fast_dist_phase(c, 1, a))) return rc;
     if (!f->ghost_g2p && (rc = rccl_exchange(c, false))) return rc;
     if ((rc = fast_dist_phase(c, 2, a))) return rc;

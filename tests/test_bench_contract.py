@@ -73,4 +73,9 @@ def test_bench_gpus_n_without_a_launcher():
     assert r.returncode == 0, r.stderr[-3000:]
     out = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(out) == 1, r.stdout[:500]
-    _check(json.loads(out[0]), n_gpus=2, with_cpu=False)
+    o = json.loads(out[0])
+    _check(o, n_gpus=2, with_cpu=False)
+    # N > 1 lines carry the per-rank roofline and what the exchange moves
+    assert o["roofline"]["bound"] == "hbm" and 0 < o["roofline"]["frac"] < 1 and o["kernels_mode"].startswith("fused-loop, rank 0")
+    assert o["exchange"]["transport"] in ("torch", "rccl") and o["exchange"]["halo_bytes_per_substep_sent_by_rank0"] > 0
+    assert o["config"]["exchange"] == o["exchange"]["transport"]

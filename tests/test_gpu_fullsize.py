@@ -5,7 +5,7 @@ collider + mover + swaying body): 50 substeps, OpenMP oracle on all host threads
 workload): 20 substeps, OpenMP oracle.  The oracle is pinned by the reference's own source (tests/test_ref_golden.py);
 here it carries that to the sizes the reference fixtures cannot reach.  Bounds: x and v within 1e-4 (north star); for S3
 the cloth rests on the return mapping's R22 = 1 discontinuity from the first substep on, so its v bound is the reference's
-own sensitivity there (3 x the self-distance of the reference's garment sequence, tests/golden/ref_seq_garment.npz)."""
+own sensitivity there (3 x the self-distance, in m/s, of the reference's garment sequence, tests/golden/ref_seq_garment.npz)."""
 import os
 
 import numpy as np
@@ -45,9 +45,13 @@ def test_s3_garment_120k_anisotropic_with_collider_50_substeps(oracle_lib):
     sc, o, x, v = _pair("garment-120k-aniso", 50, omp=True)
     assert sc.n_elements == 79600 and sc.n_vertices == 40000 and sc.mesh_faces is not None and sc.num_joint_v > 0
     z = rg.load("ref_seq_garment")
-    envelope = max(rg.rel(z[f"alt_s{c}_particle_v"], z[f"s{c}_particle_v"]) for c in (40, 80))
+    # The kick a branch flip at R22 = 1 gives a vertex is set by the material (gamma, kappa, dt), not by how fast the body
+    # moves, and this scene's body starts slowly (0.06 m/s in the first frame against 0.3 m/s in the fixture's), so the
+    # envelope is taken in m/s: how far the reference's garment run moves away from itself when svd3 / qr3 are fp32-accurate.
+    envelope = max(float(np.abs(z[f"alt_s{c}_particle_v"] - z[f"s{c}_particle_v"]).max()) for c in (40, 80))
     assert rg.rel(x, o.x) < 1e-4
-    assert rg.rel(v, o.v) < max(1e-4, 3.0 * envelope), (rg.rel(v, o.v), envelope)
+    dv = float(np.abs(v - o.v).max())
+    assert dv < 3.0 * envelope, (dv, envelope)
 
 
 def test_s4_sheet_500k_20_substeps(oracle_lib):
