@@ -39,7 +39,10 @@ namespace {
 
 constexpr int TPB = 256;
 constexpr int CHUNK = 256;     // particles of one block handled by one workgroup of p2g / g2p (192, re-measured with
-                               // the 92/95-VGPR kernels: sheet -1 us, garment and dense scenes 15 % slower)
+                               // the 92/95-VGPR kernels: sheet -1 us, garment and dense scenes 15 % slower; round 2, chunk size
+                               // chosen per scene at run time: 128 / 64 are slower on every scene but demo-250 (-3 %), even on
+                               // the 8k cube whose 256-particle chunks occupy a quarter of the CUs -- the cost is per workgroup:
+                               // tile clear, two barriers, flush; profiles/r02_experiments.md)
 constexpr int PT = CHUNK;      // threads of those workgroups (and of the extra workgroups riding in their launches)
 constexpr int TILE = 8;        // tile edge in nodes: block (4) + 1 below + 3 above
 constexpr int TILE3 = TILE * TILE * TILE;
@@ -349,7 +352,7 @@ struct GridPtrs {
   int *m_flag;      // [block] 1 = p2g (or a halo sum) may have written this block's mass / momentum this substep
   int *counters;    // [0] particles outside their tile margin, [1] dropped contributions (inactive block)
   int dbg;          // MPMHIP_DBG bitmask (perf experiments only, results are wrong): 1 skip p2g flush, 2 skip the p2g
-                    // scatter, 8 / 16 skip vertex-force / stress loads, 128 skip the LDS atomics only, 256 skip the splat workgroups; 64 (results stay
+                    // scatter, 8 / 16 skip vertex-force / stress loads, 128 skip the LDS atomics only, 256 skip the splat workgroups, 2048 skip the clearing workgroups; 64 (results stay
                     // right) runs the stand-alone element finalize every substep instead of fusing it into the stress kernel
 };
 
@@ -1188,7 +1191,7 @@ __global__ __launch_bounds__(PT) void k_p2g(Bufs b, VAdj va, const ChunkRec *rec
     return;
   }
   if ((int)blockIdx.x >= sa.z_first) {  // ... and the clearing workgroups last: they fill the tail of the launch
-    zero_blocks_wg(sa.z, (int)blockIdx.x - sa.z_first);
+    if (!(g.dbg & 2048)) zero_blocks_wg(sa.z, (int)blockIdx.x - sa.z_first);
     return;
   }
   int w = xcd_slice((int)blockIdx.x - sa.n_extra, n_chunks);

@@ -15,10 +15,11 @@ def measure(sim, flags, n=120):
     sv._call("mpmhip_set_debug_flags", 0)
     return {k: round(1e3 * sum(v) / len(v), 1) for k, v in sv.time_profile.items() if k in ("compute_stress_from_F_trial", "p2g", "g2p_v")}
 
-for upto in (100, 2200):
+for upto in (100,):
     print(f"== state after {upto} substeps", flush=True)
     for flags, what in ((0, "full"), (256, "no splat workgroups"), (128, "no LDS atomics"), (2, "no scatter arithmetic"), (1, "no flush"),
-                        (2 | 256 | 1, "loads + barriers only"), (8, "no vertex-force gather")):
+                        (2 | 256 | 1, "loads + barriers only"), (8, "no vertex-force gather"), (16, "no stress loads"), (2048, "no clearing workgroups"),
+                        (2 | 256 | 1 | 2048 | 8 | 16, "record + x, m, C, v loads + barriers")):
         sim = harness.build_solver(scenes.REGISTRY["sheet-500k"](), "cuda:0")
         harness.run(sim, upto, fused=True)
         st = sim.solver.stats()
