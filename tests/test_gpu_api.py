@@ -40,7 +40,7 @@ def test_read_modify_continue(mode, oracle_lib):
         o.p2g2p(sc.dt, **kw)
     harness.run(sim, 10, fused=False)
     assert rel(sim.state.particle_x.cpu().numpy(), o.x) < 1e-5
-    assert rel(sim.state.particle_v.cpu().numpy(), o.v) < 2e-2
+    assert rel(sim.state.particle_v.cpu().numpy(), o.v) < 3e-3   # cloth on the R22 = 1 discontinuity (tests/test_gpu_parity.py docstring)
 
 
 def test_plain_read_back_costs_no_reimport():
@@ -178,7 +178,7 @@ def test_fast_profiled_equals_fused(scene):
     xa, xb = fused.state.particle_x.cpu().numpy(), prof.state.particle_x.cpu().numpy()
     va, vb = fused.state.particle_v.cpu().numpy(), prof.state.particle_v.cpu().numpy()
     assert rel(xa, xb) < 2e-6
-    assert rel(va, vb) < (1e-5 if scene == "cube" else 2e-2)  # cloth: branch flips at R22 == 1 (test_gpu_parity docstring)
+    assert rel(va, vb) < (1e-5 if scene == "cube" else 3e-3)  # cloth: branch flips at R22 == 1 (test_gpu_parity docstring)
     (ma, _, voa), (mb, _, vob) = fused.solver.export_grid(), prof.solver.export_grid()
     ma, mb = ma.cpu().numpy(), mb.cpu().numpy()
     assert (ma > 0).sum() > 0 and rel(ma, mb) < 1e-4
@@ -203,7 +203,7 @@ def test_headline_size_fast_equals_baseline(big_pair):
     sc, a, b = big_pair
     xa, xb = a.state.particle_x.cpu().numpy(), b.state.particle_x.cpu().numpy()
     assert np.isfinite(xa).all() and rel(xa, xb) < 1e-5
-    assert rel(a.state.particle_v.cpu().numpy(), b.state.particle_v.cpu().numpy()) < 2e-2
+    assert rel(a.state.particle_v.cpu().numpy(), b.state.particle_v.cpu().numpy()) < 3e-3
     st = a.solver.stats()
     assert st["rebins"] >= 1
 

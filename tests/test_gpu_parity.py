@@ -4,9 +4,12 @@ the oracle is pinned by tests/test_oracle_*.py.
 
 Tolerances (BASELINE.json north_star: particle x / v within 1e-4 relative after N substeps):
   rel(a, b) = max|a-b| / max(max|b|, 1e-3).
-Cloth scenes carry a documented caveat: the reference's anisotropic return mapping is discontinuous at
-R22 == 1 (mpm_utils.py:196-204: shear kept above, projected to ~0 just below), so fp32 rounding-order
-differences flip branches and velocities decorrelate at the 1e-3..1e-2 level while positions stay < 1e-4.
+Cloth scenes with gamma > 0 carry a documented caveat: the reference's anisotropic return mapping is discontinuous at
+R22 == 1 (mpm_utils.py:196-204: shear kept above, projected to ~0 just below) and a cloth at rest sits exactly there, so
+the rounding of the QR flips branches.  The reference moves by up to 1.2e-3 (relative) / 2.2e-4 m/s against ITSELF when
+its svd3 / qr3 are fp32- instead of fp64-accurate (tests/test_ref_golden.py, tests/golden/ref_seq_*.npz); the velocity bounds
+of the cloth cases below are a few times what was measured here (tools/gpu/dv_report.py: sheet <= 1.7e-4, garment <= 8.4e-4,
+demo mix <= 4e-6), not the blanket 5e-2 of round 1.  Positions stay < 1e-6.
 """
 import numpy as np
 import pytest
@@ -56,9 +59,9 @@ def test_sheet_over_sphere(mode, oracle_lib):
     sc = scenes.small_sheet()
     o, g, _ = _run_pair(sc, 200, mode)
     assert np.isfinite(g["particle_x"]).all()
-    assert rel(g["particle_x"], o.x) < 1e-4
-    assert rel(g["particle_v"], o.v) < 5e-2   # see module docstring: branch flips at R22 == 1
-    assert rel(g["particle_d"], o.d) < 5e-2
+    assert rel(g["particle_x"], o.x) < 1e-5
+    assert rel(g["particle_v"], o.v) < 1e-3   # measured 2.3e-5 (peak 1.7e-4 on the way); see module docstring
+    assert rel(g["particle_d"], o.d) < 3e-3   # measured 1.9e-5 (peak 4.5e-4)
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -76,16 +79,16 @@ def test_sheet_short_strict(mode, oracle_lib):
 def test_garment_with_mover(mode, oracle_lib):
     sc = scenes.small_garment()
     o, g, _ = _run_pair(sc, 100, mode)
-    assert rel(g["particle_x"], o.x) < 1e-4
-    assert rel(g["particle_v"], o.v) < 5e-2
+    assert rel(g["particle_x"], o.x) < 1e-5
+    assert rel(g["particle_v"], o.v) < 3e-3   # measured 5.6e-4 (fast) / 8.4e-4 (baseline); the reference against itself: 7.2e-4
 
 
 @pytest.mark.parametrize("mode", MODES)
 def test_demo_mix(mode, oracle_lib):
     sc = scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8))
     o, g, _ = _run_pair(sc, 100, mode)
-    assert rel(g["particle_x"], o.x) < 1e-4
-    assert rel(g["particle_v"], o.v) < 5e-3
+    assert rel(g["particle_x"], o.x) < 1e-5
+    assert rel(g["particle_v"], o.v) < 1e-4   # measured 4.1e-6
     assert rel(g["particle_F_trial"], o.F_trial) < 1e-4
 
 
@@ -153,7 +156,7 @@ def test_out_of_margin_paths(scene, oracle_lib):
     assert st["rebins"] == 1 and stc["rebins"] >= 2
     assert st["n_fallback_particles"] > 1000, "scene did not drift far enough to exercise the out-of-margin paths"
     assert rel(x, o.x) < (1e-4 if scene == "cube" else 1e-3)
-    assert rel(v, o.v) < (3e-4 if scene == "cube" else 5e-2)
+    assert rel(v, o.v) < (3e-4 if scene == "cube" else 1e-2)
     assert rel(x, xc) < (2e-5 if scene == "cube" else 2e-4)
 
 
@@ -169,8 +172,8 @@ def test_staged_sand_release(mode, sand, oracle_lib):
     sc = mk()
     assert sc.joint_t_count(0) == sc.n_traditional and 0 < sc.joint_t_count(45) < sc.n_traditional
     o, g, _ = _run_pair(sc, 80, mode)
-    assert rel(g["particle_x"], o.x) < 1e-4
-    assert rel(g["particle_v"], o.v) < 5e-3
+    assert rel(g["particle_x"], o.x) < 1e-5
+    assert rel(g["particle_v"], o.v) < 5e-4
     held = slice(sc.n_elements + sc.n_traditional - sc.joint_t_count(80), sc.n_elements + sc.n_traditional)
     if sc.joint_t_count(80) > 0:   # still held: has not moved
         assert np.abs(g["particle_x"][held] - sc.x[held]).max() < 1e-6

@@ -51,12 +51,12 @@ def test_sheet_first_substep_strict(oracle_lib):
 
 def test_sheet_200_substeps(oracle_lib):
     o, t = pair(scenes.small_sheet(), 200)
-    assert rel(o.x, t.x) < 1e-4 and rel(o.v, t.v) < 5e-2
+    assert rel(o.x, t.x) < 1e-5 and rel(o.v, t.v) < 5e-3   # cloth on the R22 = 1 discontinuity: see tests/test_ref_golden.py
 
 
 def test_garment_with_collider_and_mover(oracle_lib):
     o, t = pair(scenes.small_garment(), 100)
-    assert rel(o.x, t.x) < 1e-4 and rel(o.v, t.v) < 5e-2
+    assert rel(o.x, t.x) < 1e-5 and rel(o.v, t.v) < 5e-3
 
 
 def test_demo_mix(oracle_lib):
