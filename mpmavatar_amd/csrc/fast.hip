@@ -1601,7 +1601,7 @@ __global__ void k_pre_sorted(PreOp op, Bufs b, const int *perm, Dims d, float dt
     V3 a1 = v3(op.axis1[0], op.axis1[1], op.axis1[2]), a2 = v3(op.axis2[0], op.axis2[1], op.axis2[2]);
     V3 off = ld3(b.all, A_X, s) - v3(op.point[0], op.point[1], op.point[2]);
     float hd = length(off - dot(off, nrm) * nrm);
-    float theta = acosf(dot(off, a1) / hd);
+    float theta = acosf(fminf(fmaxf(dot(off, a1) / hd, -1.f), 1.f));  // wp.acos clamps its argument
     if (!(dot(off, a2) > 0.0f)) theta = -theta;
     pv = (-hd * sinf(theta) * op.rotation_scale) * a1 + (hd * cosf(theta) * op.rotation_scale) * a2 + op.translation_scale * nrm;
   }

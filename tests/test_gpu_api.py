@@ -289,3 +289,22 @@ def test_selection_two_is_not_simulated_on_a_single_context(oracle_lib):
     o = _oracle(sc)
     run_scene(o, sc, 10)
     assert rel(res["fast"], o.x) < 1e-5
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_rotation_modifier_on_the_axis_stays_finite(mode):
+    """wp.acos clamps its argument (the reference's modify_particle_v_before_p2g, mpm_solver.py:1235); a particle lying
+    exactly along +-axis1 from the rotation point gives dot/|.| = 1 +- 1 ulp and must not come out NaN."""
+    rng = np.random.default_rng(4)
+    sc = scenes.small_cube(n=5)
+    sc.bcs = []
+    c = np.array([1.0, 1.0, 1.0], np.float32)
+    h1 = np.array([1.0, 0.0, 1.0]) / np.sqrt(2.0)
+    r = rng.uniform(0.01, 0.15, sc.x.shape[0]) * rng.choice([-1.0, 1.0], sc.x.shape[0])
+    sc.x = (c + np.outer(r, h1)).astype(np.float32)
+    sim = harness.build_solver(sc, "cuda:0", mode=mode)
+    sim.solver.enforce_particle_velocity_rotation(sim.state, c.tolist(), [0.0, 1.0, 0.0], [0.05, 0.3], 2.0, 0.0, 0.0, 1.0)
+    sim.solver.p2g2p(sim.model, sim.state, sc.dt)
+    v = sim.state.particle_v.cpu().numpy()
+    assert np.isfinite(v).all()
+    assert np.isfinite(sim.state.particle_x.cpu().numpy()).all()
