@@ -1779,7 +1779,14 @@ struct Rccl {  // entry points resolved with dlsym: libmpmhip.so itself does not
   int rank = 0, world = 1;
   bool load(std::string &err) {
     if (h) return true;
-    h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // MPMHIP_RCCL_LIB: another library with the same ten entry points (tests/mock_rccl: shared-memory stand-in that lets
+    // 2-3 ranks share the one GPU of a test box, which RCCL itself refuses)
+    const char *over = getenv("MPMHIP_RCCL_LIB");
+    if (over && *over) {
+      h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+      if (!h) { err = std::string("dlopen MPMHIP_RCCL_LIB=") + over + ": " + dlerror(); return false; }
+    }
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) { err = std::string("dlopen librccl.so.1: ") + dlerror(); return false; }
     auto sym = [&](const char *n) { void *p = dlsym(h, n); if (!p) err = std::string("dlsym ") + n; return p; };

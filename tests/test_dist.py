@@ -115,6 +115,42 @@ def test_in_library_rccl_transport_two_ranks(scene, steps):
     assert "max rel dx" in r.stdout
 
 
+def _mock_rccl_env(**kw):
+    """MPMHIP_RCCL_LIB -> tests/mock_rccl (shared-memory stand-in for the ten RCCL entry points the library binds)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "mock_rccl"))
+    from build import build as build_mock
+    return dict(MPMHIP_DIST_TRANSPORT="rccl", MPMHIP_RCCL_LIB=build_mock(), **{k: str(v) for k, v in kw.items()})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,scene,steps,rebin,ghost_g2p", [
+    (2, "garment", 60, 8, 1), (2, "garment", 40, 8, 0), (2, "sheet", 100, 8, 1), (3, "sheet", 60, 8, 1), (3, "demo", 60, 8, 1),
+    (2, "demo", 30, 8, 0), (2, "cube", 30, 8, 1), (2, "fastcube", 200, 0, 1), (2, "sheet", 60, 0, 1), (2, "demohold", 60, 8, 1)])
+def test_in_library_loop_with_several_ranks(world, scene, steps, rebin, ghost_g2p):
+    """`mpmhip_rccl_steps` -- the loop bench.py --gpus N runs -- with 2 and 3 ranks on ONE GPU: the library binds RCCL by
+    dlsym, and MPMHIP_RCCL_LIB points it at a stand-in that moves the same messages through shared memory (real RCCL
+    refuses two ranks on one device).  Covers what a one-GPU box otherwise never executes: the all-gather of the block
+    maps, the shared-block lists, the halo send/recv group (sizes checked pairwise by the stand-in), ghost
+    re-synchronisation at collective re-sorts, the all-reduced drift flag (rebin 0), staged release.  Result: the single
+    context's trajectory."""
+    import re
+    out = _launch(world, "gpu", scene, steps, extra_env=_mock_rccl_env(MPMHIP_TEST_REBIN=rebin, MPMHIP_DIST_GHOST_G2P=ghost_g2p))
+    assert "max rel dx" in out and "(rccl)" in out
+    n = [int(x) for x in re.findall(r"rank \d+: (\d+) collective re-sorts", out)]
+    assert len(n) == world and len(set(n)) == 1          # every rank took the same decisions
+    if rebin == 0:
+        assert (n[0] >= 3) if scene == "fastcube" else (n[0] <= 2)
+
+
+@pytest.mark.gpu
+def test_in_library_loop_migration_over_the_stand_in():
+    import re
+    out = _launch(2, "gpu", "crossing", 150, extra_env=_mock_rccl_env(MPMHIP_TEST_MIGRATE=0.1, MPMHIP_TEST_RUN_CHUNK=30))
+    assert "max rel dx" in out and "(rccl)" in out
+    n = [int(x) for x in re.findall(r"rank \d+: (\d+) re-partitions", out)]
+    assert len(n) == 2 and n[0] == n[1] and n[0] >= 1
+
+
 @pytest.mark.gpu
 def test_sharded_staged_sand_release():
     """run_demo.py:524 in the sharded driver: each rank holds its share (a suffix of its owned traditional particles) of the
