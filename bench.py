@@ -316,7 +316,12 @@ def _main(out_stream):
         hb = ctypes.c_int64(0)
         sv._call("mpmhip_dist_halo_bytes", ctypes.byref(hb))
         halo_bytes = int(hb.value)
-        out["exchange"] = {"transport": box["ss"].transport, "halo_bytes_per_substep_sent_by_rank0": halo_bytes,
+        halo = None
+        if box["ss"].transport == "rccl":
+            ht = ctypes.c_int32(0)
+            sv._call("mpmhip_dist_halo_transport", ctypes.byref(ht))
+            halo = "peer-mapped buffers (HIP IPC, flags in the receiver's memory)" if ht.value == 1 else "ncclSend/ncclRecv"
+        out["exchange"] = {"transport": box["ss"].transport, "halo": halo, "halo_bytes_per_substep_sent_by_rank0": halo_bytes,
                            "channels_per_node": ch, "peers_of_rank0": len(box["ss"].static) - 1,
                            "halo_exchange_us": next((k["ms"] * 1e3 for k in kernels if k["phase"] == "halo_exchange"), None),
                            "re_partitions": box["ss"].migrations}

@@ -251,6 +251,12 @@ int mpmhip_rccl_set_ghosts(mpmhip_ctx *ctx, int32_t n_peers, const int32_t *peer
  * staged release of run_demo.py:524; a rank's share of the held particles is a suffix of its owned ones), or NULL */
 /* bytes this rank sends per substep in the halo exchange with the current shared-block lists (measurement) */
 int mpmhip_dist_halo_bytes(mpmhip_ctx *ctx, int64_t *out);
+/* how mpmhip_rccl_steps moves the halos: 1 = peer-mapped buffers (each pair of neighbouring ranks maps the other's
+ * fine-grained receive arena with HIP IPC at the first collective re-sort; the pack kernel stores into it and raises a flag
+ * there, the add kernel waits for its own flag -- no RCCL kernel in the substep), 0 = ncclSend/ncclRecv groups.  Peer
+ * mapping is the default and is used only if a four-round handshake over every link of every rank succeeded (max-reduced);
+ * MPMHIP_DIST_HALO=rccl keeps send/recv.  No counterpart in the reference (single GPU). */
+int mpmhip_dist_halo_transport(mpmhip_ctx *ctx, int32_t *out);
 int mpmhip_rccl_steps(mpmhip_ctx *ctx, float dt, int32_t n, int64_t step_index, int32_t rebin_interval,
                       const float *mesh_x, const float *mesh_v, const float *joint_traditional_v, int32_t n_joint_t,
                       const float *joint_verts_v, const float *joint_faces_v);

@@ -537,6 +537,13 @@ int mpmhip_dist_halo_bytes(mpmhip_ctx *c, int64_t *out) {
   return MPMHIP_OK;
 }
 
+int mpmhip_dist_halo_transport(mpmhip_ctx *c, int32_t *out) {
+  CHECK_CTX(c);
+  if (!fast_mode(c) || !c->fast || !out) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
+  *out = fast_dist_halo_transport(c);
+  return MPMHIP_OK;
+}
+
 int mpmhip_debug_counter(mpmhip_ctx *c, int32_t index, int64_t *out) {
   CHECK_CTX(c);
   if (!fast_mode(c) || !c->fast) return fail(c, MPMHIP_ERR_INVALID, "debug_counter: fast mode only");

@@ -1639,6 +1639,11 @@ struct HaloTab {
   const int *blocks[PEER_TAB];
   int n_blocks[PEER_TAB];
   float *buf[PEER_TAB];
+  // peer-mapped halos (see "peer links" below): pack stores straight into the neighbour's receive buffer and the last
+  // workgroup raises sig (a flag in the neighbour's memory) to seq; add waits for its own flag to reach seq.  null: none
+  int *sig[PEER_TAB];
+  int *cnt[PEER_TAB];
+  int seq;
 };
 struct GhostTab {
   int n;
@@ -1653,20 +1658,66 @@ __device__ __forceinline__ int tab_peer(const Tab &t, int wg) {
   while (p + 1 < t.n && wg >= t.wg_off[p + 1]) ++p;
   return p;
 }
+// ---- peer links: flags and data in fine-grained memory of the RECEIVING rank, mapped into the sender with HIP IPC ----------
+// Producer: every thread fences its stores at system scope, the workgroup counts itself done, the last one to do so stores
+// the flag with release semantics.  Consumer: one thread per workgroup polls the flag (acquire, system scope) with a
+// wall-clock bound, so that a lost signal fails the run (counters[10]) instead of hanging the GPU.
+constexpr long long LINK_TIMEOUT_TICKS = 20ll * 100000000ll;    // wall_clock64() ticks at 100 MHz: 20 s in a substep,
+constexpr long long LINK_HANDSHAKE_TICKS = 3ll * 100000000ll;   // 3 s in the set-up handshake (failure = fall back to send/recv)
+__device__ __forceinline__ void link_signal(int *cnt, int n_wg, int *flag, int seq) {
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == n_wg - 1) {
+      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+__device__ __forceinline__ void link_wait(const int *flag, int seq, int *err, long long ticks = LINK_TIMEOUT_TICKS) {
+  if (threadIdx.x == 0) {
+    long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > ticks) { *err = 1; break; }
+    }
+  }
+  __syncthreads();
+  (void)__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);  // every thread orders its reads after the flag
+}
+// handshake at link set-up: `n` pattern words through the link's data area, checked on the other side (rccl_link_setup)
+__device__ __forceinline__ unsigned link_pattern(int seq, int i) { return (unsigned)i * 2654435761u ^ ((unsigned)seq * 0x9E3779B9u); }
+__global__ void k_link_ping(unsigned *data, int n, int *cnt, int *flag, int seq) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) data[i] = link_pattern(seq, i);
+  link_signal(cnt, gridDim.x, flag, seq);
+}
+__global__ void k_link_check(const unsigned *data, int n, const int *flag, int seq, int *counters) {
+  link_wait(flag, seq, counters + 10, LINK_HANDSHAKE_TICKS);
+  int bad = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) bad += data[i] != link_pattern(seq, i);
+  if (bad) atomicAdd(counters + 11, bad);
+}
+
+__global__ void k_link_verdict(int *counters) { counters[12] = (counters[10] != 0 || counters[11] != 0) ? 1 : 0; }
+
 __global__ void k_halo_pack(HaloTab tb, GridPtrs g) {
   int p = tab_peer(tb, blockIdx.x);
   int t = ((int)blockIdx.x - tb.wg_off[p]) * blockDim.x + threadIdx.x;
   int CH = tb.with_mov ? 8 : 4;
-  if (t >= tb.n_blocks[p] * CH * 64) return;
-  int l = t & 63, ch = (t >> 6) % CH, i = t / (CH * 64);
-  int blk = tb.blocks[p][i];
-  tb.buf[p][t] = ch < 4 ? g.mv[((size_t)blk * GCH_MV + ch) * 64 + l] : g.mov[((size_t)blk * GCH_MOV + (ch - 4)) * 64 + l];
+  if (t < tb.n_blocks[p] * CH * 64) {
+    int l = t & 63, ch = (t >> 6) % CH, i = t / (CH * 64);
+    int blk = tb.blocks[p][i];
+    tb.buf[p][t] = ch < 4 ? g.mv[((size_t)blk * GCH_MV + ch) * 64 + l] : g.mov[((size_t)blk * GCH_MOV + (ch - 4)) * 64 + l];
+  }
+  if (tb.sig[p]) link_signal(tb.cnt[p], tb.wg_off[p + 1] - tb.wg_off[p], tb.sig[p], tb.seq);
 }
 // a block can be shared with more than one peer (slabs thinner than two blocks): atomic adds
 __global__ void k_halo_add(HaloTab tb, GridPtrs g) {
   int p = tab_peer(tb, blockIdx.x);
   int t = ((int)blockIdx.x - tb.wg_off[p]) * blockDim.x + threadIdx.x;
   int CH = tb.with_mov ? 8 : 4;
+  if (tb.sig[p]) link_wait(tb.sig[p], tb.seq, g.counters + 10);
   if (t >= tb.n_blocks[p] * CH * 64) return;
   int l = t & 63, ch = (t >> 6) % CH, i = t / (CH * 64);
   int blk = tb.blocks[p][i];
@@ -1761,6 +1812,10 @@ struct DistPeer {
   int n_send_p = 0, n_recv_p = 0, n_send_e = 0, n_recv_e = 0;
   const int *send_p = nullptr, *recv_p = nullptr, *send_e = nullptr, *recv_e = nullptr;
   float *ghost_send = nullptr, *ghost_recv = nullptr;
+  // peer link (in-library loop only): this rank's receive arena and the neighbour's, mapped; see rccl_link_setup
+  float *link_local = nullptr, *link_remote = nullptr;
+  int link_cap = 0;
+  int *link_cnt = nullptr;
 };
 
 struct Rccl {  // entry points resolved with dlsym: libmpmhip.so itself does not link librccl
@@ -1808,12 +1863,22 @@ struct RcclPeer {  // one neighbour rank: static ghost lists + per-re-sort share
   int *blocks = nullptr, *flag = nullptr, *index = nullptr;
   int n_blocks = 0, cap_blocks = 0;
   float *halo_send = nullptr, *halo_recv = nullptr;
+  // peer link: arena = [flag parity 0 | flag parity 1 | data parity 0 | data parity 1], flags 64 B apart, data from word 32,
+  // link_cap blocks x 8 channels x 64 nodes per parity.  link_local is fine-grained memory of this rank that the
+  // neighbour writes; link_remote is the neighbour's arena for this rank (hipIpcOpenMemHandle)
+  float *link_local = nullptr, *link_remote = nullptr;
+  int link_cap = 0;
+  int *link_cnt = nullptr;
+  unsigned char *hbuf = nullptr;  // device staging of the two IPC handles (mine at 0, theirs at 64)
 };
+constexpr int LINK_DATA0 = 32, LINK_FLAG_STRIDE = 16;
 
 struct FastState {
   Rccl rccl;
   std::vector<RcclPeer> rpeers;
   unsigned char *map_all = nullptr;  // [world][nblocks] active-block byte maps
+  bool link_want = true, link_decided = false, link_on = false;  // peer-mapped halos: asked for / decided collectively / in use
+  int halo_seq = 0;                  // substeps exchanged so far (+ handshake rounds): flag value and buffer parity
   Dims d{};
   bool dist = false;  // multi-GPU: re-sorts only on request (all ranks re-sort together)
   bool dist_keep_cur = false;  // re-sort inside mpmhip_rccl_steps: the caller's mesh pointers are valid
@@ -2252,6 +2317,10 @@ int fast_init(mpmhip_ctx *c) {
 void fast_destroy(mpmhip_ctx *c) {
   FastState *f = c->fast;
   if (!f) return;
+  for (auto &p : f->rpeers) {
+    if (p.link_remote) (void)hipIpcCloseMemHandle(p.link_remote);
+    if (p.link_local) (void)hipFree(p.link_local);
+  }
   if (f->rccl.comm) (void)f->rccl.CommDestroy(f->rccl.comm);
   for (void *p : f->allocs) (void)hipFree(p);
   if (f->h_pin) (void)hipHostFree(f->h_pin);
@@ -2589,6 +2658,9 @@ int fast_dist_set_peers(mpmhip_ctx *c, int n, const mpmhip_dist_peer *peers) {
   return MPMHIP_OK;
 }
 
+static inline bool peer_linked(const FastState *f, const DistPeer &p) {
+  return f->link_on && p.link_remote && p.n_blocks <= p.link_cap;
+}
 // halo (send = true: pack into halo_send, false: add halo_recv) for all peers, PEER_TAB per launch
 static void launch_halo(mpmhip_ctx *c, bool send) {
   FastState *f = c->fast;
@@ -2601,8 +2673,16 @@ static void launch_halo(mpmhip_ctx *c, bool send) {
       if (!p.n_blocks) continue;
       int k = tb.n++;
       tb.blocks[k] = p.blocks; tb.n_blocks[k] = p.n_blocks; tb.buf[k] = send ? p.halo_send : p.halo_recv;
+      if (peer_linked(f, p)) {  // store into / read from the receive arena of this pair instead, flag in the same memory
+        float *arena = send ? p.link_remote : p.link_local;
+        int par = f->halo_seq & 1;
+        tb.buf[k] = arena + LINK_DATA0 + (size_t)par * p.link_cap * 8 * 64;
+        tb.sig[k] = (int *)arena + par * LINK_FLAG_STRIDE;
+        tb.cnt[k] = p.link_cnt;
+      }
       tb.wg_off[k + 1] = tb.wg_off[k] + (int)nblk((size_t)p.n_blocks * CH * 64);
     }
+    tb.seq = f->halo_seq;
     if (!tb.n) continue;
     if (send) hipLaunchKernelGGL(k_halo_pack, (unsigned)tb.wg_off[tb.n], TPB, 0, c->stream, tb, f->g);
     else hipLaunchKernelGGL(k_halo_add, (unsigned)tb.wg_off[tb.n], TPB, 0, c->stream, tb, f->g);
@@ -2682,6 +2762,8 @@ int fast_rccl_init(mpmhip_ctx *c, int rank, int world, const char id[128]) {
   f->rccl.rank = rank;
   f->rccl.world = world;
   f->dist = true;
+  const char *hm = getenv("MPMHIP_DIST_HALO");  // "rccl": keep the halos on ncclSend/ncclRecv; default: peer-mapped buffers
+  f->link_want = !(hm && !strcmp(hm, "rccl"));
   int rc;
   if ((rc = dalloc(c, &f->map_all, (size_t)world * f->nblocks))) return rc;
   return MPMHIP_OK;
@@ -2724,6 +2806,96 @@ int fast_rccl_set_ghosts(mpmhip_ctx *c, int n, const int32_t *ranks, const int32
   return MPMHIP_OK;
 }
 
+// Peer-mapped halo buffers.  At the first collective re-sort every pair of ranks that shares grid blocks allocates a
+// fine-grained receive arena each, swaps the HIP IPC handles (64 bytes through ncclSend/ncclRecv), maps the other side's
+// arena and pushes four rounds of a test pattern through both buffer parities with the same signal / wait primitives the
+// substep uses.  The outcome is max-reduced over all ranks: only if every link of every rank works do the halos go
+// through the links (k_halo_pack stores into the neighbour's memory and raises its flag, k_halo_add waits for the
+// flag: no RCCL kernel in the substep); otherwise every rank stays on ncclSend/ncclRecv.  Pairs that start sharing
+// blocks only later, or share more than link_cap of them, use send/recv for that interval (both sides see the same count).
+static int rccl_link_setup(mpmhip_ctx *c) {
+  FastState *f = c->fast;
+  Rccl &r = f->rccl;
+  hipStream_t s = c->stream;
+  int rc, bad = 0;
+  f->link_decided = true;
+  std::vector<hipIpcMemHandle_t> mine(f->rpeers.size()), theirs(f->rpeers.size());
+  for (size_t i = 0; i < f->rpeers.size(); ++i) {
+    RcclPeer &p = f->rpeers[i];
+    memset(&mine[i], 0, sizeof(hipIpcMemHandle_t));
+    if (!p.n_blocks) continue;
+    if ((rc = dalloc(c, &p.link_cnt, 1))) return rc;
+    if ((rc = dalloc(c, &p.hbuf, 128))) return rc;
+    p.link_cap = std::max(4 * p.n_blocks, 1024);
+    size_t bytes = ((size_t)LINK_DATA0 + 2 * (size_t)p.link_cap * 8 * 64) * sizeof(float);
+    if (hipExtMallocWithFlags((void **)&p.link_local, bytes, hipDeviceMallocFinegrained) != hipSuccess) { p.link_local = nullptr; bad = 1; continue; }
+    if (hipMemsetAsync(p.link_local, 0, bytes, s) != hipSuccess || hipIpcGetMemHandle(&mine[i], p.link_local) != hipSuccess) {
+      memset(&mine[i], 0, sizeof(hipIpcMemHandle_t));
+      bad = 1;
+    }
+  }
+  (void)hipGetLastError();
+  for (size_t i = 0; i < f->rpeers.size(); ++i)
+    if (f->rpeers[i].n_blocks) MPM_HIP_CHECK(c, hipMemcpyAsync(f->rpeers[i].hbuf, &mine[i], 64, hipMemcpyHostToDevice, s));
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handle size");
+  MPM_NCCL_CHECK(c, r, r.GroupStart());
+  for (auto &p : f->rpeers) {
+    if (!p.n_blocks) continue;
+    MPM_NCCL_CHECK(c, r, r.Send(p.hbuf, 64, ncclUint8, p.rank, r.comm, s));
+    MPM_NCCL_CHECK(c, r, r.Recv(p.hbuf + 64, 64, ncclUint8, p.rank, r.comm, s));
+  }
+  MPM_NCCL_CHECK(c, r, r.GroupEnd());
+  for (size_t i = 0; i < f->rpeers.size(); ++i)
+    if (f->rpeers[i].n_blocks) MPM_HIP_CHECK(c, hipMemcpyAsync(&theirs[i], f->rpeers[i].hbuf + 64, 64, hipMemcpyDeviceToHost, s));
+  MPM_HIP_CHECK(c, hipStreamSynchronize(s));
+  for (size_t i = 0; i < f->rpeers.size(); ++i) {
+    RcclPeer &p = f->rpeers[i];
+    if (!p.n_blocks) continue;
+    static const hipIpcMemHandle_t none{};
+    if (!memcmp(&theirs[i], &none, 64) ||
+        hipIpcOpenMemHandle((void **)&p.link_remote, theirs[i], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+      p.link_remote = nullptr;
+      bad = 1;
+    }
+  }
+  (void)hipGetLastError();
+  const char *fault = getenv("MPMHIP_LINK_FAULT");  // tests: this rank pretends its links failed
+  if (fault && *fault && atoi(fault) == r.rank) bad = 1;
+  // agree before the handshake: a rank without its links would leave its neighbours waiting for pings
+  int *vote = f->g.counters + 12;
+  MPM_HIP_CHECK(c, hipMemcpyAsync(vote, &bad, sizeof(int), hipMemcpyHostToDevice, s));
+  MPM_NCCL_CHECK(c, r, r.AllReduce(vote, vote + 1, 1, ncclInt32, ncclMax, r.comm, s));
+  MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 28, vote + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+  MPM_HIP_CHECK(c, hipStreamSynchronize(s));
+  if (f->h_pin[28] == 0) {
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + 10, 0, 2 * sizeof(int), s));
+    for (int round = 0; round < 4; ++round) {
+      int seq = ++f->halo_seq, par = seq & 1;
+      for (auto &p : f->rpeers) {
+        if (!p.link_remote) continue;
+        int n = (int)std::min<size_t>((size_t)p.link_cap * 8 * 64, (size_t)1 << 16);
+        hipLaunchKernelGGL(k_link_ping, 16, TPB, 0, s, (unsigned *)p.link_remote + LINK_DATA0 + (size_t)par * p.link_cap * 8 * 64, n,
+                           p.link_cnt, (int *)p.link_remote + par * LINK_FLAG_STRIDE, seq);
+      }
+      for (auto &p : f->rpeers) {
+        if (!p.link_remote) continue;
+        int n = (int)std::min<size_t>((size_t)p.link_cap * 8 * 64, (size_t)1 << 16);
+        hipLaunchKernelGGL(k_link_check, 16, TPB, 0, s, (const unsigned *)p.link_local + LINK_DATA0 + (size_t)par * p.link_cap * 8 * 64, n,
+                           (const int *)p.link_local + par * LINK_FLAG_STRIDE, seq, f->g.counters);
+      }
+    }
+    hipLaunchKernelGGL(k_link_verdict, 1, 1, 0, s, f->g.counters);
+    MPM_NCCL_CHECK(c, r, r.AllReduce(vote, vote + 1, 1, ncclInt32, ncclMax, r.comm, s));
+    MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 28, vote + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    MPM_HIP_CHECK(c, hipStreamSynchronize(s));
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + 10, 0, 2 * sizeof(int), s));
+  }
+  f->link_on = f->h_pin[28] == 0;
+  if (getenv("MPMHIP_VERBOSE"))
+    fprintf(stderr, "[mpmhip] rank %d: halo transport %s\n", r.rank, f->link_on ? "peer-mapped buffers" : "ncclSend/ncclRecv");
+  return MPMHIP_OK;
+}
+
 static int rccl_rebin(mpmhip_ctx *c) {
   FastState *f = c->fast;
   Rccl &r = f->rccl;
@@ -2753,6 +2925,12 @@ static int rccl_rebin(mpmhip_ctx *c) {
     f->peers.push_back(q);
   }
   (void)CH;
+  if (f->link_want && !f->link_decided && (rc = rccl_link_setup(c))) return rc;
+  for (size_t i = 0; i < f->peers.size(); ++i) {
+    const RcclPeer &p = f->rpeers[i];
+    DistPeer &q = f->peers[i];
+    q.link_local = p.link_local; q.link_remote = p.link_remote; q.link_cap = p.link_cap; q.link_cnt = p.link_cnt;
+  }
   return MPMHIP_OK;
 }
 
@@ -2761,16 +2939,18 @@ static int rccl_exchange(mpmhip_ctx *c, bool halo) {
   FastState *f = c->fast;
   Rccl &r = f->rccl;
   int CH = c->movers.empty() ? 4 : 8;
-  MPM_NCCL_CHECK(c, r, r.GroupStart());
+  bool open = false;
   for (size_t i = 0; i < f->peers.size(); ++i) {
     const DistPeer &p = f->peers[i];
     int peer = f->rpeers[i].rank;
+    if (halo && peer_linked(f, p)) continue;  // went through the pair's link (k_halo_pack / k_halo_add)
     size_t ns = halo ? (size_t)p.n_blocks * CH * 64 : (size_t)6 * p.n_send_p + 3 * p.n_send_e;
     size_t nr = halo ? (size_t)p.n_blocks * CH * 64 : (size_t)6 * p.n_recv_p + 3 * p.n_recv_e;
+    if ((ns || nr) && !open) { MPM_NCCL_CHECK(c, r, r.GroupStart()); open = true; }
     if (ns) MPM_NCCL_CHECK(c, r, r.Send(halo ? p.halo_send : p.ghost_send, ns, ncclFloat, peer, r.comm, c->stream));
     if (nr) MPM_NCCL_CHECK(c, r, r.Recv(halo ? p.halo_recv : p.ghost_recv, nr, ncclFloat, peer, r.comm, c->stream));
   }
-  MPM_NCCL_CHECK(c, r, r.GroupEnd());
+  if (open) MPM_NCCL_CHECK(c, r, r.GroupEnd());
   return MPMHIP_OK;
 }
 
@@ -2817,6 +2997,7 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
         f->dflag_pending = false;
       }
     }
+    f->halo_seq += 1;
     if ((rc = fast_dist_phase(c, 0, a))) return rc;
     {
       ScopedPhase ph(c, "halo_exchange");  // (profiling only: the ncclSend/ncclRecv group between the pack and the add kernel)
@@ -2836,8 +3017,14 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
       f->dflag_check_at = idx + 1 + DIST_LAG;
     }
   }
+  if (f->link_on) {  // a wait that ran into its wall-clock bound computed with an incomplete halo: fail the call
+    MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 29, f->g.counters + 10, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (f->h_pin[29]) return fail(c, MPMHIP_ERR_HIP, "rccl_steps: a peer-mapped halo never arrived (flag wait timed out)");
+  }
   return MPMHIP_OK;
 }
+int fast_dist_halo_transport(const mpmhip_ctx *c) { return c->fast->link_on ? 1 : 0; }
 
 // the drift flag of this rank (set by the kernels when a particle is about to leave its tile margin); synchronous
 int fast_dist_drift_flag(mpmhip_ctx *c, int32_t *out) {

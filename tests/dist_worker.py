@@ -99,7 +99,13 @@ def main():
         st = ss.sim.solver.stats()
         ok &= st["n_dropped"] == 0
         n_resorts = ss.resorts if ss.transport == "torch" else st["rebins"]
-        print(f"dist[{scene_name}] rank {rank}: {n_resorts} collective re-sorts in {steps} substeps ({ss.transport})", flush=True)
+        halo = ""
+        if ss.transport == "rccl":
+            import ctypes
+            t = ctypes.c_int32(-1)
+            ss.sim.solver._call("mpmhip_dist_halo_transport", ctypes.byref(t))
+            halo = ", halos: " + ("peer-mapped" if t.value == 1 else "send/recv")
+        print(f"dist[{scene_name}] rank {rank}: {n_resorts} collective re-sorts in {steps} substeps ({ss.transport}{halo})", flush=True)
         got = mdist.gather_positions(ss)
         parts = [None] * world
         dist.gather_object(got, parts if rank == 0 else None, dst=0)

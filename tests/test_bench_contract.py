@@ -79,3 +79,13 @@ def test_bench_gpus_n_without_a_launcher():
     assert o["roofline"]["bound"] == "hbm" and 0 < o["roofline"]["frac"] < 1 and o["kernels_mode"].startswith("fused-loop, rank 0")
     assert o["exchange"]["transport"] in ("torch", "rccl") and o["exchange"]["halo_bytes_per_substep_sent_by_rank0"] > 0
     assert o["config"]["exchange"] == o["exchange"]["transport"]
+    # the in-library loop (what a multi-GPU node runs), its RCCL entry points bound to the shared-memory stand-in
+    sys.path.insert(0, os.path.join(ROOT, "tests", "mock_rccl"))
+    from build import build as build_mock
+    r = subprocess.run(base, cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env=dict(env, MPMHIP_DIST_BACKEND="gloo", OMP_NUM_THREADS="1", MPMHIP_DIST_TRANSPORT="rccl", MPMHIP_RCCL_LIB=build_mock()))
+    assert r.returncode == 0, r.stderr[-3000:]
+    o = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    _check(o, n_gpus=2, with_cpu=False)
+    assert o["exchange"]["transport"] == "rccl" and o["exchange"]["halo"].startswith("peer-mapped")
+    assert 0 < o["roofline"]["frac"] < 1

@@ -123,19 +123,24 @@ def _mock_rccl_env(**kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("halo", ["peer", "rccl"])
 @pytest.mark.parametrize("world,scene,steps,rebin,ghost_g2p", [
     (2, "garment", 60, 8, 1), (2, "garment", 40, 8, 0), (2, "sheet", 100, 8, 1), (3, "sheet", 60, 8, 1), (3, "demo", 60, 8, 1),
     (2, "demo", 30, 8, 0), (2, "cube", 30, 8, 1), (2, "fastcube", 200, 0, 1), (2, "sheet", 60, 0, 1), (2, "demohold", 60, 8, 1)])
-def test_in_library_loop_with_several_ranks(world, scene, steps, rebin, ghost_g2p):
+def test_in_library_loop_with_several_ranks(world, scene, steps, rebin, ghost_g2p, halo):
     """`mpmhip_rccl_steps` -- the loop bench.py --gpus N runs -- with 2 and 3 ranks on ONE GPU: the library binds RCCL by
     dlsym, and MPMHIP_RCCL_LIB points it at a stand-in that moves the same messages through shared memory (real RCCL
     refuses two ranks on one device).  Covers what a one-GPU box otherwise never executes: the all-gather of the block
     maps, the shared-block lists, the halo send/recv group (sizes checked pairwise by the stand-in), ghost
     re-synchronisation at collective re-sorts, the all-reduced drift flag (rebin 0), staged release.  Result: the single
-    context's trajectory."""
+    context's trajectory.
+    halo = "peer": the halos go through peer-mapped buffers (HIP IPC between the processes, flags in the receiver's
+    fine-grained memory, handshake at set-up); "rccl": through the send/recv groups."""
     import re
-    out = _launch(world, "gpu", scene, steps, extra_env=_mock_rccl_env(MPMHIP_TEST_REBIN=rebin, MPMHIP_DIST_GHOST_G2P=ghost_g2p))
-    assert "max rel dx" in out and "(rccl)" in out
+    out = _launch(world, "gpu", scene, steps, extra_env=_mock_rccl_env(MPMHIP_TEST_REBIN=rebin, MPMHIP_DIST_GHOST_G2P=ghost_g2p,
+                                                                        MPMHIP_DIST_HALO=halo, MPMHIP_VERBOSE=1))
+    assert "max rel dx" in out and "(rccl, halos: " in out
+    assert out.count("halos: peer-mapped" if halo == "peer" else "halos: send/recv") == world, out[-2000:]
     n = [int(x) for x in re.findall(r"rank \d+: (\d+) collective re-sorts", out)]
     assert len(n) == world and len(set(n)) == 1          # every rank took the same decisions
     if rebin == 0:
@@ -143,10 +148,18 @@ def test_in_library_loop_with_several_ranks(world, scene, steps, rebin, ghost_g2
 
 
 @pytest.mark.gpu
+def test_peer_link_failure_on_one_rank_sends_every_rank_back_to_send_recv():
+    """The decision for peer-mapped halos is collective: rank 1 reports that its links failed (MPMHIP_LINK_FAULT), and
+    all three ranks keep their halos on the send/recv groups -- with the same result."""
+    out = _launch(3, "gpu", "sheet", 40, extra_env=_mock_rccl_env(MPMHIP_DIST_HALO="peer", MPMHIP_LINK_FAULT=1))
+    assert "max rel dx" in out and out.count("halos: send/recv") == 3, out[-2000:]
+
+
+@pytest.mark.gpu
 def test_in_library_loop_migration_over_the_stand_in():
     import re
     out = _launch(2, "gpu", "crossing", 150, extra_env=_mock_rccl_env(MPMHIP_TEST_MIGRATE=0.1, MPMHIP_TEST_RUN_CHUNK=30))
-    assert "max rel dx" in out and "(rccl)" in out
+    assert "max rel dx" in out and "(rccl, halos: peer-mapped)" in out
     n = [int(x) for x in re.findall(r"rank \d+: (\d+) re-partitions", out)]
     assert len(n) == 2 and n[0] == n[1] and n[0] >= 1
 
