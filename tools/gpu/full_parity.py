@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """North-star parity protocol at FULL size: the HIP fast path against the CPU oracle (OpenMP build, all
 host threads) on the same inputs, N substeps, positions / velocities / cloth directions at checkpoints, and the substep
-at which 1e-4 is first exceeded.      python tools/gpu/full_parity.py <scene> [n_substeps]
+at which 1e-4 is first exceeded.      python tools/gpu/full_parity.py <scene>[@gamma0] [n_substeps]
 Writes gpurun_out/full_parity_<scene>.json."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -11,7 +11,10 @@ from oracle.scene_adapter import oracle_from_scene, run_scene
 
 name = sys.argv[1] if len(sys.argv) > 1 else "sheet-500k"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-sc = scenes.REGISTRY[name]()
+gamma0 = name.endswith("@gamma0")   # the same scene without the shear-friction term (no R22 = 1 discontinuity, mpm_utils.py:196-204)
+sc = scenes.REGISTRY[name.split("@")[0]]()
+if gamma0:
+    sc.gamma = 0.0
 cores = os.cpu_count() or 1
 o = oracle_from_scene(sc, omp=True, n_threads=cores)
 a = harness.build_solver(sc, "cuda:0", mode="fast")
