@@ -2713,9 +2713,15 @@ int fast_dist_phase(mpmhip_ctx *c, int phase, const StepArgs &a) {
   if (phase == 0) {
     f->dist_args = a;
     if ((rc = step_phase_a(c, a))) return rc;
-    launch_halo(c, true);
+    {
+      ScopedPhase ph(c, "halo_pack");  // (profiling only) with peer links: the stores into the neighbour's memory + its flag
+      launch_halo(c, true);
+    }
   } else if (phase == 1) {
-    launch_halo(c, false);
+    {
+      ScopedPhase ph(c, "halo_add");   // (profiling only) with peer links: includes the wait for the neighbour's flag
+      launch_halo(c, false);
+    }
     if ((rc = step_phase_b(c, f->dist_args))) return rc;
     if (!f->ghost_g2p) launch_ghosts(c, true);
   } else {

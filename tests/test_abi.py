@@ -92,3 +92,20 @@ def test_product_never_imports_the_oracle():
                 assert "liboracle" not in txt and "mpm_oracle" not in txt, f
                 if f.endswith(".py"):
                     assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
+
+
+def test_rccl_stand_in_exports_what_the_library_binds():
+    """tests/mock_rccl (test infrastructure for the multi-rank GPU tests) must offer every RCCL entry point that
+    csrc/fast.hip resolves with dlsym -- a new binding without a stand-in would make those tests fall back silently."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "mpmavatar_amd", "csrc", "fast.hip")).read()
+    bound = set(re.findall(r'sym\("(nccl\w+)"\)', src))
+    assert len(bound) == 10, bound
+    sys.path.insert(0, os.path.join(root, "tests", "mock_rccl"))
+    from build import build as build_mock
+    out = subprocess.run(["nm", "-D", "--defined-only", build_mock()], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (nccl\w+)", out))
+    assert bound <= exported, bound - exported
