@@ -154,10 +154,24 @@ class MaterialFD:
 
     def train_one_step(self) -> dict:
         if len(self.variants) != len(DELTAS):
-            raise RuntimeError("train_one_step needs all four variants here; with variant_slice() gather the losses "
-                               "of the other ranks and call apply_losses()")
+            raise RuntimeError("train_one_step needs all four variants here; with variant_slice() use train_one_step_sharded()")
         p = self.torch_param
         return self.apply_losses(self.losses(p["D"].item(), p["E"].item(), p["H"].item()))
+
+    def train_one_step_sharded(self, group=None) -> dict:
+        """The same step with the four simulations spread over the ranks of a ``torch.distributed`` group (construct
+        every rank's MaterialFD with ``variants=variant_slice(rank, world)``): the runs are independent, the only
+        exchange is an all-gather of the four losses, after which every rank applies the identical Adam update -- so the
+        parameters stay bit-identical on all ranks without a broadcast.  1, 2 or 4 ranks."""
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if list(self.variants) != list(variant_slice(rank, world)):
+            raise RuntimeError(f"rank {rank} of {world} must hold variants {list(variant_slice(rank, world))}, not {self.variants}")
+        p = self.torch_param
+        mine = self.losses(p["D"].item(), p["E"].item(), p["H"].item())
+        parts = [None] * world
+        dist.all_gather_object(parts, [float(x) for x in mine], group=group)
+        return self.apply_losses([x for part in parts for x in part])
 
     def close(self):
         if self.pool is not None:
