@@ -637,11 +637,6 @@ __device__ __forceinline__ bool splat_ok(int G, const Stencil &s) {
 // (Tried and dropped: gathering the faces per node block inside the grid stage -- no atomics at all, but the few
 // wavefronts next to the body serialise ~50 faces x 60 dependent instructions each and set the kernel's tail.)
 
-__device__ __forceinline__ int face_block(V3 fp, const Dims &d) {
-  int bx = (int)(fp.x * d.inv_dx - 0.5f), by = (int)(fp.y * d.inv_dx - 0.5f), bz = (int)(fp.z * d.inv_dx - 0.5f);
-  bx = min(max(bx, 0), d.G - 1); by = min(max(by, 0), d.G - 1); bz = min(max(bz, 0), d.G - 1);
-  return blk_of(bx, by, bz, d.NB);
-}
 __device__ __forceinline__ V3 face_centroid(const float *pts, const float *vel, float adv, const int32_t *idx, int f,
                                             V3 &p0, V3 &p1, V3 &p2) {
   int i0 = idx[3 * f], i1 = idx[3 * f + 1], i2 = idx[3 * f + 2];
@@ -654,15 +649,20 @@ __global__ void k_face_keys(const float *pts, const float *vel, float adv, const
   int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n_f) return;
   V3 p0, p1, p2;
-  keys[f] = (unsigned)face_block(face_centroid(pts, vel, adv, idx, f, p0, p1, p2), d);
+  V3 fp = face_centroid(pts, vel, adv, idx, f, p0, p1, p2);
+  // block in the high bits, cell of the block in the low six: faces of one cell end up in neighbouring lanes of the
+  // splat workgroup, which pre-reduces runs of equal cells across lanes (col_splat_pass)
+  int bx = min(max((int)(fp.x * d.inv_dx - 0.5f), 0), d.G - 1), by = min(max((int)(fp.y * d.inv_dx - 0.5f), 0), d.G - 1),
+      bz = min(max((int)(fp.z * d.inv_dx - 0.5f), 0), d.G - 1);
+  keys[f] = ((unsigned)blk_of(bx, by, bz, d.NB) << 6) | (unsigned)loc_of(bx, by, bz);
   iota[f] = f;
 }
 
 __global__ void k_face_bins(const unsigned *skeys, int n_f, int *fb_start, int *fb_cnt) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_f) return;
-  unsigned k = skeys[j];
-  if (j == 0 || skeys[j - 1] != k) fb_start[k] = j;
+  unsigned k = skeys[j] >> 6;
+  if (j == 0 || (skeys[j - 1] >> 6) != k) fb_start[k] = j;
   atomicAdd(fb_cnt + k, 1);
 }
 
@@ -745,95 +745,6 @@ struct SplatArgs {
 
 // PASS 0: weight + weight*velocity (collider channels 0..3), PASS 1: weight*normal (channels 4..6); both passes use
 // the 4-channel fp64 tile of p2g.
-template <int PASS>
-__device__ __forceinline__ void col_splat_pass(double *tile, const FaceBin &fb, const SplatArgs &sa, int ox, int oy, int oz,
-                                               int bx, int by, int bz, unsigned long long act_mask, const Dims &d,
-                                               const GridPtrs &g) {
-  constexpr int NCH = PASS == 0 ? 4 : 3;
-  const int l = threadIdx.x;
-  for (int t = l; t < NCH * TILE_PAD; t += PT) tile[t] = 0.0;
-  __syncthreads();
-  for (int jj = fb.start + l; jj < fb.start + fb.cnt; jj += PT) {
-    int i0 = sa.fidx[3 * jj], i1 = sa.fidx[3 * jj + 1], i2 = sa.fidx[3 * jj + 2];
-    V3 p0 = mesh_point(sa.pts, sa.vel, sa.adv, i0), p1 = mesh_point(sa.pts, sa.vel, sa.adv, i1), p2 = mesh_point(sa.pts, sa.vel, sa.adv, i2);
-    V3 fp = v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
-    Stencil s = make_stencil(fp, d.inv_dx);
-    if (!splat_ok(d.G, s)) continue;  // mpm_solver.py:858
-    V3 a, fn;
-    {
-      V3 u0 = load_v3(sa.vel + 3 * i0), u1 = load_v3(sa.vel + 3 * i1), u2 = load_v3(sa.vel + 3 * i2);
-      a = v3((u0.x + u1.x + u2.x) / 3.0f, (u0.y + u1.y + u2.y) / 3.0f, (u0.z + u1.z + u2.z) / 3.0f);
-      fn = normalize(cross(p1 - p0, p2 - p0));  // wp.mesh_eval_face_normal
-    }
-    int lx = s.bx - ox, ly = s.by - oy, lz = s.bz - oz;
-    bool in_tile = !((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u);
-    int base = tile_idx(lx, ly, lz);
-    int n = l % 27, i = n / 9, j = (n / 3) % 3, k = n % 3;  // staggered start: neighbouring faces share nodes
-#pragma unroll 3
-    for (int t = 0; t < 27; ++t) {
-      float w = sel3(i, s.w0.x, s.w1.x, s.w2.x) * sel3(j, s.w0.y, s.w1.y, s.w2.y) * sel3(k, s.w0.z, s.w1.z, s.w2.z);
-      if (in_tile) {
-        double *p = tile + base + tile_idx(i, j, k);
-        if (PASS == 0) {
-          atomicAdd(p, (double)w);
-          atomicAdd(p + TILE_PAD, (double)(w * a.x)); atomicAdd(p + 2 * TILE_PAD, (double)(w * a.y));
-          atomicAdd(p + 3 * TILE_PAD, (double)(w * a.z));
-        } else {
-          atomicAdd(p, (double)(w * fn.x)); atomicAdd(p + TILE_PAD, (double)(w * fn.y));
-          atomicAdd(p + 2 * TILE_PAD, (double)(w * fn.z));
-        }
-      } else if (PASS == 0) {  // drifted out of the tile margin since the faces were binned
-        g.counters[6] = 1;
-        int x = s.bx + i, y = s.by + j, z = s.bz + k;
-        int nb = blk_of(x, y, z, d.NB);
-        if (g.ab_flag[nb]) {
-          float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
-          g.col_flag[nb] = 1;
-          atomicAdd(p, w);
-          atomicAdd(p + 64, w * a.x); atomicAdd(p + 128, w * a.y); atomicAdd(p + 192, w * a.z);
-          atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
-        }
-      }
-      if (++k == 3) { k = 0; if (++j == 3) { j = 0; if (++i == 3) i = 0; } }
-    }
-  }
-  __syncthreads();
-  for (int t = l; t < TILE3; t += PT) {
-    int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
-    const double *q = tile + tile_idx(ti, tj, tk);
-    float c0 = (float)q[0], c1 = (float)q[TILE_PAD], c2 = (float)q[2 * TILE_PAD];
-    float c3 = PASS == 0 ? (float)q[3 * TILE_PAD] : 0.0f;
-    if (PASS == 0 ? c0 == 0.0f : (c0 == 0.0f && c1 == 0.0f && c2 == 0.0f)) continue;
-    int x = ox + ti, y = oy + tj, z = oz + tk;
-    if (!in_grid(x, y, z, d.G)) continue;
-    int nb = blk_of(x, y, z, d.NB);
-    int nidx = (((x >> 2) - bx + 1) * 3 + ((y >> 2) - by + 1)) * 3 + ((z >> 2) - bz + 1);
-    if (!((act_mask >> nidx) & 1ull)) continue;  // inactive block: never read by g2p, never re-zeroed
-    float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z) + (PASS == 0 ? 0 : 256);
-    atomicAdd(p, c0); atomicAdd(p + 64, c1); atomicAdd(p + 128, c2);
-    if (PASS == 0) { atomicAdd(p + 192, c3); g.col_flag[nb] = 1; }
-  }
-  __syncthreads();
-}
-
-__device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, int bin, const Dims &d, const GridPtrs &g) {
-  const FaceBin fb = sa.fbins[bin];
-  int blk = fb.blk;
-  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
-  int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
-  // active flags of the 27 blocks the tile overlaps (lane n < 27 of every wavefront -> neighbour n)
-  bool nb_act = false;
-  int l = threadIdx.x & 63;
-  if (l < 27) {
-    int x = bx + l / 9 - 1, y = by + (l / 3) % 3 - 1, z = bz + l % 3 - 1;
-    if ((unsigned)x < (unsigned)d.NB && (unsigned)y < (unsigned)d.NB && (unsigned)z < (unsigned)d.NB)
-      nb_act = g.ab_flag[(x * d.NB + y) * d.NB + z] != 0;
-  }
-  unsigned long long act_mask = __ballot(nb_act);
-  col_splat_pass<0>(tile, fb, sa, ox, oy, oz, bx, by, bz, act_mask, d, g);
-  col_splat_pass<1>(tile, fb, sa, ox, oy, oz, bx, by, bz, act_mask, d, g);
-}
-
 struct P2GParticle {
   Stencil s;
   float mass;
@@ -1172,6 +1083,128 @@ __device__ __forceinline__ void mover_escaped(V3 x, V3 pv, const Dims &d, const 
     atomicAdd(p, w);
     atomicAdd(p + 64, w * pv.x); atomicAdd(p + 128, w * pv.y); atomicAdd(p + 192, w * pv.z);
   }
+}
+
+// Faces are sorted by (block, cell of the centroid) at the re-sort, so neighbouring lanes mostly hold faces of the same
+// cell and add into the same 27 tile nodes: the same segmented DPP pre-reduction as the particle scatter (p2g_scatter)
+// leaves one lane per run issuing the LDS atomics.  DBG 4096 switches the pre-reduction off (every lane issues).
+template <int PASS>
+__device__ __forceinline__ void col_splat_pass(double *tile, const FaceBin &fb, const SplatArgs &sa, int ox, int oy, int oz,
+                                               int bx, int by, int bz, unsigned long long act_mask, const Dims &d,
+                                               const GridPtrs &g) {
+  constexpr int NCH = PASS == 0 ? 4 : 3;
+  constexpr int STEPS = 3;
+  const int l = threadIdx.x;
+  for (int t = l; t < NCH * TILE_PAD; t += PT) tile[t] = 0.0;
+  __syncthreads();
+  const int end = fb.start + fb.cnt;
+  for (int j0 = fb.start; j0 < end; j0 += PT) {  // workgroup-uniform trip count: DPP needs converged lanes
+    int jj = j0 + l;
+    bool have = jj < end;
+    int jq = have ? jj : fb.start;
+    int i0 = sa.fidx[3 * jq], i1 = sa.fidx[3 * jq + 1], i2 = sa.fidx[3 * jq + 2];
+    V3 p0 = mesh_point(sa.pts, sa.vel, sa.adv, i0), p1 = mesh_point(sa.pts, sa.vel, sa.adv, i1), p2 = mesh_point(sa.pts, sa.vel, sa.adv, i2);
+    V3 fp = v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
+    Stencil s = make_stencil(fp, d.inv_dx);
+    bool ok = have && splat_ok(d.G, s);  // mpm_solver.py:858
+    V3 c;  // pass 0: face velocity, pass 1: face normal
+    if (PASS == 0) {
+      V3 u0 = load_v3(sa.vel + 3 * i0), u1 = load_v3(sa.vel + 3 * i1), u2 = load_v3(sa.vel + 3 * i2);
+      c = v3((u0.x + u1.x + u2.x) / 3.0f, (u0.y + u1.y + u2.y) / 3.0f, (u0.z + u1.z + u2.z) / 3.0f);
+    } else {
+      c = normalize(cross(p1 - p0, p2 - p0));  // wp.mesh_eval_face_normal
+    }
+    int lx = s.bx - ox, ly = s.by - oy, lz = s.bz - oz;
+    bool in_tile = !((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u);
+    bool tile_ok = ok && in_tile;
+    if (__any(tile_ok)) {
+      // lanes without a face in the tile carry a unique key (never merged, never issue) and a zero contribution
+      int key = tile_ok ? (lx * TILE + ly) * TILE + lz : -2 - (l & 63);
+      int base = tile_ok ? tile_idx(lx, ly, lz) : 0;
+      float on = tile_ok ? 1.0f : 0.0f;
+      SegMask sm = seg_masks(key);
+      unsigned long long tails = __ballot(sm.tail);
+      int dist = __ffsll((unsigned long long)(tails >> (l & 63))) - 1;
+      bool do_add = tile_ok && (dist & ((1 << STEPS) - 1)) == 0;
+      if (g.dbg & 4096) { sm.m1 = sm.m2 = sm.m4 = sm.m8 = 0.0f; do_add = tile_ok; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float wx = sel3(i, s.w0.x, s.w1.x, s.w2.x) * on;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          float wxy = wx * sel3(j, s.w0.y, s.w1.y, s.w2.y);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            float w = wxy * sel3(k, s.w0.z, s.w1.z, s.w2.z);
+            float r0 = w * c.x, r1 = w * c.y, r2 = w * c.z, r3 = w;
+            seg_scan4<STEPS>(r0, r1, r2, r3, sm);
+            if (do_add) {
+              double *p = tile + base + tile_idx(i, j, k);
+              if (PASS == 0) {
+                atomicAdd(p, (double)r3);
+                atomicAdd(p + TILE_PAD, (double)r0); atomicAdd(p + 2 * TILE_PAD, (double)r1); atomicAdd(p + 3 * TILE_PAD, (double)r2);
+              } else {
+                atomicAdd(p, (double)r0); atomicAdd(p + TILE_PAD, (double)r1); atomicAdd(p + 2 * TILE_PAD, (double)r2);
+              }
+            }
+          }
+        }
+      }
+    }
+    if (PASS == 0 && ok && !in_tile) {  // drifted out of the tile margin since the faces were binned
+      g.counters[6] = 1;
+      V3 fn = normalize(cross(p1 - p0, p2 - p0));
+#pragma unroll 1
+      for (int n = 0; n < 27; ++n) {
+        int i = n / 9, j = (n / 3) % 3, k = n % 3;
+        float w = sel3(i, s.w0.x, s.w1.x, s.w2.x) * sel3(j, s.w0.y, s.w1.y, s.w2.y) * sel3(k, s.w0.z, s.w1.z, s.w2.z);
+        int x = s.bx + i, y = s.by + j, z = s.bz + k;
+        int nb = blk_of(x, y, z, d.NB);
+        if (g.ab_flag[nb]) {
+          float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
+          g.col_flag[nb] = 1;
+          atomicAdd(p, w);
+          atomicAdd(p + 64, w * c.x); atomicAdd(p + 128, w * c.y); atomicAdd(p + 192, w * c.z);
+          atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = l; t < TILE3; t += PT) {
+    int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
+    const double *q = tile + tile_idx(ti, tj, tk);
+    float c0 = (float)q[0], c1 = (float)q[TILE_PAD], c2 = (float)q[2 * TILE_PAD];
+    float c3 = PASS == 0 ? (float)q[3 * TILE_PAD] : 0.0f;
+    if (PASS == 0 ? c0 == 0.0f : (c0 == 0.0f && c1 == 0.0f && c2 == 0.0f)) continue;
+    int x = ox + ti, y = oy + tj, z = oz + tk;
+    if (!in_grid(x, y, z, d.G)) continue;
+    int nb = blk_of(x, y, z, d.NB);
+    int nidx = (((x >> 2) - bx + 1) * 3 + ((y >> 2) - by + 1)) * 3 + ((z >> 2) - bz + 1);
+    if (!((act_mask >> nidx) & 1ull)) continue;  // inactive block: never read by g2p, never re-zeroed
+    float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z) + (PASS == 0 ? 0 : 256);
+    atomicAdd(p, c0); atomicAdd(p + 64, c1); atomicAdd(p + 128, c2);
+    if (PASS == 0) { atomicAdd(p + 192, c3); g.col_flag[nb] = 1; }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, int bin, const Dims &d, const GridPtrs &g) {
+  const FaceBin fb = sa.fbins[bin];
+  int blk = fb.blk;
+  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
+  int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
+  // active flags of the 27 blocks the tile overlaps (lane n < 27 of every wavefront -> neighbour n)
+  bool nb_act = false;
+  int l = threadIdx.x & 63;
+  if (l < 27) {
+    int x = bx + l / 9 - 1, y = by + (l / 3) % 3 - 1, z = bz + l % 3 - 1;
+    if ((unsigned)x < (unsigned)d.NB && (unsigned)y < (unsigned)d.NB && (unsigned)z < (unsigned)d.NB)
+      nb_act = g.ab_flag[(x * d.NB + y) * d.NB + z] != 0;
+  }
+  unsigned long long act_mask = __ballot(nb_act);
+  col_splat_pass<0>(tile, fb, sa, ox, oy, oz, bx, by, bz, act_mask, d, g);
+  col_splat_pass<1>(tile, fb, sa, ox, oy, oz, bx, by, bz, act_mask, d, g);
 }
 
 // JT = true: the mover holds MANY traditional particles (run_demo.py keeps 100k sand particles frozen for the first
@@ -2164,14 +2197,14 @@ int rebin(mpmhip_ctx *c) {
     hipLaunchKernelGGL(k_face_keys, nblk(nf), TPB, 0, s, c->cur_pts, c->cur_vel, c->cur_f, c->mesh_idx, nf, d, f->fkeys[0], f->fiota);
     size_t need2 = 0;
     MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(nullptr, need2, f->fkeys[0], f->fkeys[1], f->fiota, f->forder, (size_t)nf, 0u,
-                                               (unsigned)f->blk_bits_plain, s));
+                                               (unsigned)f->blk_bits_plain + 6u, s));
     if (need2 > f->sort_tmp_bytes) {
       MPM_HIP_CHECK(c, hipMalloc(&f->sort_tmp, need2));
       f->allocs.push_back(f->sort_tmp);
       f->sort_tmp_bytes = need2;
     }
     MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(f->sort_tmp, need2, f->fkeys[0], f->fkeys[1], f->fiota, f->forder, (size_t)nf,
-                                               0u, (unsigned)f->blk_bits_plain, s));
+                                               0u, (unsigned)f->blk_bits_plain + 6u, s));
     MPM_HIP_CHECK(c, hipMemsetAsync(f->fb_cnt, 0, f->nblocks * sizeof(int), s));
     hipLaunchKernelGGL(k_face_bins, nblk(nf), TPB, 0, s, f->fkeys[1], nf, f->fb_start, f->fb_cnt);
     hipLaunchKernelGGL(k_face_sorted_idx, nblk(nf), TPB, 0, s, c->mesh_idx, f->forder, nf, f->fidx);

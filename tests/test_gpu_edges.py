@@ -168,8 +168,9 @@ def test_high_valence_vertex(mode, oracle_lib):
     o, sim = _pair(sc, 60, mode)
     assert rel(sim.state.particle_x.cpu().numpy(), o.x) < 1e-5
     # 60 elements released from rest, every one of them on the return mapping's R22 = 1 discontinuity and nothing to average
-    # over: measured 8e-3 relative to the 0.05 m/s the fan has reached (4e-4 m/s; test_gpu_parity docstring)
-    assert rel(sim.state.particle_v.cpu().numpy(), o.v) < 2e-2
+    # over: 8e-3 ... 3.1e-2 relative to the 0.05 m/s the fan has reached (4e-4 ... 1.6e-3 m/s; test_gpu_parity docstring).
+    # The spread is run to run: the baseline back end scatters with global fp32 atomics, whose order is not fixed.
+    assert rel(sim.state.particle_v.cpu().numpy(), o.v) < 6e-2
     o1, sim1 = _pair(sc, 1, mode)
     assert rel(sim1.state.particle_v.cpu().numpy(), o1.v) < 1e-4
 
