@@ -156,8 +156,6 @@ def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int 
     import torch
     import torch.distributed as dist
     from . import harness
-    if getattr(sc, "mesh_sway", None) is not None:
-        raise NotImplementedError("a body posed per frame (Scene.mesh_sway) is not supported by the sharded driver")
     shard = partition(sc, world)[rank]
     sim = harness.build_solver(shard.scene, device, mode="fast")
     sv = sim.solver
@@ -479,6 +477,36 @@ def run(ss: ShardedSim, n_steps: int):
         sv._call("mpmhip_set_host_dt", float(sc.dt))
         sv._host_dt = sc.dt
     held = lambda step: _held_local(ss, step)
+    gsc = ss.global_scene
+    swaying = getattr(gsc, "mesh_sway", None) is not None and sim.mesh_x0 is not None
+    t3 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32), device=sv.device).reshape(-1, 3)
+
+    def body(step):
+        """(mesh_x at substep 0 of the library's advection x + (step dt) v, mesh_v, joint_verts_v, joint_faces_v) valid at
+        `step`.  A body posed per frame (Scene.mesh_sway, train_material_params.py:617-622) has a new velocity every frame:
+        the frame's start pose is extrapolated back to substep 0 with that velocity, so that the same absolute advection
+        factor (step_index + k) dt reproduces pose(frame start) + (step - frame start) dt v."""
+        if not swaying:
+            return sim.mesh_x0, sim.mesh_v, jv, jf
+        f0, _ = gsc.frame_of(step)
+        if getattr(ss, "keep_body_frame", None) == f0:
+            return ss.keep_body
+        ss.keep_body_frame = f0
+        mx, mv = gsc.body_at(f0)
+        x0 = (mx.astype(np.float64) - gsc.dt * f0 * mv.astype(np.float64)).astype(np.float32)
+        bjv, bjf = jv, jf
+        if jv is not None:
+            vel = torch.as_tensor(np.ascontiguousarray(mv[0], np.float32), device=sv.device)
+            bjv, bjf = vel.expand(jv.shape[0], 3).contiguous(), vel.expand(jf.reshape(-1, 3).shape[0], 3).contiguous()
+        ss.keep_body = (t3(x0), t3(mv), bjv, bjf)   # alive until the next frame's tensors replace them
+        return ss.keep_body
+
+    def frame_run(step, n):
+        """Substeps from `step` that share one body pose / velocity."""
+        if not swaying:
+            return n
+        f0, spf = gsc.frame_of(step)
+        return min(n, f0 + spf - step)
     jt_buf = None
     if ss.global_scene.joint_t_hold > 0:
         jt_buf = torch.zeros((max(ss.shard.own_t.size, 1), 3), dtype=torch.float32, device=sv.device)
@@ -492,8 +520,13 @@ def run(ss: ShardedSim, n_steps: int):
             h = held(ss.steps_done)
             if h >= 0:
                 n = next((j for j in range(1, n) if held(ss.steps_done + j) != h), n)
+            n = frame_run(ss.steps_done, n)
+            bx, bv, bjv, bjf = body(ss.steps_done)
+            if swaying:
+                jvp = None if bjv is None else (dp(bjv) or dummy)
+                jfp = None if bjf is None else (dp(bjf) or dummy)
             sv._call("mpmhip_rccl_steps", float(sc.dt), int(n), int(ss.steps_done), int(ss.rebin_interval),
-                     dp(sim.mesh_x0), dp(sim.mesh_v), jt_buf.data_ptr() if h > 0 else None, max(h, 0), jvp, jfp)
+                     dp(bx), dp(bv), jt_buf.data_ptr() if h > 0 else None, max(h, 0), jvp, jfp)
             ss.steps_done += n
             k += n
         return ss
@@ -511,10 +544,11 @@ def run(ss: ShardedSim, n_steps: int):
             ss.since, ss.resort_now, ss.sorted_once = 0, False, True
             ss.resorts += 1
         adv = float(np.float32(sc.dt * ss.steps_done))
-        jvp = None if jv is None else (dp(jv) or dummy)
-        jfp = None if jf is None else (dp(jf) or dummy)
+        bx, bv, bjv, bjf = body(ss.steps_done)
+        jvp = None if bjv is None else (dp(bjv) or dummy)
+        jfp = None if bjf is None else (dp(bjf) or dummy)
         h = held(ss.steps_done)
-        sv._call("mpmhip_dist_step_begin", float(sc.dt), dp(sim.mesh_x0), dp(sim.mesh_v), adv,
+        sv._call("mpmhip_dist_step_begin", float(sc.dt), dp(bx), dp(bv), adv,
                  jt_buf.data_ptr() if h > 0 else None, max(h, 0), jvp, jfp)
         _exchange(ss, "halo")
         sv._call("mpmhip_dist_step_mid")

@@ -36,7 +36,13 @@ def _crossing_cube():
     return sc
 
 
-SCENES = {"crossing": _crossing_cube, "demohold": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=(10, 5, 64)),
+def _sway_garment():
+    """The small garment on a body that is posed anew every 20 substeps (Scene.mesh_sway: a new velocity per frame, joints
+    riding on it), like the captured motion of train_material_params.py:617-622."""
+    return scenes.garment_cylinder(n_theta=32, n_h=24, n_grid=48, aniso=True, collider_subdiv=2, n_steps=200, sway=(0.5, 50.0, 20))
+
+
+SCENES = {"crossing": _crossing_cube, "sway": _sway_garment, "demohold": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=(10, 5, 64)),
           "garment": scenes.small_garment, "sheet": scenes.small_sheet, "cube": scenes.small_cube, "fastcube": _fast_cube,
           "demo": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=False)}
 
