@@ -26,6 +26,8 @@
 
 #include <rccl/rccl.h>
 
+#include <thread>
+
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -351,6 +353,8 @@ struct GridPtrs {
   int *col_flag;    // [block] 1 = the body-face splat may have written this block's collider channels this substep
   int *m_flag;      // [block] 1 = p2g (or a halo sum) may have written this block's mass / momentum this substep
   int *counters;    // [0] particles outside their tile margin, [1] dropped contributions (inactive block)
+  int *host_sig;    // host-mapped pinned memory: [0] the drift flag (counters[6]) as of this launch, [1] step_id -- written by
+  int step_id;      // one thread of every k_p2g launch, read by the host without any stream operation (fast_step)
   int dbg;          // MPMHIP_DBG bitmask (perf experiments only, results are wrong): 1 skip p2g flush, 2 skip the p2g
                     // scatter, 8 / 16 skip vertex-force / stress loads, 128 skip the LDS atomics only, 256 skip the splat workgroups, 2048 skip the clearing workgroups; 64 (results stay
                     // right) runs the stand-alone element finalize every substep instead of fusing it into the stress kernel
@@ -1216,11 +1220,18 @@ __global__ __launch_bounds__(PT) void k_p2g(Bufs b, VAdj va, const ChunkRec *rec
   __shared__ double tile[4 * TILE_PAD];
   __shared__ int esc[CHUNK];
   __shared__ int esc_n;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && g.host_sig) {
+    // progress + drift flag for the host (plain stores into pinned host memory instead of a copy + event every few
+    // substeps: on the stream those cost a blit kernel and ~10-20 us of idle queue each).  Everything before this launch
+    // has completed, so step_id - 1 substeps are done and counters[6] holds every warning they raised.
+    __hip_atomic_store(g.host_sig, g.counters[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(g.host_sig + 1, g.step_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if ((int)blockIdx.x < sa.n_extra) {  // extra workgroups first: they are the long-latency ones
     int e = blockIdx.x;
     if (g.dbg & 256) return;
-    if (e < sa.n_fbins) col_splat_wg(tile, sa, e, d, g);
-    else if (e < sa.n_fbins + sa.n_mov_wg) mover_splat_wg(b, sa.js, e - sa.n_fbins, d, g);
+    if (e < sa.n_fbins) { if (!(g.dbg & 8192)) col_splat_wg(tile, sa, e, d, g); }   // (8192 / 16384: ablation switches)
+    else if (e < sa.n_fbins + sa.n_mov_wg) { if (!(g.dbg & 16384)) mover_splat_wg(b, sa.js, e - sa.n_fbins, d, g); }
     return;
   }
   if ((int)blockIdx.x >= sa.z_first) {  // ... and the clearing workgroups last: they fill the tail of the launch
@@ -1991,6 +2002,9 @@ struct FastState {
   int steps_since_rebin = 0;
   hipEvent_t ev_flag = nullptr;
   bool flag_pending = false;
+  volatile int *h_sig = nullptr;  // pinned, host-mapped: [0] drift flag, [1] last step_id seen by a p2g launch (GridPtrs::host_sig)
+  int sig_seq = 0;                // step_id of the last p2g launch issued
+  int host_lead = 6;              // substeps the host may run ahead of the GPU (MPMHIP_HOST_LEAD)
   bool have_order = false;
   int64_t rebins = 0;
   int rebin_interval = 32;
@@ -2283,6 +2297,10 @@ int rebin(mpmhip_ctx *c) {
   MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + 6, 0, sizeof(int), s));
   f->h_pin[24] = 0;
   f->flag_pending = false;
+  if (f->g.host_sig) {  // every launch that could still store the old flag has to be gone before the host clears its copy
+    MPM_HIP_CHECK(c, hipStreamSynchronize(s));
+    f->h_sig[0] = 0;
+  }
   f->g.ab_flag = f->ab_flag;
   f->steps_since_rebin = 0;
   f->rebins += 1;
@@ -2344,6 +2362,15 @@ int fast_init(mpmhip_ctx *c) {
   if (const char *e = getenv("MPMHIP_FUSE_TRAD")) f->fuse_trad = atoi(e) != 0;
   MPM_HIP_CHECK(c, hipHostMalloc((void **)&f->h_pin, 64 * sizeof(int), hipHostMallocDefault));
   MPM_HIP_CHECK(c, hipEventCreateWithFlags(&f->ev_flag, hipEventDisableTiming));
+  {
+    int *hs = nullptr, *ds = nullptr;
+    MPM_HIP_CHECK(c, hipHostMalloc((void **)&hs, 16 * sizeof(int), hipHostMallocMapped));
+    memset(hs, 0, 16 * sizeof(int));
+    MPM_HIP_CHECK(c, hipHostGetDevicePointer((void **)&ds, hs, 0));
+    f->h_sig = hs;
+    f->g.host_sig = getenv("MPMHIP_FLAG_COPY") ? nullptr : ds;  // MPMHIP_FLAG_COPY=1: the former copy + event poll (A/B)
+    if (const char *e = getenv("MPMHIP_HOST_LEAD")) f->host_lead = std::max(1, atoi(e));
+  }
   return MPMHIP_OK;
 }
 
@@ -2357,6 +2384,7 @@ void fast_destroy(mpmhip_ctx *c) {
   if (f->rccl.comm) (void)f->rccl.CommDestroy(f->rccl.comm);
   for (void *p : f->allocs) (void)hipFree(p);
   if (f->h_pin) (void)hipHostFree(f->h_pin);
+  if (f->h_sig) (void)hipHostFree((void *)f->h_sig);
   f->h_ranges.release(); f->h_plist.release(); f->h_chunks.release(); f->h_chunks_g.release();
   if (f->ev_flag) (void)hipEventDestroy(f->ev_flag);
   delete f;
@@ -2456,7 +2484,21 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     // the next copy is issued the host waits for the previous one, which also bounds how far the host may run
     // ahead of the GPU (<= 16 substeps) -- otherwise a fused mpmhip_steps(n) would have enqueued all n substeps
     // long before the first flag arrives.
-    if (f->flag_pending && (f->steps_since_rebin & f->poll_mask) == 0) {
+    if (f->g.host_sig) {
+      // the kernels report progress and the flag into pinned host memory (k_p2g): no stream operation here, and the flag
+      // is looked at before every substep.  The host keeps host_lead substeps queued (enough to hide its launch latency)
+      // and no more, so a warning takes effect within host_lead + 1 substeps (the copy + event scheme: 8-16) -- well
+      // inside the kernels' 20-substep look-ahead.
+      for (long spins = 0; f->sig_seq - f->h_sig[1] > f->host_lead; ++spins) {
+        if ((spins & 0x3ff) == 0x3ff) {
+          hipError_t e = hipStreamQuery(s);
+          if (e == hipSuccess) break;  // nothing in flight (e.g. the progress word was never written): do not wait for it
+          if (e != hipErrorNotReady) MPM_HIP_CHECK(c, e);
+        }
+        std::this_thread::yield();
+      }
+      if (f->h_sig[0] && f->adaptive_rebin) f->steps_since_rebin = 1 << 30;
+    } else if (f->flag_pending && (f->steps_since_rebin & f->poll_mask) == 0) {
       MPM_HIP_CHECK(c, hipEventSynchronize(f->ev_flag));
       f->flag_pending = false;
       if (f->h_pin[24] && f->adaptive_rebin) f->steps_since_rebin = 1 << 30;
@@ -2518,6 +2560,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   }
   sa.n_extra = (sa.n_fbins + sa.n_mov_wg + 7) & ~7;
   sa.z_first = sa.n_extra + (int)xcd_grid(f->n_chunks);
+  f->g.step_id = ++f->sig_seq;
   if (d.n_e || (d.n_t && !trad_fused)) {  // (no empty event bracket when the stress update rides in p2g)
     ScopedPhase ph(c, "compute_stress_from_F_trial");
     if (d.n_e) {
@@ -2622,7 +2665,7 @@ static int step_phase_c(mpmhip_ctx *c, const StepArgs &a) {
     flush_elements(c);
   }
   f->steps_since_rebin += 1;
-  if (!f->dist && !f->flag_pending && (f->steps_since_rebin & f->poll_mask) == 0) {
+  if (!f->dist && !f->g.host_sig && !f->flag_pending && (f->steps_since_rebin & f->poll_mask) == 0) {
     MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 24, f->g.counters + 6, sizeof(int), hipMemcpyDeviceToHost, s));
     MPM_HIP_CHECK(c, hipEventRecord(f->ev_flag, s));
     f->flag_pending = true;
