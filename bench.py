@@ -96,12 +96,14 @@ def cpu_baseline(sc, budget_s=20.0):
 def main():
     # stdout carries exactly one line (the JSON result); everything else this process prints -- the shim repeats the
     # reference's "Particles initialized from torch data." messages -- goes to stderr
-    real_stdout = sys.stdout
+    # ... and so does what native libraries write to file descriptor 1 behind Python's back (RCCL prints a version banner
+    # through C stdio when the first communicator is created; it would come out after the JSON line at exit)
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     sys.stdout = sys.stderr
-    try:
-        _main(real_stdout)
-    finally:
-        sys.stdout = real_stdout
+    _main(real_stdout)
+    real_stdout.flush()
 
 
 def _main(out_stream):
