@@ -188,8 +188,7 @@ def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int 
             print(f"[mpmavatar_amd.dist] rank {rank}: in-library RCCL transport unavailable ({e}); using torch.distributed", flush=True)
             ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=dev if ss.backend == "nccl" else "cpu")
-        if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ss.transport = "rccl" if int(flag.item()) == 1 else "torch"
     return ss
 
@@ -292,10 +291,13 @@ def slab_leavers(ss: "ShardedSim") -> float:
     xs = np.concatenate([x[ne_l:ne_l + sh.own_t.size], x[ne_l + sh.own_t.size:ne_l + sh.own_t.size + sh.own_v.size]])
     lo = -np.inf if sh.rank == 0 else sh.cuts[sh.rank - 1]
     hi = np.inf if sh.rank == sh.world - 1 else sh.cuts[sh.rank]
-    t = torch.tensor([float(((xs < lo) | (xs >= hi)).sum()), float(xs.size)], dtype=torch.float64)
-    if sh.world > 1:
-        dist.all_reduce(t)
-    return float(t[0] / max(t[1], 1.0))
+    # (collectives run at world size 1 too: a tensor on the wrong device for the backend -- NCCL takes no CPU tensors --
+    # then fails on a one-GPU test box and not first on the node)
+    t = torch.tensor([float(((xs < lo) | (xs >= hi)).sum()), float(xs.size)], dtype=torch.float64,
+                     device="cpu" if ss.backend == "gloo" else ss.sim.solver.device)
+    dist.all_reduce(t)
+    t = t.cpu()
+    return float(t[0] / max(float(t[1]), 1.0))
 
 
 def repartition(ss: "ShardedSim") -> "ShardedSim":
@@ -340,8 +342,7 @@ def _init_rccl(ss: ShardedSim, rank: int, world: int):
     if rank == 0:
         L.check(sv._lib, None, sv._lib.mpmhip_rccl_unique_id(uid))
     box = [bytes(uid.raw) if rank == 0 else None]
-    if world > 1:
-        dist.broadcast_object_list(box, src=0)
+    dist.broadcast_object_list(box, src=0)
     uid = (C.c_char * 128).from_buffer_copy(box[0])
     sv._call("mpmhip_rccl_init", rank, world, uid)
     peers = sorted(set(sh.send_p) | set(sh.recv_p))
@@ -450,8 +451,7 @@ def _any_rank_drifting(ss: ShardedSim) -> bool:
     flag = C.c_int32(0)
     sv._call("mpmhip_dist_drift_flag", C.byref(flag))
     t = torch.tensor([flag.value], dtype=torch.int32, device="cpu" if ss.backend == "gloo" else sv.device)
-    if ss.shard.world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return bool(int(t.item()))
 
 

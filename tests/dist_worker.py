@@ -49,7 +49,12 @@ SCENES = {"crossing": _crossing_cube, "sway": _sway_garment, "demohold": lambda:
 
 def main():
     mode, scene_name, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    dist.init_process_group("gloo")
+    backend = os.environ.get("MPMHIP_TEST_BACKEND", "gloo")   # "nccl": what bench.py --gpus N uses on a node
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+        dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     sc = SCENES[scene_name]()
     ok = True
@@ -102,6 +107,14 @@ def main():
             ok &= ss.transport == "rccl"   # the test asked for the in-library loop: falling back silently is a failure
         if float(os.environ.get("MPMHIP_TEST_MIGRATE", "0")) > 0:
             print(f"dist[{scene_name}] rank {rank}: {ss.migrations} re-partitions", flush=True)
+        # every collective of the driver once more, whatever the world size: with the NCCL backend a tensor on the wrong
+        # device fails here, on the one-GPU box, and not first on a multi-GPU node
+        frac = mdist.slab_leavers(ss)
+        ok &= 0.0 <= frac <= 1.0
+        glob = mdist.gather_global_state(ss)
+        ok &= glob["particle_x"].shape == (sc.n_particles, 3) and bool(np.isfinite(glob["particle_x"]).all())
+        ok &= mdist._any_rank_drifting(ss) in (True, False)
+        ok &= len(mdist._all_gather_maps(ss)) == world
         st = ss.sim.solver.stats()
         ok &= st["n_dropped"] == 0
         n_resorts = ss.resorts if ss.transport == "torch" else st["rebins"]
@@ -128,7 +141,7 @@ def main():
             scale = max(float(np.abs(x).max()), 1e-3)
             print(f"dist[{scene_name}] world={world} steps={steps} max rel dx vs single context = {err / scale:.3e}", flush=True)
             ok &= np.isfinite(err) and err / scale < 1e-5
-    flag = torch.tensor([1 if ok else 0])
+    flag = torch.tensor([1 if ok else 0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()
     sys.exit(0 if flag.item() == 1 else 1)

@@ -96,6 +96,22 @@ def test_in_library_rccl_transport_single_rank_adaptive():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["rccl", "torch"])
+def test_nccl_backend_world_one_runs_every_collective(transport):
+    """torch.distributed with the NCCL (= RCCL) backend, as bench.py --gpus N initialises it, at world size 1: every
+    collective the sharded driver issues (all-reduce of counts and flags, all-gather of block maps and of the state,
+    object broadcast) runs with device tensors.  Found this way: a float64 CPU tensor in an all-reduce that only ran for
+    world > 1."""
+    env = dict(os.environ, MPMHIP_DIST_TRANSPORT=transport, MPMHIP_TEST_BACKEND="nccl", MPMHIP_TEST_REBIN="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "gpu", "garment", "40"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "max rel dx" in r.stdout and f"({transport}" in r.stdout
+
+
+@pytest.mark.gpu
 def test_in_library_rccl_transport_single_rank():
     """World size 1 through the library's own RCCL communicator (dlopen, ncclCommInitRank, ncclAllGather of the block
     map, empty send/recv groups) -- the multi-rank send/recv itself cannot run on a one-GPU box."""
