@@ -151,7 +151,7 @@ def _mock_rccl_env(**kw):
 @pytest.mark.parametrize("world,scene,steps,rebin,ghost_g2p", [
     (2, "garment", 60, 8, 1), (2, "garment", 40, 8, 0), (2, "sheet", 100, 8, 1), (3, "sheet", 60, 8, 1), (3, "demo", 60, 8, 1),
     (2, "demo", 30, 8, 0), (2, "cube", 30, 8, 1), (2, "fastcube", 200, 0, 1), (2, "sheet", 60, 0, 1), (2, "demohold", 60, 8, 1),
-    (2, "sway", 70, 8, 1)])
+    (2, "sway", 70, 8, 1), (4, "demo", 40, 8, 1)])
 def test_in_library_loop_with_several_ranks(world, scene, steps, rebin, ghost_g2p, halo):
     """`mpmhip_rccl_steps` -- the loop bench.py --gpus N runs -- with 2 and 3 ranks on ONE GPU: the library binds RCCL by
     dlsym, and MPMHIP_RCCL_LIB points it at a stand-in that moves the same messages through shared memory (real RCCL
