@@ -26,6 +26,7 @@
 
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <thread>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -1092,90 +1093,39 @@ __device__ __forceinline__ void mover_escaped(V3 x, V3 pv, const Dims &d, const 
 // Faces are sorted by (block, cell of the centroid) at the re-sort, so neighbouring lanes mostly hold faces of the same
 // cell and add into the same 27 tile nodes: the same segmented DPP pre-reduction as the particle scatter (p2g_scatter)
 // leaves one lane per run issuing the LDS atomics.  DBG 4096 switches the pre-reduction off (every lane issues).
+// Two passes through the four-channel tile per batch of faces -- (weight, weight * velocity), then weight * normal -- with
+// the face, its stencil and the scan masks loaded / computed once for both (seven channels at once would need 43 KB of LDS:
+// three instead of five workgroups per CU for the whole launch).
 template <int PASS>
-__device__ __forceinline__ void col_splat_pass(double *tile, const FaceBin &fb, const SplatArgs &sa, int ox, int oy, int oz,
-                                               int bx, int by, int bz, unsigned long long act_mask, const Dims &d,
-                                               const GridPtrs &g) {
-  constexpr int NCH = PASS == 0 ? 4 : 3;
-  constexpr int STEPS = 3;
-  const int l = threadIdx.x;
-  for (int t = l; t < NCH * TILE_PAD; t += PT) tile[t] = 0.0;
-  __syncthreads();
-  const int end = fb.start + fb.cnt;
-  for (int j0 = fb.start; j0 < end; j0 += PT) {  // workgroup-uniform trip count: DPP needs converged lanes
-    int jj = j0 + l;
-    bool have = jj < end;
-    int jq = have ? jj : fb.start;
-    int i0 = sa.fidx[3 * jq], i1 = sa.fidx[3 * jq + 1], i2 = sa.fidx[3 * jq + 2];
-    V3 p0 = mesh_point(sa.pts, sa.vel, sa.adv, i0), p1 = mesh_point(sa.pts, sa.vel, sa.adv, i1), p2 = mesh_point(sa.pts, sa.vel, sa.adv, i2);
-    V3 fp = v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
-    Stencil s = make_stencil(fp, d.inv_dx);
-    bool ok = have && splat_ok(d.G, s);  // mpm_solver.py:858
-    V3 c;  // pass 0: face velocity, pass 1: face normal
-    if (PASS == 0) {
-      V3 u0 = load_v3(sa.vel + 3 * i0), u1 = load_v3(sa.vel + 3 * i1), u2 = load_v3(sa.vel + 3 * i2);
-      c = v3((u0.x + u1.x + u2.x) / 3.0f, (u0.y + u1.y + u2.y) / 3.0f, (u0.z + u1.z + u2.z) / 3.0f);
-    } else {
-      c = normalize(cross(p1 - p0, p2 - p0));  // wp.mesh_eval_face_normal
-    }
-    int lx = s.bx - ox, ly = s.by - oy, lz = s.bz - oz;
-    bool in_tile = !((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u);
-    bool tile_ok = ok && in_tile;
-    if (__any(tile_ok)) {
-      // lanes without a face in the tile carry a unique key (never merged, never issue) and a zero contribution
-      int key = tile_ok ? (lx * TILE + ly) * TILE + lz : -2 - (l & 63);
-      int base = tile_ok ? tile_idx(lx, ly, lz) : 0;
-      float on = tile_ok ? 1.0f : 0.0f;
-      SegMask sm = seg_masks(key);
-      unsigned long long tails = __ballot(sm.tail);
-      int dist = __ffsll((unsigned long long)(tails >> (l & 63))) - 1;
-      bool do_add = tile_ok && (dist & ((1 << STEPS) - 1)) == 0;
-      if (g.dbg & 4096) { sm.m1 = sm.m2 = sm.m4 = sm.m8 = 0.0f; do_add = tile_ok; }
+__device__ __forceinline__ void col_splat_scatter(double *tile, const Stencil &s, float on, V3 c, SegMask sm, bool do_add, int base) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        float wx = sel3(i, s.w0.x, s.w1.x, s.w2.x) * on;
+  for (int i = 0; i < 3; ++i) {
+    float wx = sel3(i, s.w0.x, s.w1.x, s.w2.x) * on;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          float wxy = wx * sel3(j, s.w0.y, s.w1.y, s.w2.y);
+    for (int j = 0; j < 3; ++j) {
+      float wxy = wx * sel3(j, s.w0.y, s.w1.y, s.w2.y);
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            float w = wxy * sel3(k, s.w0.z, s.w1.z, s.w2.z);
-            float r0 = w * c.x, r1 = w * c.y, r2 = w * c.z, r3 = w;
-            seg_scan4<STEPS>(r0, r1, r2, r3, sm);
-            if (do_add) {
-              double *p = tile + base + tile_idx(i, j, k);
-              if (PASS == 0) {
-                atomicAdd(p, (double)r3);
-                atomicAdd(p + TILE_PAD, (double)r0); atomicAdd(p + 2 * TILE_PAD, (double)r1); atomicAdd(p + 3 * TILE_PAD, (double)r2);
-              } else {
-                atomicAdd(p, (double)r0); atomicAdd(p + TILE_PAD, (double)r1); atomicAdd(p + 2 * TILE_PAD, (double)r2);
-              }
-            }
+      for (int k = 0; k < 3; ++k) {
+        float w = wxy * sel3(k, s.w0.z, s.w1.z, s.w2.z);
+        float r0 = w * c.x, r1 = w * c.y, r2 = w * c.z, r3 = w;
+        seg_scan4<3>(r0, r1, r2, r3, sm);
+        if (do_add) {
+          double *p = tile + base + tile_idx(i, j, k);
+          if (PASS == 0) {
+            atomicAdd(p, (double)r3);
+            atomicAdd(p + TILE_PAD, (double)r0); atomicAdd(p + 2 * TILE_PAD, (double)r1); atomicAdd(p + 3 * TILE_PAD, (double)r2);
+          } else {
+            atomicAdd(p, (double)r0); atomicAdd(p + TILE_PAD, (double)r1); atomicAdd(p + 2 * TILE_PAD, (double)r2);
           }
         }
       }
     }
-    if (PASS == 0 && ok && !in_tile) {  // drifted out of the tile margin since the faces were binned
-      g.counters[6] = 1;
-      V3 fn = normalize(cross(p1 - p0, p2 - p0));
-#pragma unroll 1
-      for (int n = 0; n < 27; ++n) {
-        int i = n / 9, j = (n / 3) % 3, k = n % 3;
-        float w = sel3(i, s.w0.x, s.w1.x, s.w2.x) * sel3(j, s.w0.y, s.w1.y, s.w2.y) * sel3(k, s.w0.z, s.w1.z, s.w2.z);
-        int x = s.bx + i, y = s.by + j, z = s.bz + k;
-        int nb = blk_of(x, y, z, d.NB);
-        if (g.ab_flag[nb]) {
-          float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
-          g.col_flag[nb] = 1;
-          atomicAdd(p, w);
-          atomicAdd(p + 64, w * c.x); atomicAdd(p + 128, w * c.y); atomicAdd(p + 192, w * c.z);
-          atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
-        }
-      }
-    }
   }
-  __syncthreads();
-  for (int t = l; t < TILE3; t += PT) {
+}
+template <int PASS>
+__device__ __forceinline__ void col_splat_flush(const double *tile, int ox, int oy, int oz, int bx, int by, int bz,
+                                                unsigned long long act_mask, const Dims &d, const GridPtrs &g) {
+  for (int t = threadIdx.x; t < TILE3; t += PT) {
     int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
     const double *q = tile + tile_idx(ti, tj, tk);
     float c0 = (float)q[0], c1 = (float)q[TILE_PAD], c2 = (float)q[2 * TILE_PAD];
@@ -1190,7 +1140,6 @@ __device__ __forceinline__ void col_splat_pass(double *tile, const FaceBin &fb, 
     atomicAdd(p, c0); atomicAdd(p + 64, c1); atomicAdd(p + 128, c2);
     if (PASS == 0) { atomicAdd(p + 192, c3); g.col_flag[nb] = 1; }
   }
-  __syncthreads();
 }
 
 __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, int bin, const Dims &d, const GridPtrs &g) {
@@ -1200,15 +1149,70 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
   int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
   // active flags of the 27 blocks the tile overlaps (lane n < 27 of every wavefront -> neighbour n)
   bool nb_act = false;
-  int l = threadIdx.x & 63;
-  if (l < 27) {
-    int x = bx + l / 9 - 1, y = by + (l / 3) % 3 - 1, z = bz + l % 3 - 1;
+  const int l = threadIdx.x;
+  if ((l & 63) < 27) {
+    int n = l & 63;
+    int x = bx + n / 9 - 1, y = by + (n / 3) % 3 - 1, z = bz + n % 3 - 1;
     if ((unsigned)x < (unsigned)d.NB && (unsigned)y < (unsigned)d.NB && (unsigned)z < (unsigned)d.NB)
       nb_act = g.ab_flag[(x * d.NB + y) * d.NB + z] != 0;
   }
   unsigned long long act_mask = __ballot(nb_act);
-  col_splat_pass<0>(tile, fb, sa, ox, oy, oz, bx, by, bz, act_mask, d, g);
-  col_splat_pass<1>(tile, fb, sa, ox, oy, oz, bx, by, bz, act_mask, d, g);
+  const int end = fb.start + fb.cnt;
+  for (int j0 = fb.start; j0 < end; j0 += PT) {  // workgroup-uniform trip count: barriers and DPP need converged lanes
+    for (int t = l; t < 4 * TILE_PAD; t += PT) tile[t] = 0.0;
+    int jj = j0 + l;
+    bool have = jj < end;
+    int jq = have ? jj : fb.start;
+    int i0 = sa.fidx[3 * jq], i1 = sa.fidx[3 * jq + 1], i2 = sa.fidx[3 * jq + 2];
+    V3 p0 = mesh_point(sa.pts, sa.vel, sa.adv, i0), p1 = mesh_point(sa.pts, sa.vel, sa.adv, i1), p2 = mesh_point(sa.pts, sa.vel, sa.adv, i2);
+    V3 u0 = load_v3(sa.vel + 3 * i0), u1 = load_v3(sa.vel + 3 * i1), u2 = load_v3(sa.vel + 3 * i2);
+    V3 fp = v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
+    V3 a = v3((u0.x + u1.x + u2.x) / 3.0f, (u0.y + u1.y + u2.y) / 3.0f, (u0.z + u1.z + u2.z) / 3.0f);
+    V3 fn = normalize(cross(p1 - p0, p2 - p0));  // wp.mesh_eval_face_normal
+    Stencil s = make_stencil(fp, d.inv_dx);
+    bool ok = have && splat_ok(d.G, s);  // mpm_solver.py:858
+    int lx = s.bx - ox, ly = s.by - oy, lz = s.bz - oz;
+    bool in_tile = !((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u);
+    bool tile_ok = ok && in_tile;
+    // lanes without a face in the tile carry a unique key (never merged, never issue) and a zero contribution
+    int key = tile_ok ? (lx * TILE + ly) * TILE + lz : -2 - (l & 63);
+    int base = tile_ok ? tile_idx(lx, ly, lz) : 0;
+    float on = tile_ok ? 1.0f : 0.0f;
+    bool any = __any(tile_ok);
+    SegMask sm = seg_masks(key);
+    unsigned long long tails = __ballot(sm.tail);
+    int dist = __ffsll((unsigned long long)(tails >> (l & 63))) - 1;
+    bool do_add = tile_ok && (dist & 7) == 0;
+    if (g.dbg & 4096) { sm.m1 = sm.m2 = sm.m4 = sm.m8 = 0.0f; do_add = tile_ok; }
+    __syncthreads();
+    if (any) col_splat_scatter<0>(tile, s, on, a, sm, do_add, base);
+    if (ok && !in_tile) {  // drifted out of the tile margin since the faces were binned
+      g.counters[6] = 1;
+#pragma unroll 1
+      for (int n = 0; n < 27; ++n) {
+        int i = n / 9, j = (n / 3) % 3, k = n % 3;
+        float w = sel3(i, s.w0.x, s.w1.x, s.w2.x) * sel3(j, s.w0.y, s.w1.y, s.w2.y) * sel3(k, s.w0.z, s.w1.z, s.w2.z);
+        int x = s.bx + i, y = s.by + j, z = s.bz + k;
+        int nb = blk_of(x, y, z, d.NB);
+        if (g.ab_flag[nb]) {
+          float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
+          g.col_flag[nb] = 1;
+          atomicAdd(p, w);
+          atomicAdd(p + 64, w * a.x); atomicAdd(p + 128, w * a.y); atomicAdd(p + 192, w * a.z);
+          atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
+        }
+      }
+    }
+    __syncthreads();
+    col_splat_flush<0>(tile, ox, oy, oz, bx, by, bz, act_mask, d, g);
+    __syncthreads();
+    for (int t = l; t < 3 * TILE_PAD; t += PT) tile[t] = 0.0;
+    __syncthreads();
+    if (any) col_splat_scatter<1>(tile, s, on, fn, sm, do_add, base);
+    __syncthreads();
+    col_splat_flush<1>(tile, ox, oy, oz, bx, by, bz, act_mask, d, g);
+    __syncthreads();
+  }
 }
 
 // JT = true: the mover holds MANY traditional particles (run_demo.py keeps 100k sand particles frozen for the first
@@ -1743,6 +1747,12 @@ __global__ void k_link_check(const unsigned *data, int n, const int *flag, int s
   if (bad) atomicAdd(counters + 11, bad);
 }
 
+// the all-reduced drift flag of the sharded loop -> pinned host memory: value first, then its sequence number
+__global__ void k_post_flag(const int *value, int *host_sig, int seq) {
+  __hip_atomic_store(host_sig + 2, *value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __hip_atomic_store(host_sig + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void k_link_verdict(int *counters) { counters[12] = (counters[10] != 0 || counters[11] != 0) ? 1 : 0; }
 
 __global__ void k_halo_pack(HaloTab tb, GridPtrs g) {
@@ -1932,6 +1942,7 @@ struct FastState {
   int dist_since = 0;
   bool dist_resort = false, dflag_pending = false, rccl_sorted = false;
   int64_t dflag_check_at = 0;
+  int dflag_seq = 0;  // sequence number of the last reduction posted to host memory (k_post_flag)
   std::vector<DistPeer> peers;
   StepArgs dist_args{};
   int blk_bits = 0, key_bits = 0;  // blk_bits: packed key format kf (field widths) as the kernels take it
@@ -3053,9 +3064,23 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
     c->cur_vel = a.mesh_v ? a.mesh_v : c->mesh_vel;
     c->cur_f = (a.mesh_x && a.mesh_v) ? a.mesh_f : 0.0f;
     if (adaptive && f->dflag_pending && idx >= f->dflag_check_at) {
-      MPM_HIP_CHECK(c, hipEventSynchronize(f->ev_flag));
+      if (f->g.host_sig) {  // posted by k_post_flag: wait for THIS reduction's sequence number, then read its value
+        for (long spins = 0; f->h_sig[3] != f->dflag_seq; ++spins) {
+          if ((spins & 0x3ff) == 0x3ff) {
+            hipError_t e = hipStreamQuery(c->stream);
+            if (e == hipSuccess && f->h_sig[3] != f->dflag_seq)
+              return fail(c, MPMHIP_ERR_HIP, "rccl_steps: the reduced drift flag never reached host memory");
+            if (e != hipSuccess && e != hipErrorNotReady) MPM_HIP_CHECK(c, e);
+          }
+          std::this_thread::yield();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (f->h_sig[2]) f->dist_resort = true;
+      } else {
+        MPM_HIP_CHECK(c, hipEventSynchronize(f->ev_flag));
+        if (f->h_pin[26]) f->dist_resort = true;
+      }
       f->dflag_pending = false;
-      if (f->h_pin[26]) f->dist_resort = true;
     }
     bool due = adaptive ? (f->dist_resort || f->dist_since >= cap || !f->rccl_sorted) : (idx % cap == 0);
     if (due || c->caller_dirty) {
@@ -3075,8 +3100,8 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
       f->dist_resort = false;
       f->rccl_sorted = true;
       if (f->dflag_pending) {  // a reduction issued before this re-sort speaks about the old order: drop it (every rank does)
-        MPM_HIP_CHECK(c, hipEventSynchronize(f->ev_flag));
-        f->dflag_pending = false;
+        if (!f->g.host_sig) MPM_HIP_CHECK(c, hipEventSynchronize(f->ev_flag));
+        f->dflag_pending = false;  // (host memory: the next poll waits for a newer sequence number)
       }
     }
     f->halo_seq += 1;
@@ -3093,8 +3118,12 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
     f->dist_since += 1;
     if (adaptive && !f->dflag_pending && f->dist_since % DIST_POLL == 0) {
       MPM_NCCL_CHECK(c, f->rccl, f->rccl.AllReduce(f->g.counters + 6, f->g.counters + 7, 1, ncclInt32, ncclMax, f->rccl.comm, c->stream));
-      MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 26, f->g.counters + 7, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      MPM_HIP_CHECK(c, hipEventRecord(f->ev_flag, c->stream));
+      if (f->g.host_sig) {  // no copy + event on the stream (each costs an idle queue, see fast_step): one thread posts the result
+        hipLaunchKernelGGL(k_post_flag, 1, 1, 0, c->stream, f->g.counters + 7, f->g.host_sig, ++f->dflag_seq);
+      } else {
+        MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 26, f->g.counters + 7, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        MPM_HIP_CHECK(c, hipEventRecord(f->ev_flag, c->stream));
+      }
       f->dflag_pending = true;
       f->dflag_check_at = idx + 1 + DIST_LAG;
     }
