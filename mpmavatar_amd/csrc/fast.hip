@@ -1726,7 +1726,7 @@ __device__ __forceinline__ void link_signal(int *cnt, int n_wg, int *flag, int s
 __device__ __forceinline__ void link_wait(const int *flag, int seq, int *err, long long ticks = LINK_TIMEOUT_TICKS) {
   if (threadIdx.x == 0) {
     long long t0 = wall_clock64();
-    while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+    while ((int)((unsigned)__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - (unsigned)seq) < 0) {  // wraps
       __builtin_amdgcn_s_sleep(4);
       if (wall_clock64() - t0 > ticks) { *err = 1; break; }
     }
@@ -1932,7 +1932,8 @@ struct FastState {
   std::vector<RcclPeer> rpeers;
   unsigned char *map_all = nullptr;  // [world][nblocks] active-block byte maps
   bool link_want = true, link_decided = false, link_on = false;  // peer-mapped halos: asked for / decided collectively / in use
-  int halo_seq = 0;                  // substeps exchanged so far (+ handshake rounds): flag value and buffer parity
+  unsigned halo_seq = 0;             // substeps exchanged so far (+ handshake rounds): flag value and buffer parity (wraps: the
+                                     // kernels compare (int)(flag - seq), long trainings run billions of substeps)
   Dims d{};
   bool dist = false;  // multi-GPU: re-sorts only on request (all ranks re-sort together)
   bool dist_keep_cur = false;  // re-sort inside mpmhip_rccl_steps: the caller's mesh pointers are valid
@@ -1942,7 +1943,7 @@ struct FastState {
   int dist_since = 0;
   bool dist_resort = false, dflag_pending = false, rccl_sorted = false;
   int64_t dflag_check_at = 0;
-  int dflag_seq = 0;  // sequence number of the last reduction posted to host memory (k_post_flag)
+  unsigned dflag_seq = 0;  // sequence number of the last reduction posted to host memory (k_post_flag; wraps)
   std::vector<DistPeer> peers;
   StepArgs dist_args{};
   int blk_bits = 0, key_bits = 0;  // blk_bits: packed key format kf (field widths) as the kernels take it
@@ -2014,7 +2015,7 @@ struct FastState {
   hipEvent_t ev_flag = nullptr;
   bool flag_pending = false;
   volatile int *h_sig = nullptr;  // pinned, host-mapped: [0] drift flag, [1] last step_id seen by a p2g launch (GridPtrs::host_sig)
-  int sig_seq = 0;                // step_id of the last p2g launch issued
+  unsigned sig_seq = 0;           // step_id of the last p2g launch issued (wraps)
   int host_lead = 6;              // substeps the host may run ahead of the GPU (MPMHIP_HOST_LEAD)
   bool have_order = false;
   int64_t rebins = 0;
@@ -2500,7 +2501,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       // is looked at before every substep.  The host keeps host_lead substeps queued (enough to hide its launch latency)
       // and no more, so a warning takes effect within host_lead + 1 substeps (the copy + event scheme: 8-16) -- well
       // inside the kernels' 20-substep look-ahead.
-      for (long spins = 0; f->sig_seq - f->h_sig[1] > f->host_lead; ++spins) {
+      for (long spins = 0; (int)(f->sig_seq - (unsigned)f->h_sig[1]) > f->host_lead; ++spins) {
         if ((spins & 0x3ff) == 0x3ff) {
           hipError_t e = hipStreamQuery(s);
           if (e == hipSuccess) break;  // nothing in flight (e.g. the progress word was never written): do not wait for it
@@ -2571,7 +2572,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   }
   sa.n_extra = (sa.n_fbins + sa.n_mov_wg + 7) & ~7;
   sa.z_first = sa.n_extra + (int)xcd_grid(f->n_chunks);
-  f->g.step_id = ++f->sig_seq;
+  f->g.step_id = (int)++f->sig_seq;
   if (d.n_e || (d.n_t && !trad_fused)) {  // (no empty event bracket when the stress update rides in p2g)
     ScopedPhase ph(c, "compute_stress_from_F_trial");
     if (d.n_e) {
@@ -2762,14 +2763,14 @@ static void launch_halo(mpmhip_ctx *c, bool send) {
       tb.blocks[k] = p.blocks; tb.n_blocks[k] = p.n_blocks; tb.buf[k] = send ? p.halo_send : p.halo_recv;
       if (peer_linked(f, p)) {  // store into / read from the receive arena of this pair instead, flag in the same memory
         float *arena = send ? p.link_remote : p.link_local;
-        int par = f->halo_seq & 1;
+        int par = (int)(f->halo_seq & 1u);
         tb.buf[k] = arena + LINK_DATA0 + (size_t)par * p.link_cap * 8 * 64;
         tb.sig[k] = (int *)arena + par * LINK_FLAG_STRIDE;
         tb.cnt[k] = p.link_cnt;
       }
       tb.wg_off[k + 1] = tb.wg_off[k] + (int)nblk((size_t)p.n_blocks * CH * 64);
     }
-    tb.seq = f->halo_seq;
+    tb.seq = (int)f->halo_seq;
     if (!tb.n) continue;
     if (send) hipLaunchKernelGGL(k_halo_pack, (unsigned)tb.wg_off[tb.n], TPB, 0, c->stream, tb, f->g);
     else hipLaunchKernelGGL(k_halo_add, (unsigned)tb.wg_off[tb.n], TPB, 0, c->stream, tb, f->g);
@@ -2963,7 +2964,7 @@ static int rccl_link_setup(mpmhip_ctx *c) {
   if (f->h_pin[28] == 0) {
     MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + 10, 0, 2 * sizeof(int), s));
     for (int round = 0; round < 4; ++round) {
-      int seq = ++f->halo_seq, par = seq & 1;
+      int seq = (int)++f->halo_seq, par = seq & 1;
       for (auto &p : f->rpeers) {
         if (!p.link_remote) continue;
         int n = (int)std::min<size_t>((size_t)p.link_cap * 8 * 64, (size_t)1 << 16);
@@ -3065,10 +3066,10 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
     c->cur_f = (a.mesh_x && a.mesh_v) ? a.mesh_f : 0.0f;
     if (adaptive && f->dflag_pending && idx >= f->dflag_check_at) {
       if (f->g.host_sig) {  // posted by k_post_flag: wait for THIS reduction's sequence number, then read its value
-        for (long spins = 0; f->h_sig[3] != f->dflag_seq; ++spins) {
+        for (long spins = 0; (unsigned)f->h_sig[3] != f->dflag_seq; ++spins) {
           if ((spins & 0x3ff) == 0x3ff) {
             hipError_t e = hipStreamQuery(c->stream);
-            if (e == hipSuccess && f->h_sig[3] != f->dflag_seq)
+            if (e == hipSuccess && (unsigned)f->h_sig[3] != f->dflag_seq)
               return fail(c, MPMHIP_ERR_HIP, "rccl_steps: the reduced drift flag never reached host memory");
             if (e != hipSuccess && e != hipErrorNotReady) MPM_HIP_CHECK(c, e);
           }
@@ -3119,7 +3120,7 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
     if (adaptive && !f->dflag_pending && f->dist_since % DIST_POLL == 0) {
       MPM_NCCL_CHECK(c, f->rccl, f->rccl.AllReduce(f->g.counters + 6, f->g.counters + 7, 1, ncclInt32, ncclMax, f->rccl.comm, c->stream));
       if (f->g.host_sig) {  // no copy + event on the stream (each costs an idle queue, see fast_step): one thread posts the result
-        hipLaunchKernelGGL(k_post_flag, 1, 1, 0, c->stream, f->g.counters + 7, f->g.host_sig, ++f->dflag_seq);
+        hipLaunchKernelGGL(k_post_flag, 1, 1, 0, c->stream, f->g.counters + 7, f->g.host_sig, (int)++f->dflag_seq);
       } else {
         MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 26, f->g.counters + 7, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         MPM_HIP_CHECK(c, hipEventRecord(f->ev_flag, c->stream));
