@@ -356,6 +356,7 @@ struct GridPtrs {
   int *counters;    // [0] particles outside their tile margin, [1] dropped contributions (inactive block)
   int *host_sig;    // host-mapped pinned memory: [0] the drift flag (counters[6]) as of this launch, [1] step_id -- written by
   int step_id;      // one thread of every k_p2g launch, read by the host without any stream operation (fast_step)
+  float lookahead;  // substeps the early warning of the adaptive re-sort looks ahead (k_p2g)
   int dbg;          // MPMHIP_DBG bitmask (perf experiments only, results are wrong): 1 skip p2g flush, 2 skip the p2g
                     // scatter, 8 / 16 skip vertex-force / stress loads, 128 skip the LDS atomics only, 256 skip the splat workgroups, 2048 skip the clearing workgroups; 64 (results stay
                     // right) runs the stand-alone element finalize every substep instead of fusing it into the stress kernel
@@ -770,7 +771,11 @@ __device__ __forceinline__ P2GParticle p2g_zero(int ox, int oy, int oz, const Di
 // when the wavefront holds any element or traditional particle, the first ADJ_BATCH adjacency entries when it holds
 // any vertex (wave-uniform branches; lanes of the other class read slot 0 and are masked afterwards).  The
 // per-class `if` ladder this replaces serialised stress -> adjacency -> corner-force latencies.
-constexpr float DRIFT_LOOKAHEAD = 20.0f;  // substeps
+// substeps the early warning looks ahead.  A warning raised in p2g(n) reaches the host with p2g(n + 1) and takes effect at
+// most host_lead + 1 = 7 substeps later (fast_step), so 10 leave three in hand -- and every substep of look-ahead that is not
+// needed is margin given away: with 20 the scenes re-sorted 2.4-2.9x as often in their fast-moving phases
+// (profiles/r02_experiments.md).  The sharded loops see the all-reduced flag up to 16 + 4 substeps late and keep 20.
+constexpr float DRIFT_LOOKAHEAD = 10.0f, DRIFT_LOOKAHEAD_DIST = 20.0f;
 struct P2GRaw {
   V3 x, v;
   float mass, vol;
@@ -1260,7 +1265,7 @@ __global__ __launch_bounds__(PT) void k_p2g(Bufs b, VAdj va, const ChunkRec *rec
   if (valid) {  // early warning for the adaptive re-sort: will this particle still fit the tile DRIFT_LOOKAHEAD substeps
                 // from now (the host reads the flag with a lag of up to 16 substeps)?  The out-of-margin paths work
                 // but cost ~100 scattered global atomics per particle and substep.
-    float la = DRIFT_LOOKAHEAD * dt;
+    float la = g.lookahead * dt;
     int fx = (int)((raw.x.x + la * raw.v.x) * d.inv_dx - 0.5f) - ox, fy = (int)((raw.x.y + la * raw.v.y) * d.inv_dx - 0.5f) - oy,
         fz = (int)((raw.x.z + la * raw.v.z) * d.inv_dx - 0.5f) - oz;
     if ((unsigned)fx > 5u || (unsigned)fy > 5u || (unsigned)fz > 5u) g.counters[6] = 1;
@@ -2382,6 +2387,8 @@ int fast_init(mpmhip_ctx *c) {
     f->h_sig = hs;
     f->g.host_sig = getenv("MPMHIP_FLAG_COPY") ? nullptr : ds;  // MPMHIP_FLAG_COPY=1: the former copy + event poll (A/B)
     if (const char *e = getenv("MPMHIP_HOST_LEAD")) f->host_lead = std::max(1, atoi(e));
+    f->g.lookahead = DRIFT_LOOKAHEAD;
+    if (const char *e = getenv("MPMHIP_DRIFT_LOOKAHEAD")) f->g.lookahead = (float)atof(e);
   }
   return MPMHIP_OK;
 }
@@ -2698,6 +2705,7 @@ int fast_step(mpmhip_ctx *c, const StepArgs &a) {
 // ---- multi-GPU entry points --------------------------------------------------------------------------------
 int fast_dist_enable(mpmhip_ctx *c) {
   c->fast->dist = true;
+  if (!getenv("MPMHIP_DRIFT_LOOKAHEAD")) c->fast->g.lookahead = DRIFT_LOOKAHEAD_DIST;
   return MPMHIP_OK;
 }
 int fast_dist_set_ghost_mode(mpmhip_ctx *c, int ghosts_gather) {
@@ -2856,6 +2864,7 @@ int fast_rccl_init(mpmhip_ctx *c, int rank, int world, const char id[128]) {
   f->rccl.rank = rank;
   f->rccl.world = world;
   f->dist = true;
+  if (!getenv("MPMHIP_DRIFT_LOOKAHEAD")) f->g.lookahead = DRIFT_LOOKAHEAD_DIST;
   const char *hm = getenv("MPMHIP_DIST_HALO");  // "rccl": keep the halos on ncclSend/ncclRecv; default: peer-mapped buffers
   f->link_want = !(hm && !strcmp(hm, "rccl"));
   int rc;
