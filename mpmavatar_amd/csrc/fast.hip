@@ -1193,6 +1193,7 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
     if (any) col_splat_scatter<0>(tile, s, on, a, sm, do_add, base);
     if (ok && !in_tile) {  // drifted out of the tile margin since the faces were binned
       g.counters[6] = 1;
+      g.counters[5] = 1;  // ... which is what makes the next re-sort bin the faces again (rebin)
 #pragma unroll 1
       for (int n = 0; n < 27; ++n) {
         int i = n / 9, j = (n / 3) % 3, k = n % 3;
@@ -1235,6 +1236,7 @@ __global__ __launch_bounds__(PT) void k_p2g(Bufs b, VAdj va, const ChunkRec *rec
     // has completed, so step_id - 1 substeps are done and counters[6] holds every warning they raised.
     __hip_atomic_store(g.host_sig, g.counters[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(g.host_sig + 1, g.step_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(g.host_sig + 4, g.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // a body face left its bin's tile
   }
   if ((int)blockIdx.x < sa.n_extra) {  // extra workgroups first: they are the long-latency ones
     int e = blockIdx.x;
@@ -1965,6 +1967,8 @@ struct FastState {
   unsigned *fkeys[2] = {nullptr, nullptr};
   int *forder = nullptr, *fiota = nullptr, *fb_start = nullptr, *fb_cnt = nullptr;
   bool faces_binned = false;
+  int rebins_since_face_sort = 0;
+  bool face_flag_stale = false;
   FaceBin *fbins = nullptr;
   int *fidx = nullptr;  // [n_f][3] face vertex ids in bin order
   int cap_fbins = 0, n_fbins = 0;
@@ -2224,7 +2228,14 @@ int rebin(mpmhip_ctx *c) {
   int rc;
   const bool with_faces = !c->colliders.empty() && c->num_mesh_f;
   const int nf = c->num_mesh_f;
-  if (with_faces) {  // body faces: sort by block, per-block ranges (independent of the particle tables)
+  // The face bins survive a particle re-sort (they do not depend on the particle tables; only their compaction onto the
+  // active list below does): the ~13 launches of the face sort run when a face has actually left its bin's tile since the
+  // last one (counters[5], seen through host memory), at the latest every 16th re-sort, and always in the sharded loops.
+  bool face_sort = with_faces;
+  if (with_faces && f->faces_binned && f->g.host_sig && !f->dist && f->h_sig[4] == 0 && f->rebins_since_face_sort < 16 &&
+      !getenv("MPMHIP_FACE_SORT_ALWAYS"))
+    face_sort = false;
+  if (face_sort) {  // body faces: sort by block, per-block ranges (independent of the particle tables)
     hipLaunchKernelGGL(k_face_keys, nblk(nf), TPB, 0, s, c->cur_pts, c->cur_vel, c->cur_f, c->mesh_idx, nf, d, f->fkeys[0], f->fiota);
     size_t need2 = 0;
     MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(nullptr, need2, f->fkeys[0], f->fkeys[1], f->fiota, f->forder, (size_t)nf, 0u,
@@ -2239,6 +2250,11 @@ int rebin(mpmhip_ctx *c) {
     MPM_HIP_CHECK(c, hipMemsetAsync(f->fb_cnt, 0, f->nblocks * sizeof(int), s));
     hipLaunchKernelGGL(k_face_bins, nblk(nf), TPB, 0, s, f->fkeys[1], nf, f->fb_start, f->fb_cnt);
     hipLaunchKernelGGL(k_face_sorted_idx, nblk(nf), TPB, 0, s, c->mesh_idx, f->forder, nf, f->fidx);
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + 5, 0, sizeof(int), s));
+    f->rebins_since_face_sort = 0;
+    f->face_flag_stale = true;  // h_sig[4] is cleared after this re-sort's host wait
+  } else if (with_faces) {
+    f->rebins_since_face_sort += 1;
   }
   // Block tables, chunk records and face bins: every kernel takes its counts from the device array f->rcnt and its array
   // sizes from CAPACITIES, so the whole sequence is enqueued without a host round trip; the host reads the counts once, at
@@ -2317,6 +2333,7 @@ int rebin(mpmhip_ctx *c) {
   if (f->g.host_sig) {  // every launch that could still store the old flag has to be gone before the host clears its copy
     MPM_HIP_CHECK(c, hipStreamSynchronize(s));
     f->h_sig[0] = 0;
+    if (f->face_flag_stale) { f->h_sig[4] = 0; f->face_flag_stale = false; }
   }
   f->g.ab_flag = f->ab_flag;
   f->steps_since_rebin = 0;
