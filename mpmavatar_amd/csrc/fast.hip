@@ -602,16 +602,30 @@ __global__ __launch_bounds__(1024) void k_build_chunks(const int *plist, const i
     gh |= g > 0;
   }
   if (t == 0) any_ghost = 0;
-  sc[t] = c; sg[t] = cg;
+  // inclusive scan over the 1024 threads: inside each wavefront with shuffles, then over the 16 wavefront totals
+  // (three barriers instead of the twenty of a Hillis-Steele scan through LDS)
+  int ic = c, ig = cg;
+  const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int a = __shfl_up(ic, o), b = __shfl_up(ig, o);
+    if (lane >= o) { ic += a; ig += b; }
+  }
+  if (lane == 63) { sc[wv] = ic; sg[wv] = ig; }
   __syncthreads();
   if (gh) any_ghost = 1;
-  for (int o = 1; o < 1024; o <<= 1) {  // inclusive scan
-    int a = t >= o ? sc[t - o] : 0, b = t >= o ? sg[t - o] : 0;
-    __syncthreads();
-    sc[t] += a; sg[t] += b;
-    __syncthreads();
+  if (t < 16) {
+    int a = sc[t], b = sg[t];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      int ua = __shfl_up(a, o), ub = __shfl_up(b, o);
+      if (t >= o) { a += ua; b += ub; }
+    }
+    sc[32 + t] = a; sg[32 + t] = b;  // inclusive totals of wavefronts 0..t
   }
-  int o = sc[t] - c, og = sg[t] - cg;
+  __syncthreads();
+  if (wv > 0) { ic += sc[32 + wv - 1]; ig += sg[32 + wv - 1]; }
+  int o = ic - c, og = ig - cg;
   for (int p = p0; p < p1; ++p) {
     ChunkRec r{plist[p], 0, R(0, p), R(1, p) - R(0, p), R(2, p), R(3, p) - R(2, p), R(4, p), R(5, p) - R(4, p), 0, 0, 0, 0};
     int tot = r.ne + r.nt + r.nv;
@@ -621,8 +635,8 @@ __global__ __launch_bounds__(1024) void k_build_chunks(const int *plist, const i
     for (int k = 0; k * CHUNK < tot; ++k, ++og) { r.chunk = k; if (og < cap) recs_g[og] = r; }
   }
   if (t == 1023) {
-    rc[RC_NCH] = sc[t]; rc[RC_NCHG] = sg[t]; rc[RC_GHOST] = any_ghost;
-    if (sc[t] > cap || sg[t] > cap) atomicOr(rc + RC_OVER, 4);
+    rc[RC_NCH] = ic; rc[RC_NCHG] = ig; rc[RC_GHOST] = any_ghost;
+    if (ic > cap || ig > cap) atomicOr(rc + RC_OVER, 4);
   }
 }
 
