@@ -2294,9 +2294,7 @@ int rebin(mpmhip_ctx *c) {
       f->cap_fbins = cap_fb + 64;
     }
     (void)dummy;
-    MPM_HIP_CHECK(c, hipMemsetAsync(f->rcnt, 0, RC_N * sizeof(int), s));
-    MPM_HIP_CHECK(c, hipMemsetAsync(f->pb_flag, 0, f->nblocks * sizeof(int), s));
-    MPM_HIP_CHECK(c, hipMemsetAsync(f->ab_flag, 0, f->nblocks * sizeof(int), s));
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->pb_flag, 0, (2 * f->nblocks + 64) * sizeof(int), s));  // pb_flag, ab_flag, rcnt
     hipLaunchKernelGGL(k_mark_blocks, nblk(d.n_p), TPB, 0, s, skeys, d.n_p, f->blk_bits, f->pb_flag);
     if ((rc = scan_flags_dev(c, f->pb_flag, f->pb_index, nb))) return rc;
     hipLaunchKernelGGL(k_flag_total, 1, 1, 0, s, f->pb_flag, f->pb_index, nb, f->rcnt, (int)RC_NP, cap_P, 1);
@@ -2397,10 +2395,12 @@ int fast_init(mpmhip_ctx *c) {
   select_buffer(f, 0);
   if ((rc = dalloc(c, &f->g.vout, f->nblocks * GCH_VOUT * 64))) return rc;
   if ((rc = dalloc(c, &f->g.counters, 16))) return rc;
-  if ((rc = dalloc(c, &f->rcnt, (size_t)RC_N))) return rc;
-  if ((rc = dalloc(c, &f->pb_flag, f->nblocks))) return rc;
+  // one allocation, one memset per re-sort: [particle-block flags | active-block flags | device counts]
+  static_assert(RC_N <= 64, "device counts of a re-sort");
+  if ((rc = dalloc(c, &f->pb_flag, 2 * f->nblocks + 64))) return rc;
+  f->ab_flag = f->pb_flag + f->nblocks;
+  f->rcnt = f->pb_flag + 2 * f->nblocks;
   if ((rc = dalloc(c, &f->pb_index, f->nblocks))) return rc;
-  if ((rc = dalloc(c, &f->ab_flag, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->ab_index, f->nblocks))) return rc;
   f->g.ab_flag = f->ab_flag;
   if (const char *e = getenv("MPMHIP_DBG")) f->g.dbg = (int)strtoul(e, nullptr, 0);
