@@ -354,8 +354,8 @@ struct GridPtrs {
   int *col_flag;    // [block] 1 = the body-face splat may have written this block's collider channels this substep
   int *m_flag;      // [block] 1 = p2g (or a halo sum) may have written this block's mass / momentum this substep
   int *counters;    // [0] particles outside their tile margin, [1] dropped contributions (inactive block)
-  int *host_sig;    // host-mapped pinned memory: [0] the drift flag (counters[6]) as of this launch, [1] step_id -- written by
-  int step_id;      // one thread of every k_p2g launch, read by the host without any stream operation (fast_step)
+  int *host_sig;    // host-mapped pinned memory: [1] step_id of the newest k_p2g launch that started, [8 + (step_id & 15)] its
+  int step_id;      // flags (see k_p2g); [2], [3] the sharded loop's reduced flag and its sequence number (k_post_flag)
   float lookahead;  // substeps the early warning of the adaptive re-sort looks ahead (k_p2g)
   int dbg;          // MPMHIP_DBG bitmask (perf experiments only, results are wrong): 1 skip p2g flush, 2 skip the p2g
                     // scatter, 8 / 16 skip vertex-force / stress loads, 128 skip the LDS atomics only, 256 skip the splat workgroups, 2048 skip the clearing workgroups; 64 (results stay
@@ -1248,9 +1248,12 @@ __global__ __launch_bounds__(PT) void k_p2g(Bufs b, VAdj va, const ChunkRec *rec
     // progress + drift flag for the host (plain stores into pinned host memory instead of a copy + event every few
     // substeps: on the stream those cost a blit kernel and ~10-20 us of idle queue each).  Everything before this launch
     // has completed, so step_id - 1 substeps are done and counters[6] holds every warning they raised.
-    __hip_atomic_store(g.host_sig, g.counters[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(g.host_sig + 1, g.step_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(g.host_sig + 4, g.counters[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // a body face left its bin's tile
+    // One ring entry per launch -- (step_id, a body face left its bin's tile, drift flag) -- and the progress word after it.
+    // The host decides at substep s with the entry of substep s - host_lead, whatever the GPU has done since: the re-sort
+    // schedule is a function of the simulation, not of host / GPU timing, and a run stays bit-reproducible.
+    unsigned v = ((unsigned)g.step_id << 2) | (g.counters[5] != 0 ? 2u : 0u) | (g.counters[6] != 0 ? 1u : 0u);
+    __hip_atomic_store(g.host_sig + 8 + (g.step_id & 15), (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(g.host_sig + 1, g.step_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if ((int)blockIdx.x < sa.n_extra) {  // extra workgroups first: they are the long-latency ones
     int e = blockIdx.x;
@@ -1982,7 +1985,6 @@ struct FastState {
   int *forder = nullptr, *fiota = nullptr, *fb_start = nullptr, *fb_cnt = nullptr;
   bool faces_binned = false;
   int rebins_since_face_sort = 0;
-  bool face_flag_stale = false;
   FaceBin *fbins = nullptr;
   int *fidx = nullptr;  // [n_f][3] face vertex ids in bin order
   int cap_fbins = 0, n_fbins = 0;
@@ -2037,8 +2039,10 @@ struct FastState {
   int steps_since_rebin = 0;
   hipEvent_t ev_flag = nullptr;
   bool flag_pending = false;
-  volatile int *h_sig = nullptr;  // pinned, host-mapped: [0] drift flag, [1] last step_id seen by a p2g launch (GridPtrs::host_sig)
+  volatile int *h_sig = nullptr;  // pinned, host-mapped, written by the kernels (GridPtrs::host_sig)
   unsigned sig_seq = 0;           // step_id of the last p2g launch issued (wraps)
+  unsigned sig_at_rebin = 0;      // sig_seq when the last re-sort finished: ring entries up to it speak about the old order
+  bool face_flag_seen = false;    // some ring entry since the last face sort had the face bit set
   int host_lead = 6;              // substeps the host may run ahead of the GPU (MPMHIP_HOST_LEAD)
   bool have_order = false;
   int64_t rebins = 0;
@@ -2246,7 +2250,7 @@ int rebin(mpmhip_ctx *c) {
   // active list below does): the ~13 launches of the face sort run when a face has actually left its bin's tile since the
   // last one (counters[5], seen through host memory), at the latest every 16th re-sort, and always in the sharded loops.
   bool face_sort = with_faces;
-  if (with_faces && f->faces_binned && f->g.host_sig && !f->dist && f->h_sig[4] == 0 && f->rebins_since_face_sort < 16 &&
+  if (with_faces && f->faces_binned && f->g.host_sig && !f->dist && !f->face_flag_seen && f->rebins_since_face_sort < 16 &&
       !getenv("MPMHIP_FACE_SORT_ALWAYS"))
     face_sort = false;
   if (face_sort) {  // body faces: sort by block, per-block ranges (independent of the particle tables)
@@ -2266,7 +2270,7 @@ int rebin(mpmhip_ctx *c) {
     hipLaunchKernelGGL(k_face_sorted_idx, nblk(nf), TPB, 0, s, c->mesh_idx, f->forder, nf, f->fidx);
     MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + 5, 0, sizeof(int), s));
     f->rebins_since_face_sort = 0;
-    f->face_flag_stale = true;  // h_sig[4] is cleared after this re-sort's host wait
+    f->face_flag_seen = false;
   } else if (with_faces) {
     f->rebins_since_face_sort += 1;
   }
@@ -2342,11 +2346,7 @@ int rebin(mpmhip_ctx *c) {
   MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + 6, 0, sizeof(int), s));
   f->h_pin[24] = 0;
   f->flag_pending = false;
-  if (f->g.host_sig) {  // every launch that could still store the old flag has to be gone before the host clears its copy
-    MPM_HIP_CHECK(c, hipStreamSynchronize(s));
-    f->h_sig[0] = 0;
-    if (f->face_flag_stale) { f->h_sig[4] = 0; f->face_flag_stale = false; }
-  }
+  f->sig_at_rebin = f->sig_seq;  // ring entries of earlier substeps speak about the old order
   f->g.ab_flag = f->ab_flag;
   f->steps_since_rebin = 0;
   f->rebins += 1;
@@ -2417,7 +2417,7 @@ int fast_init(mpmhip_ctx *c) {
     MPM_HIP_CHECK(c, hipHostGetDevicePointer((void **)&ds, hs, 0));
     f->h_sig = hs;
     f->g.host_sig = getenv("MPMHIP_FLAG_COPY") ? nullptr : ds;  // MPMHIP_FLAG_COPY=1: the former copy + event poll (A/B)
-    if (const char *e = getenv("MPMHIP_HOST_LEAD")) f->host_lead = std::max(1, atoi(e));
+    if (const char *e = getenv("MPMHIP_HOST_LEAD")) f->host_lead = std::min(std::max(1, atoi(e)), 12);  // (ring of 16 entries)
     f->g.lookahead = DRIFT_LOOKAHEAD;
     if (const char *e = getenv("MPMHIP_DRIFT_LOOKAHEAD")) f->g.lookahead = (float)atof(e);
   }
@@ -2535,19 +2535,28 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     // ahead of the GPU (<= 16 substeps) -- otherwise a fused mpmhip_steps(n) would have enqueued all n substeps
     // long before the first flag arrives.
     if (f->g.host_sig) {
-      // the kernels report progress and the flag into pinned host memory (k_p2g): no stream operation here, and the flag
-      // is looked at before every substep.  The host keeps host_lead substeps queued (enough to hide its launch latency)
-      // and no more, so a warning takes effect within host_lead + 1 substeps (the copy + event scheme: 8-16) -- well
-      // inside the kernels' 20-substep look-ahead.
-      for (long spins = 0; (int)(f->sig_seq - (unsigned)f->h_sig[1]) > f->host_lead; ++spins) {
+      // the kernels report progress and their flags into pinned host memory (k_p2g): no stream operation here.  Before
+      // substep s the host waits until substep s - host_lead has started and decides with THAT substep's entry: it keeps
+      // host_lead substeps queued (enough to hide its launch latency) and no more, and a warning takes effect exactly
+      // host_lead substeps after the launch that posted it (the copy + event scheme: 8-16) -- inside the look-ahead.
+      const unsigned e = f->sig_seq + 1u - (unsigned)f->host_lead;  // the substep whose ring entry decides now
+      bool arrived = true;
+      for (long spins = 0; (int)((unsigned)f->h_sig[1] - e) < 0; ++spins) {
         if ((spins & 0x3ff) == 0x3ff) {
-          hipError_t e = hipStreamQuery(s);
-          if (e == hipSuccess) break;  // nothing in flight (e.g. the progress word was never written): do not wait for it
-          if (e != hipErrorNotReady) MPM_HIP_CHECK(c, e);
+          hipError_t q = hipStreamQuery(s);
+          if (q == hipSuccess) { arrived = (int)((unsigned)f->h_sig[1] - e) >= 0; break; }  // nothing in flight any more
+          if (q != hipErrorNotReady) MPM_HIP_CHECK(c, q);
         }
         std::this_thread::yield();
       }
-      if (f->h_sig[0] && f->adaptive_rebin) f->steps_since_rebin = 1 << 30;
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (arrived && (int)(e - f->sig_at_rebin) > 0) {  // an entry written after the last re-sort
+        unsigned v = (unsigned)f->h_sig[8 + (e & 15u)];
+        if ((v >> 2) == (e & 0x3fffffffu)) {
+          if (v & 2u) f->face_flag_seen = true;
+          if ((v & 1u) && f->adaptive_rebin) f->steps_since_rebin = 1 << 30;
+        }
+      }
     } else if (f->flag_pending && (f->steps_since_rebin & f->poll_mask) == 0) {
       MPM_HIP_CHECK(c, hipEventSynchronize(f->ev_flag));
       f->flag_pending = false;
