@@ -118,6 +118,8 @@ def _main(out_stream):
     ap.add_argument("--no-kernels", action="store_true", help="skip the HIP-event passes")
     ap.add_argument("--advance", type=int, default=2000, help="untimed substeps before the second (draped-state) measurement; "
                     "0 = skip it")
+    ap.add_argument("--pre-advance", type=int, default=0, help="diagnostics: untimed substeps BEFORE the warm-up (profile the "
+                    "draped state with --advance 0)")
     ap.add_argument("--force-dist", action="store_true", help="diagnostics: run the sharded driver even with one rank "
                     "(launch under torch.distributed.run --nproc-per-node 1)")
     args = ap.parse_args()
@@ -179,6 +181,8 @@ def _main(out_stream):
         run = lambda n: harness.run(sim, n, fused=True)
         barrier = lambda: None
 
+    if args.pre_advance > 0:
+        run(args.pre_advance)
     run(args.warmup)
     barrier()
     torch.cuda.synchronize()

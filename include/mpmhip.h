@@ -277,6 +277,12 @@ int mpmhip_bind_gaussians(int32_t device, void *stream, int32_t n_gaussians, con
                           const float *face_orien_mat, const float *face_orien_quat, const float *face_scaling, float *xyz,
                           float *rotation, float *scaling);
 
+/* MPMWARP.export_particle_cov_to_torch (warp_mpm/mpm_solver.py:543-561) = kernel compute_cov_from_F
+ * (warp_mpm/mpm_utils.py:1108-1132): new_cov[6p..] = upper triangle (xx xy xz yy yz zz) of F_trial[p] * sym(particle_cov[6p..])
+ * * F_trial[p]^T for p < n (= n_particles - n_vertices).  Stand-alone map on [dev] arrays in the reference's AoS layout. */
+int mpmhip_cov_from_F(int32_t device, void *stream, const float *particle_F_trial, const float *particle_cov, int32_t n,
+                      float *new_cov);
+
 /* ---- introspection ---------------------------------------------------------------------- */
 /* dense reference-layout copies of grid_m [G^3], grid_v_in [G^3*3], grid_v_out [G^3*3] as they
  * stand after the last substep's grid stage ([dev] outputs, any may be NULL).  Synchronous. */

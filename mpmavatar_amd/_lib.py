@@ -88,6 +88,7 @@ SIGNATURES = {
     "mpmhip_add_velocity_rotation": (C.c_int, [vp, f3, f3, f3, f3, C.c_float, C.c_float, vp, C.c_float, C.c_float]),
     "mpmhip_step": (C.c_int, [vp, C.c_float, vp, vp, vp, C.c_int32, vp, vp]),
     "mpmhip_steps": (C.c_int, [vp, C.c_float, C.c_int32, vp, vp, vp, C.c_int32, vp, vp]),
+    "mpmhip_cov_from_F": (C.c_int, [C.c_int32, vp, vp, vp, C.c_int32, vp]),
     "mpmhip_face_frames": (C.c_int, [C.c_int32, vp, vp, vp, C.c_int32, vp, vp, vp, vp]),
     "mpmhip_bind_gaussians": (C.c_int, [C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mpmhip_dist_enable": (C.c_int, [vp]),

@@ -110,11 +110,44 @@ __global__ void k_bind_gaussians(int n_g, const int32_t *binding, const float *x
     for (int k = 0; k < 3; ++k) scaling[3 * (size_t)g + k] = expf(scaling_raw[3 * (size_t)g + k]) * s;
 }
 
+// compute_cov_from_F (/root/reference/warp_mpm/mpm_utils.py:1108-1132): cov = F_trial * sym(cov0) * F_trial^T per
+// particle, upper triangle out (xx, xy, xz, yy, yz, zz).  Products summed left to right as Warp's mat33 product does.
+__global__ void k_cov_from_F(const float *F_trial, const float *cov0, int n, float *out) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float F[3][3], S[3][3], T[3][3];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) F[r][c] = F_trial[9 * (size_t)p + 3 * r + c];
+  const float *q = cov0 + 6 * (size_t)p;
+  S[0][0] = q[0]; S[0][1] = q[1]; S[0][2] = q[2];
+  S[1][0] = q[1]; S[1][1] = q[3]; S[1][2] = q[4];
+  S[2][0] = q[2]; S[2][1] = q[4]; S[2][2] = q[5];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) T[r][c] = F[r][0] * S[0][c] + F[r][1] * S[1][c] + F[r][2] * S[2][c];
+  float *o = out + 6 * (size_t)p;
+  int k = 0;
+  for (int r = 0; r < 3; ++r)
+    for (int c = r; c < 3; ++c) o[k++] = T[r][0] * F[c][0] + T[r][1] * F[c][1] + T[r][2] * F[c][2];
+}
+
 int check(hipError_t e) { return e == hipSuccess ? MPMHIP_OK : MPMHIP_ERR_HIP; }
 
 }  // namespace
 
 extern "C" {
+
+int mpmhip_cov_from_F(int32_t device, void *stream, const float *particle_F_trial, const float *particle_cov, int32_t n,
+                      float *new_cov) {
+  if (n < 0 || (n > 0 && (!particle_F_trial || !particle_cov || !new_cov))) return MPMHIP_ERR_INVALID;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0 || device < 0 || device >= n_dev) return MPMHIP_ERR_NO_DEVICE;
+  if (n == 0) return MPMHIP_OK;
+  if (int rc = check(hipSetDevice(device))) return rc;
+  hipLaunchKernelGGL(k_cov_from_F, (unsigned)((n + TPB - 1) / TPB), TPB, 0, (hipStream_t)stream, particle_F_trial, particle_cov, n,
+                     new_cov);
+  return check(hipGetLastError());
+}
+
 
 int mpmhip_face_frames(int32_t device, void *stream, const float *verts, const int32_t *faces, int32_t n_faces,
                        float *face_center, float *face_orien_mat, float *face_orien_quat, float *face_scaling) {

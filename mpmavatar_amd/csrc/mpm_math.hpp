@@ -2,10 +2,9 @@
 //
 // Everything here is a pure per-particle map held in VGPRs (no scratch arrays indexed
 // dynamically).  Reference semantics: /root/reference/warp_mpm/mpm_utils.py:8-399.
-// The cloth path avoids Warp's qr3/svd3 entirely: the sign-fixed QR of the reference
-// (R00,R11 >= 0, det Q = +1; mpm_utils.py:109-123) is unique, so it is computed as
-// Gram-Schmidt with q3 = q1 x q2, and the rotation U V^T of the padded 2x2 block
-// (mpm_utils.py:133-141) is the closed-form 2x2 polar rotation.
+// Cloth path: the sign-fixed QR of the reference (R00,R11 >= 0, det Q = +1; mpm_utils.py:109-123) by Givens
+// rotations, operation for operation what the CPU oracle does (see qr_cloth); the rotation U V^T of the
+// padded 2x2 block (mpm_utils.py:133-141) is the closed-form 2x2 polar rotation instead of an svd3.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -301,26 +300,49 @@ struct QR3 {
 // first: these two functions are compiled without FMA contraction so that every kernel that inlines them (fused and
 // stand-alone element finalize, both back ends) takes the same branch on the same input, whatever the surrounding
 // code lets the compiler fuse (needs -ffp-contract=fast-honor-pragmas, see build.py).
+//
+// QR by three Givens rotations (zeroing d10, d20, d21 in that order; det Q = +1) followed by the reference's two sign
+// flips (mpm_utils.py:109-123,181-195) -- the algorithm behind wp.qr3, in the operation order of the test suite's CPU
+// restatement of it (checked bit for bit by tests/test_hip_math_on_host.py), so that r22 carries the same rounding here and there.
+// It matters: a cloth at rest has r22 = 1 exactly, the return mapping branches on r22 > 1, and WHICH way an fp32 QR
+// rounds r22 there is a property of the algorithm.  Rounds 1-2 used Gram-Schmidt with q2 = q0 x q1 (same Q, R in exact
+// arithmetic): |q2| = 1 +- ulp is not re-normalised, r22 = q2 . d2 inherits that bias, and the run left the
+// reference-produced cloth sequences 2.7x further (2.6e-3 / 1.6e-3 in v on ref_seq_sheet / ref_seq_garment after 80
+// substeps) than the oracle did (9.7e-4 / 5.8e-4) -- reproduced and bisected on the CPU by swapping this one function
+// (profiles/r03_cloth_qr_bisect.md).  Qt = G3 G2 G1 starts as the identity, so its products with 0 and 1 are written out.
 __device__ __forceinline__ QR3 qr_cloth(const M3 &d) {
 #pragma clang fp contract(off)
-  // (written out: the pragma covers this body, not the bodies of dot / length / cross / operator*)
-  V3 d0 = col0(d), d1 = col1(d), d2 = col2(d);
   QR3 o;
-  o.r00 = sqrtf((d0.x * d0.x + d0.y * d0.y) + d0.z * d0.z);
-  float i0 = 1.0f / o.r00;
-  o.q0 = v3(i0 * d0.x, i0 * d0.y, i0 * d0.z);
-  o.r01 = (o.q0.x * d1.x + o.q0.y * d1.y) + o.q0.z * d1.z;
-  float ax = o.r01 * o.q0.x, ay = o.r01 * o.q0.y, az = o.r01 * o.q0.z;
-  V3 u1 = v3(d1.x - ax, d1.y - ay, d1.z - az);
-  o.r11 = sqrtf((u1.x * u1.x + u1.y * u1.y) + u1.z * u1.z);
-  float i1 = 1.0f / o.r11;
-  o.q1 = v3(i1 * u1.x, i1 * u1.y, i1 * u1.z);
-  float c0a = o.q0.y * o.q1.z, c0b = o.q0.z * o.q1.y, c1a = o.q0.z * o.q1.x, c1b = o.q0.x * o.q1.z;
-  float c2a = o.q0.x * o.q1.y, c2b = o.q0.y * o.q1.x;
-  o.q2 = v3(c0a - c0b, c1a - c1b, c2a - c2b);
-  o.r02 = (o.q0.x * d2.x + o.q0.y * d2.y) + o.q0.z * d2.z;
-  o.r12 = (o.q1.x * d2.x + o.q1.y * d2.y) + o.q1.z * d2.z;
-  o.r22 = (o.q2.x * d2.x + o.q2.y * d2.y) + o.q2.z * d2.z;
+  // G1: rows 0, 1 from (d00, d10)
+  float n1 = sqrtf(d.a00 * d.a00 + d.a10 * d.a10);
+  float c1 = n1 == 0.0f ? 1.0f : d.a00 / n1, s1 = n1 == 0.0f ? 0.0f : d.a10 / n1;
+  float t00 = c1 * d.a00 + s1 * d.a10, t01 = c1 * d.a01 + s1 * d.a11, t02 = c1 * d.a02 + s1 * d.a12;
+  float t11 = (-s1) * d.a01 + c1 * d.a11, t12 = (-s1) * d.a02 + c1 * d.a12;
+  // G2: rows 0, 2 from (t00, d20)
+  float n2 = sqrtf(t00 * t00 + d.a20 * d.a20);
+  float c2 = n2 == 0.0f ? 1.0f : t00 / n2, s2 = n2 == 0.0f ? 0.0f : d.a20 / n2;
+  float u00 = c2 * t00 + s2 * d.a20, u01 = c2 * t01 + s2 * d.a21, u02 = c2 * t02 + s2 * d.a22;
+  float u21 = (-s2) * t01 + c2 * d.a21, u22 = (-s2) * t02 + c2 * d.a22;
+  // G3: rows 1, 2 from (t11, u21)
+  float n3 = sqrtf(t11 * t11 + u21 * u21);
+  float c3 = n3 == 0.0f ? 1.0f : t11 / n3, s3 = n3 == 0.0f ? 0.0f : u21 / n3;
+  float w11 = c3 * t11 + s3 * u21, w12 = c3 * t12 + s3 * u22;
+  float w22 = (-s3) * t12 + c3 * u22;
+  // rows of Qt = columns of Q
+  float a0x = c2 * c1, a0y = c2 * s1, a0z = s2;                 // row 0 after G2
+  float a2x = (-s2) * c1, a2y = (-s2) * s1, a2z = c2;           // row 2 after G2
+  float b1x = c3 * (-s1) + s3 * a2x, b1y = c3 * c1 + s3 * a2y, b1z = s3 * a2z;      // row 1 after G3
+  float b2x = (-s3) * (-s1) + c3 * a2x, b2y = (-s3) * c1 + c3 * a2y, b2z = c3 * a2z;  // row 2 after G3
+  o.q0 = v3(a0x, a0y, a0z); o.q1 = v3(b1x, b1y, b1z); o.q2 = v3(b2x, b2y, b2z);
+  o.r00 = u00; o.r01 = u01; o.r02 = u02; o.r11 = w11; o.r12 = w12; o.r22 = w22;
+  if (o.r00 < 0.0f) {  // mpm_utils.py:112-114: columns 0, 2 of Q and rows 0, 2 of R change sign
+    o.q0 = v3(-o.q0.x, -o.q0.y, -o.q0.z); o.q2 = v3(-o.q2.x, -o.q2.y, -o.q2.z);
+    o.r00 = -o.r00; o.r01 = -o.r01; o.r02 = -o.r02; o.r22 = -o.r22;
+  }
+  if (o.r11 < 0.0f) {  // :118-120: columns 1, 2 of Q and rows 1, 2 of R
+    o.q1 = v3(-o.q1.x, -o.q1.y, -o.q1.z); o.q2 = v3(-o.q2.x, -o.q2.y, -o.q2.z);
+    o.r11 = -o.r11; o.r12 = -o.r12; o.r22 = -o.r22;
+  }
   return o;
 }
 

@@ -363,6 +363,21 @@ class MPMWARP(object):
         for key, value in self.time_profile.items():
             print(key, sum(value))
 
+    # mpm_solver.py:543-561 (kernel compute_cov_from_F, mpm_utils.py:1108-1132)
+    def export_particle_cov_to_torch(self, mpm_state, device="cuda:0"):
+        n = self.n_no_vertices
+        Ft, cov0 = mpm_state.particle_F_trial, mpm_state.particle_cov   # reading F_trial writes the solver's results back first
+        if cov0 is None or cov0.numel() < 6 * n:
+            raise RuntimeError("export_particle_cov_to_torch: particle_cov holds fewer than 6 * n_no_vertices values")
+        new_cov = torch.zeros(n * 6, dtype=torch.float32, device=Ft.device)
+        if n:
+            dev = Ft.device
+            rc = self._lib.mpmhip_cov_from_F(dev.index or 0, torch.cuda.current_stream(dev).cuda_stream, Ft.data_ptr(),
+                                             cov0.data_ptr(), n, new_cov.data_ptr())
+            if rc != 0:
+                raise RuntimeError(f"mpmhip_cov_from_F failed ({rc})")
+        return new_cov
+
     # ------------------------------------------------------------------ introspection (not in the reference)
     def export_grid(self):
         """Dense reference-layout (grid_m [G,G,G], grid_v_in [G,G,G,3], grid_v_out [G,G,G,3]) copies."""

@@ -432,6 +432,16 @@ void orc_zero_grid(orc_sim *s) {
   memset(s->grid_v_out, 0, 3 * n * sizeof(float));
 }
 
+/* Test hooks (tests/test_hip_math_on_host.py): when set, the per-particle constitutive update is taken from the caller
+   instead of the restatement below -- the test compiles the PRODUCT's device math header for the host and runs it inside
+   this oracle's substep, so that the header's arithmetic can be checked against the reference-produced fixtures without
+   a GPU.  NULL (the default) = the oracle's own restatement; nothing but that test sets them. */
+void (*orc_hook_element)(const float *d, const float *R_inv, float vol, float mu, float lam, float gamma, float kappa,
+                         float friction_coeff, float *new_d, float *stress, float *f1, float *f2, float *f3) = 0;
+void (*orc_hook_traditional)(const float *F_trial, int material, float alpha, float hardening, float xi,
+                             float plastic_viscosity, float softening, float dt, float *mu, float *lam,
+                             float *yield_stress, float *F, float *stress) = 0;
+
 /* compute_stress_from_F_trial, mpm_utils.py:1017-1105; launch dim n_nv (mpm_solver.py:327-332) */
 void orc_compute_stress_from_F_trial(orc_sim *s, float dt) {
   int n_nv = s->n_particles - s->n_vertices;
@@ -441,15 +451,26 @@ void orc_compute_stress_from_F_trial(orc_sim *s, float dt) {
     float stress[9] = {0};
     if (p < s->n_elements) { /* particle_elements[p] == 1 */
       float nd[9];
-      orc_anisotropy_return_mapping(&s->d[p * 9], s->gamma[p], s->kappa[p], s->friction_coeff, nd);
-      memcpy(&s->d[p * 9], nd, sizeof nd);
       float f1[3], f2[3], f3[3];
-      orc_kirchhoff_anisotropy(&s->R_inv[p * 3], &s->d[p * 9], s->vol[p], s->mu[p], s->lam[p],
-                               s->gamma[p], s->kappa[p], stress, f1, f2, f3);
+      if (orc_hook_element) {
+        orc_hook_element(&s->d[p * 9], &s->R_inv[p * 3], s->vol[p], s->mu[p], s->lam[p], s->gamma[p], s->kappa[p],
+                         s->friction_coeff, nd, stress, f1, f2, f3);
+        memcpy(&s->d[p * 9], nd, sizeof nd);
+      } else {
+        orc_anisotropy_return_mapping(&s->d[p * 9], s->gamma[p], s->kappa[p], s->friction_coeff, nd);
+        memcpy(&s->d[p * 9], nd, sizeof nd);
+        orc_kirchhoff_anisotropy(&s->R_inv[p * 3], &s->d[p * 9], s->vol[p], s->mu[p], s->lam[p],
+                                 s->gamma[p], s->kappa[p], stress, f1, f2, f3);
+      }
       int v1 = (int)s->faces[p * 3], v2 = (int)s->faces[p * 3 + 1], v3 = (int)s->faces[p * 3 + 2];
       add3(&s->vertex_force[v1 * 3], f1); /* :173-175 */
       add3(&s->vertex_force[v2 * 3], f2);
       add3(&s->vertex_force[v3 * 3], f3);
+    } else if (orc_hook_traditional) {
+      float F[9];
+      orc_hook_traditional(&s->F_trial[p * 9], s->material, s->alpha, s->hardening, s->xi, s->plastic_viscosity,
+                           s->softening, dt, &s->mu[p], &s->lam[p], &s->yield_stress[p], F, stress);
+      memcpy(&s->F[p * 9], F, sizeof F);
     } else { /* particle_traditional[p] == 1 */
       float F[9];
       const float *Ft = &s->F_trial[p * 9];

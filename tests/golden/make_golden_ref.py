@@ -431,7 +431,32 @@ def _small_garment(**kw):
     return sc
 
 
+def make_cov_from_F(name="ref_cov_from_F"):
+    """MPMWARP.export_particle_cov_to_torch (mpm_solver.py:543-561 -> compute_cov_from_F, mpm_utils.py:1108-1132) on the
+    reference: a strained jelly blob after three substeps (F_trial = (I + dt grad v) F is no longer the random start) with a
+    random symmetric particle_cov."""
+    sc, extra = trace_scene_traditional("jelly", 321, n=96)
+    sim = build_reference(sc)
+    apply_extra(sim, extra)
+    run_reference(sim, 3)
+    rng = np.random.default_rng(322)
+    n = sc.n_particles - sc.n_vertices
+    cov0 = rng.uniform(-1.0, 1.0, n * 6).astype(np.float32)
+    sim.state.particle_cov = wp.from_numpy(cov0, dtype=float)
+    F_trial = np.array(sim.state.particle_F_trial.numpy(), np.float32).reshape(n, 3, 3)
+    new_cov = sim.solver.export_particle_cov_to_torch(sim.state, device="cpu").numpy().astype(np.float32)
+    # cross-check in float64 (the fixture is the reference's output; this only guards the stand-in's mat33 product)
+    S = np.zeros((n, 3, 3)); c = cov0.reshape(n, 6).astype(np.float64)
+    S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2] = c.T
+    S = S + np.triu(S, 1).transpose(0, 2, 1)
+    want = np.einsum("nij,njk,nlk->nil", F_trial.astype(np.float64), S, F_trial.astype(np.float64))
+    want6 = np.stack([want[:, 0, 0], want[:, 0, 1], want[:, 0, 2], want[:, 1, 1], want[:, 1, 2], want[:, 2, 2]], 1).reshape(-1)
+    assert np.abs(new_cov - want6).max() < 1e-5 * max(np.abs(want6).max(), 1.0)
+    save(name, {"particle_F_trial": F_trial, "particle_cov": cov0, "new_cov": new_cov})
+
+
 FIXTURES = {
+    "ref_cov_from_F": make_cov_from_F,
     # --- per-kernel traces from random states
     **{f"ref_trace_{m}": (lambda m=m, i=i: make_trace(f"ref_trace_{m}", *trace_scene_traditional(m, 100 + i), with_pre=(m == "jelly")))
        for i, m in enumerate(["jelly", "metal", "sand", "foam", "snow", "plasticine"])},

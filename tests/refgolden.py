@@ -40,6 +40,35 @@ def rel(a, b, floor=1e-3):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), floor))
 
 
+def rel_pp(a, b, floor=1e-3):
+    """SURVEY 8(d)'s parity metric: max_i |a_i - b_i| / max(|b_i|, floor) with per-PARTICLE norms (rows), so that a slow
+    particle next to a fast one is held to its own magnitude (`rel` divides by the global maximum).  The floor is absolute
+    (1e-3 in the field's unit), as 8(d) writes it."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if a.size == 0:
+        return 0.0
+    a, b = a.reshape(len(a), -1), b.reshape(len(b), -1)
+    return float((np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), floor)).max())
+
+
+def rel_pp_scaled(a, b, frac=1e-3):
+    """The same with the floor relative to the fastest particle: max_i |da_i| / max(|b_i|, frac * max_j |b_j|)."""
+    b64 = np.asarray(b, np.float64).reshape(len(b), -1)
+    return rel_pp(a, b, floor=max(frac * float(np.linalg.norm(b64, axis=1).max()) if b64.size else 0.0, 1e-30))
+
+
+ENVELOPE_FACTOR = 1.5
+
+
+def seq_bound(z, cp, field="particle_v"):
+    """1e-4 (north star), or -- where the reference's own trajectory is that sensitive -- 1.5 x the larger of two distances of
+    the reference from ITSELF: fp64-accurate vs fp32-accurate svd3 / qr3 (``alt_`` arrays), and the same particles enumerated
+    in another order, i.e. another summation order of the atomic_adds (``alt2_`` arrays).  (Rounds 1-2: 3 x; tightened when
+    the cloth QR of the HIP path was made the oracle's, tests/test_hip_math_on_host.py.)"""
+    envs = [rel(z[f"{tag}_s{cp}_{field}"], z[f"s{cp}_{field}"]) for tag in ("alt", "alt2") if f"{tag}_s{cp}_{field}" in z.files]
+    return max([1e-4] + [ENVELOPE_FACTOR * e for e in envs])
+
+
 PRE_OPS = {"impulse": "add_impulse_on_particles", "vel_translation": "enforce_particle_velocity_translation",
            "vel_rotation": "enforce_particle_velocity_rotation"}
 

@@ -308,3 +308,38 @@ def test_rotation_modifier_on_the_axis_stays_finite(mode):
     v = sim.state.particle_v.cpu().numpy()
     assert np.isfinite(v).all()
     assert np.isfinite(sim.state.particle_x.cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_export_particle_cov_to_torch(mode):
+    """MPMWARP.export_particle_cov_to_torch (mpm_solver.py:543-561, kernel compute_cov_from_F mpm_utils.py:1108-1132) against
+    the reference's own output (tests/golden/ref_cov_from_F.npz, tests/golden/make_golden_ref.py), through the shim -- the
+    solver's F_trial is written back before it is read -- and through the bare C entry point."""
+    import refgolden as rg
+    z = rg.load("ref_cov_from_F")
+    Ft, cov0, want = z["particle_F_trial"], z["particle_cov"], z["new_cov"]
+    n = len(Ft)
+    rng = np.random.default_rng(1)
+    pts = (0.8 + 0.4 * rng.uniform(size=(n, 3))).astype(np.float32)
+    sc = scenes._trad_scene("cov", pts, 0.02 ** 3, 20, material="jelly", v=np.zeros((n, 3), np.float32), E=80.0,
+                            params={"material": "jelly", "g": [0.0, 0.0, 0.0], "density": 1.0})
+    sim = harness.build_solver(sc, "cuda:0", mode=mode)
+    dev = sim.state.particle_x.device
+    sim.state.particle_cov = torch.as_tensor(cov0, device=dev)
+    sim.state.particle_F_trial.copy_(torch.as_tensor(Ft, device=dev))
+    got = sim.solver.export_particle_cov_to_torch(sim.state, device="cuda:0")
+    assert got.shape == (6 * n,) and rel(got.cpu().numpy(), want) < 2e-6
+    # one substep with zero gravity and zero velocity leaves F_trial = (I + dt * 0) F = the elastic part of the F_trial that was
+    # set (jelly: no return mapping): the export after it must read the solver's state, not a stale caller tensor
+    harness.run(sim, 1)
+    got2 = sim.solver.export_particle_cov_to_torch(sim.state, device="cuda:0")
+    assert rel(got2.cpu().numpy(), want) < 1e-4
+    # bare C ABI
+    from mpmavatar_amd import _lib as L
+    lib = L.load()
+    out = torch.zeros(6 * n, dtype=torch.float32, device=dev)
+    a, b = torch.as_tensor(Ft, device=dev).contiguous(), torch.as_tensor(cov0, device=dev).contiguous()
+    assert lib.mpmhip_cov_from_F(0, None, a.data_ptr(), b.data_ptr(), n, out.data_ptr()) == 0
+    torch.cuda.synchronize()
+    assert rel(out.cpu().numpy(), want) < 2e-6
+    assert lib.mpmhip_cov_from_F(0, None, None, b.data_ptr(), n, out.data_ptr()) != 0

@@ -156,12 +156,7 @@ def test_oracle_whole_traced_substep(name, oracle_lib):
     assert abs(o.time - float(z["time_after"])) < 1e-12
 
 
-def seq_bound(z, cp, field="particle_v"):
-    """1e-4 (north star), or -- where the reference's own trajectory is that sensitive -- three times the larger of two distances of
-    the reference from ITSELF: fp64-accurate vs fp32-accurate svd3 / qr3 (``alt_`` arrays), and the same particles enumerated
-    in another order, i.e. another summation order of the atomic_adds (``alt2_`` arrays)."""
-    envs = [rg.rel(z[f"{tag}_s{cp}_{field}"], z[f"s{cp}_{field}"]) for tag in ("alt", "alt2") if f"{tag}_s{cp}_{field}" in z.files]
-    return max([1e-4] + [3.0 * e for e in envs])
+seq_bound = rg.seq_bound
 
 
 @pytest.mark.parametrize("name", SEQS)
