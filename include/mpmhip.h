@@ -287,9 +287,15 @@ int mpmhip_cov_from_F(int32_t device, void *stream, const float *particle_F_tria
 /* dense reference-layout copies of grid_m [G^3], grid_v_in [G^3*3], grid_v_out [G^3*3] as they
  * stand after the last substep's grid stage ([dev] outputs, any may be NULL).  Synchronous. */
 int mpmhip_export_grid(mpmhip_ctx *ctx, float *grid_m, float *grid_v_in, float *grid_v_out);
-/* performance experiments only (kernel ablations, MPMHIP_DBG bit mask of csrc/fast.hip; most bits make the results wrong) */
+/* performance experiments only (kernel ablations, MPMHIP_DBG bit mask of csrc/fast.hip; most bits make the results wrong).
+ * The kernel switches exist only in -DMPMHIP_DEBUG=1 builds; the production build accepts bit 64 (host-side) alone. */
 int mpmhip_set_debug_flags(mpmhip_ctx *ctx, int32_t flags);
 int mpmhip_debug_counter(mpmhip_ctx *ctx, int32_t index, int64_t *out); /* device-side experiment counters, synchronous */
+/* per-workgroup timeline of the newest p2g (kernel 0) / g2p (kernel 1) launch: out[wg * 8 + slot] in ticks of the 100 MHz
+ * constant clock, slot 7 = (XCC_ID << 32) | HW_ID.  out == NULL starts recording.  Only libraries built with
+ * -DMPMHIP_DEBUG=1 carry the stamps (and the kernel switches of mpmhip_set_debug_flags); the production build returns
+ * MPMHIP_ERR_INVALID.  tools/gpu/wgtrace.py. */
+int mpmhip_debug_wgtrace(mpmhip_ctx *ctx, int32_t kernel, uint64_t *out, int32_t max_wg);
 /* counts for the algorithmic-bytes formula; synchronous, runs small count kernels */
 int mpmhip_get_stats(mpmhip_ctx *ctx, mpmhip_stats *out);
 /* MPMWARP.time_profile / print_time_profile, mpm_solver.py:16,538-541: when enabled every phase is

@@ -112,6 +112,7 @@ SIGNATURES = {
     "mpmhip_set_host_dt": (C.c_int, [vp, C.c_double]),
     "mpmhip_set_debug_flags": (C.c_int, [vp, C.c_int32]),
     "mpmhip_debug_counter": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_int64)]),
+    "mpmhip_debug_wgtrace": (C.c_int, [vp, C.c_int32, vp, C.c_int32]),
     "mpmhip_dist_halo_bytes": (C.c_int, [vp, C.POINTER(C.c_int64)]),
     "mpmhip_dist_halo_transport": (C.c_int, [vp, C.POINTER(C.c_int32)]),
     "mpmhip_export_grid": (C.c_int, [vp, vp, vp, vp]),

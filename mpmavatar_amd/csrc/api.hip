@@ -550,6 +550,12 @@ int mpmhip_debug_counter(mpmhip_ctx *c, int32_t index, int64_t *out) {
   return fast_debug_counter(c, index, out);
 }
 
+int mpmhip_debug_wgtrace(mpmhip_ctx *c, int32_t kernel, uint64_t *out, int32_t max_wg) {
+  if (!c) return MPMHIP_ERR_INVALID;
+  if (!fast_mode(c) || !c->fast) return fail(c, MPMHIP_ERR_INVALID, "debug_wgtrace: fast mode only");
+  return fast_debug_wgtrace(c, kernel, out, max_wg);
+}
+
 int mpmhip_get_stats(mpmhip_ctx *c, mpmhip_stats *out) {
   CHECK_CTX(c);
   if (!out) return fail(c, MPMHIP_ERR_INVALID, "get_stats: null");

@@ -51,11 +51,42 @@ constexpr int TILE = 8;        // tile edge in nodes: block (4) + 1 below + 3 ab
 constexpr int TILE3 = TILE * TILE * TILE;
 inline unsigned nblk(size_t n) { return n ? (unsigned)((n + TPB - 1) / TPB) : 1u; }  // never an empty grid: kernels bound-check
 
+// Kernel ablation switches and the per-workgroup timeline exist only in builds with -DMPMHIP_DEBUG=1
+// (tools/build_variants.py dbg:-DMPMHIP_DEBUG=1, selected with MPMHIP_LIB): the production kernels carry neither the
+// branches nor the stamps.
+#ifndef MPMHIP_DEBUG
+#define MPMHIP_DEBUG 0
+#endif
+#define DBG(g, bits) (MPMHIP_DEBUG && ((g).dbg & (bits)))
+constexpr int WGT_MAX_WG = 16384, WGT_SLOTS = 8, WGT_KERNELS = 3;  // per-workgroup timeline: [kernel][workgroup][slot]
+#if MPMHIP_DEBUG
+// slot <- constant 100 MHz clock (the same on every CU and XCD), after everything issued before has completed; slot 7 of a
+// workgroup holds where it ran (XCC_ID << 32 | HW_ID)
+#define WGT(g, k, slot)                                                                                       \
+  do {                                                                                                         \
+    if ((g).trace && threadIdx.x == 0 && blockIdx.x < (unsigned)WGT_MAX_WG) {                                    \
+      unsigned long long t_;                                                                                   \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+      (g).trace[((size_t)(k) * WGT_MAX_WG + blockIdx.x) * WGT_SLOTS + (slot)] = t_;                             \
+      if ((slot) == 0)                                                                                         \
+        (g).trace[((size_t)(k) * WGT_MAX_WG + blockIdx.x) * WGT_SLOTS + 7] =                                    \
+            ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492); \
+    }                                                                                                          \
+  } while (0)
+#else
+#define WGT(g, k, slot) do { } while (0)
+#endif
+
 // component-major array view: comp c of item i at p[c*n + i]
+// Addressing: (uniform component base) + (zero-extended 32-bit byte offset of the item) -- the form the global_load / global_store
+// "saddr" encoding takes (SGPR pair + one VGPR), instead of a 64-bit VGPR address per component (two more VGPRs and two more
+// VALU instructions per access with the signed 64-bit index p[c * n + i]).  Arrays stay below 2^30 items per component.
 struct Soa {
   float *p;
   int n;
-  __device__ __forceinline__ float &at(int c, int i) const { return p[(size_t)c * n + i]; }
+  __device__ __forceinline__ float &at(int c, int i) const {
+    return *reinterpret_cast<float *>(reinterpret_cast<char *>(p + (size_t)c * (size_t)n) + ((unsigned)i << 2));
+  }
 };
 __device__ __forceinline__ V3 ld3(const Soa &a, int c0, int i) { return v3(a.at(c0, i), a.at(c0 + 1, i), a.at(c0 + 2, i)); }
 __device__ __forceinline__ void st3(const Soa &a, int c0, int i, V3 v) {
@@ -345,6 +376,17 @@ __global__ void k_dilate(const int *plist, const int *rc, int cap_P, int NB, int
 // of its tile on the fly (node_update<false>) and the accumulators are cleared by extra workgroups of the next
 // substep's stress launch.
 // ------------------------------------------------------------------------------------------------
+// host-mapped signal words (FastState::h_sig / GridPtrs::host_sig)
+enum { SIG_PROGRESS = 1, SIG_DFLAG = 2, SIG_DSEQ = 3, SIG_RING0 = 8, SIG_RING_N = 16, SIG_WORDS = 32 };
+static_assert(SIG_RING0 + SIG_RING_N <= SIG_WORDS && (SIG_RING_N & (SIG_RING_N - 1)) == 0, "signal ring must fit its buffer");
+// device counters (GridPtrs::counters): [0] particles outside their tile margin, [1] dropped contributions, [2] [3] collider /
+// mover node counts, [4] active nodes, [5] a body face left its bin's tile (sticky), [6] drift flag (sticky; dist loops and the
+// copy + event scheme read it), [7] all-reduced drift flag, [8] [9] experiment counters, [10]-[12] peer links,
+// [CNT_PAR0 + 2 * parity + {0, 1}] the same two flags per substep parity: the kernels of substep s raise slot s & 1 and the
+// p2g launch of substep s + 1 posts and clears it, so a ring entry holds exactly the flags of ONE finished substep (a plain
+// snapshot of the sticky flags raced with the workgroups of the posting launch that raise them)
+enum { CNT_FACE = 5, CNT_DRIFT = 6, CNT_PAR0 = 16, CNT_N = 32 };
+
 struct GridPtrs {
   float *mv;        // [block][4][64]: m, momentum xyz
   float *vout;      // [block][4][64]: v_out xyz, m (copy kept for introspection)
@@ -354,10 +396,13 @@ struct GridPtrs {
   int *col_flag;    // [block] 1 = the body-face splat may have written this block's collider channels this substep
   int *m_flag;      // [block] 1 = p2g (or a halo sum) may have written this block's mass / momentum this substep
   int *counters;    // [0] particles outside their tile margin, [1] dropped contributions (inactive block)
-  int *host_sig;    // host-mapped pinned memory: [1] step_id of the newest k_p2g launch that started, [8 + (step_id & 15)] its
-  int step_id;      // flags (see k_p2g); [2], [3] the sharded loop's reduced flag and its sequence number (k_post_flag)
+  int *host_sig;    // host-mapped pinned memory: [SIG_PROGRESS] step_id of the newest k_p2g launch that started, [SIG_RING0 +
+  int step_id;      // (step_id & 15)] the flags of substep step_id - 1 (see k_p2g); [SIG_DFLAG], [SIG_DSEQ] the sharded loop's
+                    // reduced flag and its sequence number (k_post_flag)
   float lookahead;  // substeps the early warning of the adaptive re-sort looks ahead (k_p2g)
-  int dbg;          // MPMHIP_DBG bitmask (perf experiments only, results are wrong): 1 skip p2g flush, 2 skip the p2g
+  int stagger, stagger_groups, stagger_first;  // p2g: first-round workgroups wait (wave slot % groups) * stagger * 1024 cycles
+  unsigned long long *trace;  // per-workgroup timeline (MPMHIP_DEBUG builds, mpmhip_debug_wgtrace); null otherwise
+  int dbg;          // MPMHIP_DBG bitmask (MPMHIP_DEBUG builds only; perf experiments, results are wrong): 1 skip p2g flush, 2 skip the p2g
                     // scatter, 8 / 16 skip vertex-force / stress loads, 128 skip the LDS atomics only, 256 skip the splat workgroups, 2048 skip the clearing workgroups; 64 (results stay
                     // right) runs the stand-alone element finalize every substep instead of fusing it into the stress kernel
 };
@@ -373,22 +418,30 @@ struct GridParams {
   float col_friction_more[3] = {0.0f, 0.0f, 0.0f};
 };
 
+__device__ __forceinline__ void raise_drift(int *counters, int step_id) {
+  counters[CNT_DRIFT] = 1;
+  counters[CNT_PAR0 + 2 * (step_id & 1) + 1] = 1;
+}
+__device__ __forceinline__ void raise_face(int *counters, int step_id) {
+  counters[CNT_FACE] = 1;
+  counters[CNT_PAR0 + 2 * (step_id & 1)] = 1;
+}
+
 // One node of the grid stage.  ZERO = true consumes the accumulators (re-zeroes what it read); ZERO = false only reads
 // them (g2p evaluates nodes on the fly while it stages its tile, k_zero_blocks / the zeroing workgroups of the next
 // stress launch clear them afterwards).  Returns the node's v_out; m_out = accumulated mass.
+// (the four accumulator values come in as arguments so that a caller can have issued their loads earlier: g2p does,
+// together with its particle loads, to take one dependent memory level out of the head of every workgroup)
 template <bool ZERO>
-__device__ __forceinline__ V3 node_update(int blk, int l, const Dims &d, const GridPtrs &g, const GridParams &gp,
-                                          const BCList &bcl, float &m_out, int &ncol, int &nmov, bool use_col = true,
-                                          unsigned bc_mask = 0xffffffffu) {
-  float *pm = g.mv + ((size_t)blk * GCH_MV) * 64 + l;
-  float m = pm[0], px = pm[64], py = pm[128], pz = pm[192];
+__device__ __forceinline__ V3 node_finish(int blk, int l, float m, float px, float py, float pz, const Dims &d, const GridPtrs &g,
+                                          const GridParams &gp, const BCList &bcl, int &ncol, int &nmov, bool use_col,
+                                          unsigned bc_mask) {
   V3 v = v3(0, 0, 0);
   if (m > 1e-15f) {
     float inv = 1.0f / m;
     v = v3(px * inv + gp.dt * gp.gx, py * inv + gp.dt * gp.gy, pz * inv + gp.dt * gp.gz);
   }
   if (gp.damping < 1.0f) v = v - (1.0f - gp.damping) * v;
-  if (ZERO && (m != 0.0f || px != 0.0f || py != 0.0f || pz != 0.0f)) { pm[0] = 0.0f; pm[64] = 0.0f; pm[128] = 0.0f; pm[192] = 0.0f; }
   if (gp.has_col && use_col) {  // normalize_grid + collide, mpm_solver.py:882-917
     float *pc = g.col + ((size_t)blk * GCH_COL) * 64 + l;
     float wc = pc[0];
@@ -420,8 +473,17 @@ __device__ __forceinline__ V3 node_update(int blk, int l, const Dims &d, const G
         if ((bc_mask >> k) & 1u) apply_bc(bcl.bc[k], v, gxn, gyn, gzn, d.G, d.dx, gp.time, gp.dt, dense);
     }
   }
-  m_out = m;
   return v;
+}
+template <bool ZERO>
+__device__ __forceinline__ V3 node_update(int blk, int l, const Dims &d, const GridPtrs &g, const GridParams &gp,
+                                          const BCList &bcl, float &m_out, int &ncol, int &nmov, bool use_col = true,
+                                          unsigned bc_mask = 0xffffffffu) {
+  float *pm = g.mv + ((size_t)blk * GCH_MV) * 64 + l;
+  float m = pm[0], px = pm[64], py = pm[128], pz = pm[192];
+  if (ZERO && (m != 0.0f || px != 0.0f || py != 0.0f || pz != 0.0f)) { pm[0] = 0.0f; pm[64] = 0.0f; pm[128] = 0.0f; pm[192] = 0.0f; }
+  m_out = m;
+  return node_finish<ZERO>(blk, l, m, px, py, pz, d, g, gp, bcl, ncol, nmov, use_col, bc_mask);
 }
 
 // Stand-alone grid stage: writes v_out (and the node mass, for introspection).  ZERO = true is the classic form
@@ -491,7 +553,7 @@ __global__ __launch_bounds__(TPB) void k_zero_blocks(ZeroArgs z) { zero_blocks_w
 // finished elements earlier (re-sort, read-back, pre-p2g operations, joint-face splats, multi-GPU ghosts).
 template <bool FINALIZE>
 __global__ void k_stress_elem(Bufs b, F3 *ef, Dims d, float friction_coeff, const int *face_slot,
-                              const SortKey *skeys, int blk_bits, int *counters) {
+                              const SortKey *skeys, int blk_bits, int *counters, int step_id) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.n_e) return;
   if (b.sel[e] == 1) {  // not simulated (selection == 2 marks a ghost copy: stress yes, transfers no)
@@ -511,7 +573,7 @@ __global__ void k_stress_elem(Bufs b, F3 *ef, Dims d, float friction_coeff, cons
       int oz = 4 * (blk % d.NB) - 1, oy = 4 * ((blk / d.NB) % d.NB) - 1, ox = 4 * (blk / (d.NB * d.NB)) - 1;
       // (no look-ahead here: an element follows its three vertices, whose g2p raises the flag early, see g2p_write)
       int nbx = (int)(xe.x * d.inv_dx - 0.5f) - ox, nby = (int)(xe.y * d.inv_dx - 0.5f) - oy, nbz = (int)(xe.z * d.inv_dx - 0.5f) - oz;
-      if (b.sel[e] == 0 && ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u)) counters[6] = 1;
+      if (b.sel[e] == 0 && ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u)) raise_drift(counters, step_id);
     }
     V3 d3o = v3(b.el.at(E_D + 2, e), b.el.at(E_D + 5, e), b.el.at(E_D + 8, e));
     V3 d1 = x2 - x1, d2 = x3 - x1;
@@ -1022,14 +1084,14 @@ __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p
       base = tile_idx(lx, ly, lz);
     }
   }
-  if (!(g.dbg & 2) && __any(valid)) {  // wave-uniform: DPP needs converged lanes
+  if (!DBG(g, 2) && __any(valid)) {  // wave-uniform: DPP needs converged lanes
     SegMask sm = seg_masks(key);
     // STEPS scan steps sum windows of 2^STEPS lanes: lanes at distances 0, W, 2W, ... from their segment's tail issue
     unsigned long long tails = __ballot(sm.tail);
     int dist = __ffsll((unsigned long long)(tails >> (threadIdx.x & 63))) - 1;
     bool do_add = valid && (dist & ((1 << STEPS) - 1)) == 0;
-    if (g.dbg & 128) do_add = false;
-    if (g.dbg & 512) {  // measurement: lanes that issue LDS atomics per lane that holds a particle
+    if (DBG(g, 128)) do_add = false;
+    if (DBG(g, 512)) {  // measurement: lanes that issue LDS atomics per lane that holds a particle
       unsigned long long ba = __ballot(do_add), bv = __ballot(valid);
       if ((threadIdx.x & 63) == 0) { atomicAdd(g.counters + 8, __popcll(ba)); atomicAdd(g.counters + 9, __popcll(bv)); }
     }
@@ -1082,7 +1144,7 @@ __device__ __forceinline__ void p2g_flush(double *tile, int ox, int oy, int oz, 
     float m = (float)qd[0], px = (float)qd[TILE_PAD], py = (float)qd[2 * TILE_PAD], pz = (float)qd[3 * TILE_PAD];
     if (m == 0.0f && px == 0.0f && py == 0.0f && pz == 0.0f) continue;
     if (REZERO) { qd[0] = 0.0; qd[TILE_PAD] = 0.0; qd[2 * TILE_PAD] = 0.0; qd[3 * TILE_PAD] = 0.0; }
-    if (g.dbg & 1) continue;
+    if (DBG(g, 1)) continue;
     int x = ox + ti, y = oy + tj, z = oz + tk;
     if (!in_grid(x, y, z, d.G)) continue;
     int nb = blk_of(x, y, z, d.NB);
@@ -1202,12 +1264,12 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
     unsigned long long tails = __ballot(sm.tail);
     int dist = __ffsll((unsigned long long)(tails >> (l & 63))) - 1;
     bool do_add = tile_ok && (dist & 7) == 0;
-    if (g.dbg & 4096) { sm.m1 = sm.m2 = sm.m4 = sm.m8 = 0.0f; do_add = tile_ok; }
+    if (DBG(g, 4096)) { sm.m1 = sm.m2 = sm.m4 = sm.m8 = 0.0f; do_add = tile_ok; }
     __syncthreads();
     if (any) col_splat_scatter<0>(tile, s, on, a, sm, do_add, base);
     if (ok && !in_tile) {  // drifted out of the tile margin since the faces were binned
-      g.counters[6] = 1;
-      g.counters[5] = 1;  // ... which is what makes the next re-sort bin the faces again (rebin)
+      raise_drift(g.counters, g.step_id);
+      raise_face(g.counters, g.step_id);  // ... which is what makes the next re-sort bin the faces again (rebin)
 #pragma unroll 1
       for (int n = 0; n < 27; ++n) {
         int i = n / 9, j = (n / 3) % 3, k = n % 3;
@@ -1239,35 +1301,48 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
 // frames); their joint splat (weight, weight * joint velocity into the mover channels, mpm_solver.py:677-704) is a
 // second pass through the same LDS tile by the chunk that owns them instead of 27 x 4 scattered global atomics each.
 template <int STEPS, bool TRAD, bool JT>
-__global__ __launch_bounds__(PT) void k_p2g(Bufs b, VAdj va, const ChunkRec *recs, int n_chunks, Dims d, float rpic,
-                                             float dt, GridPtrs g, SplatArgs sa, TradParams tp) {
+__device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, const Bufs &b, const VAdj &va, const Dims &d, float rpic,
+                                         float dt, const GridPtrs &g, const SplatArgs &sa, const TradParams &tp) {
   __shared__ double tile[4 * TILE_PAD];
   __shared__ int esc[CHUNK];
   __shared__ int esc_n;
+  WGT(g, 0, 0);
   if (blockIdx.x == 0 && threadIdx.x == 0 && g.host_sig) {
     // progress + drift flag for the host (plain stores into pinned host memory instead of a copy + event every few
     // substeps: on the stream those cost a blit kernel and ~10-20 us of idle queue each).  Everything before this launch
-    // has completed, so step_id - 1 substeps are done and counters[6] holds every warning they raised.
+    // has completed, so substep step_id - 1 is done and its parity slot of the flags holds every warning it raised (final: the
+    // kernels of THIS substep raise the other slot); post it and clear it for substep step_id + 1.
     // One ring entry per launch -- (step_id, a body face left its bin's tile, drift flag) -- and the progress word after it.
     // The host decides at substep s with the entry of substep s - host_lead, whatever the GPU has done since: the re-sort
     // schedule is a function of the simulation, not of host / GPU timing, and a run stays bit-reproducible.
-    unsigned v = ((unsigned)g.step_id << 2) | (g.counters[5] != 0 ? 2u : 0u) | (g.counters[6] != 0 ? 1u : 0u);
-    __hip_atomic_store(g.host_sig + 8 + (g.step_id & 15), (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(g.host_sig + 1, g.step_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    int *prev = g.counters + CNT_PAR0 + 2 * ((g.step_id - 1) & 1);
+    unsigned v = ((unsigned)g.step_id << 2) | (prev[0] != 0 ? 2u : 0u) | (prev[1] != 0 ? 1u : 0u);
+    prev[0] = 0; prev[1] = 0;
+    __hip_atomic_store(g.host_sig + SIG_RING0 + (g.step_id & (SIG_RING_N - 1)), (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(g.host_sig + SIG_PROGRESS, g.step_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if ((int)blockIdx.x < sa.n_extra) {  // extra workgroups first: they are the long-latency ones
     int e = blockIdx.x;
-    if (g.dbg & 256) return;
-    if (e < sa.n_fbins) { if (!(g.dbg & 8192)) col_splat_wg(tile, sa, e, d, g); }   // (8192 / 16384: ablation switches)
-    else if (e < sa.n_fbins + sa.n_mov_wg) { if (!(g.dbg & 16384)) mover_splat_wg(b, sa.js, e - sa.n_fbins, d, g); }
+    if (DBG(g, 256)) return;
+    if (e < sa.n_fbins) { if (!DBG(g, 8192)) col_splat_wg(tile, sa, e, d, g); }   // (8192 / 16384: ablation switches)
+    else if (e < sa.n_fbins + sa.n_mov_wg) { if (!DBG(g, 16384)) mover_splat_wg(b, sa.js, e - sa.n_fbins, d, g); }
+    WGT(g, 0, 6);
     return;
   }
   if ((int)blockIdx.x >= sa.z_first) {  // ... and the clearing workgroups last: they fill the tail of the launch
-    if (!(g.dbg & 2048)) zero_blocks_wg(sa.z, (int)blockIdx.x - sa.z_first);
+    if (!DBG(g, 2048)) zero_blocks_wg(sa.z, (int)blockIdx.x - sa.z_first);
+    WGT(g, 0, 6);
     return;
   }
   int w = xcd_slice((int)blockIdx.x - sa.n_extra, n_chunks);
   if (w < 0) return;
+  if (g.stagger > 0 && (int)blockIdx.x < g.stagger_first) {
+    // The workgroups of the first round all start within a microsecond, load together and then scatter together: memory
+    // system and VALU / LDS pipelines take turns idling, and a first-round workgroup lives 12.4 us against 9.0 us for one
+    // of the desynchronised second round (profiles/r03_wg_timeline.md).  Stagger them per CU by the wave slot they landed in.
+    int slot = (int)(__builtin_amdgcn_s_getreg(63492) & 0xfu) % g.stagger_groups;
+    for (int i = 0; i < slot * g.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   const ChunkRec cm = recs[w];
   int blk = cm.blk, chunk = cm.chunk;
   int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
@@ -1276,8 +1351,9 @@ __global__ __launch_bounds__(PT) void k_p2g(Bufs b, VAdj va, const ChunkRec *rec
   bool valid = cm.map(chunk * CHUNK + (int)threadIdx.x, cls, s);
   // issue the particle loads before the tile is cleared so that their latency overlaps
   bool w_nv = __any(valid && cls != 2), w_v = __any(valid && cls == 2);
-  if (g.dbg & 8) w_v = false;
-  if (g.dbg & 16) w_nv = false;
+  if (DBG(g, 8)) w_v = false;
+  if (DBG(g, 16)) w_nv = false;
+  WGT(g, 0, 1);  // chunk record here
   P2GRaw raw = p2g_issue<TRAD>(b, va, valid, cls, s, d, w_nv, w_v);
   for (int t = threadIdx.x; t < 4 * TILE_PAD; t += PT) tile[t] = 0.0;
   if (threadIdx.x == 0) esc_n = 0;
@@ -1287,12 +1363,16 @@ __global__ __launch_bounds__(PT) void k_p2g(Bufs b, VAdj va, const ChunkRec *rec
     float la = g.lookahead * dt;
     int fx = (int)((raw.x.x + la * raw.v.x) * d.inv_dx - 0.5f) - ox, fy = (int)((raw.x.y + la * raw.v.y) * d.inv_dx - 0.5f) - oy,
         fz = (int)((raw.x.z + la * raw.v.z) * d.inv_dx - 0.5f) - oz;
-    if ((unsigned)fx > 5u || (unsigned)fy > 5u || (unsigned)fz > 5u) g.counters[6] = 1;
+    if ((unsigned)fx > 5u || (unsigned)fy > 5u || (unsigned)fz > 5u) raise_drift(g.counters, g.step_id);
   }
+  WGT(g, 0, 2);  // particle loads + first adjacency batch here, tile cleared
   P2GParticle q = p2g_finish<TRAD>(raw, b, va, valid, cls, s, d, rpic, dt, w_v, tp);
   __syncthreads();
+  WGT(g, 0, 3);  // corner forces gathered (and the fused traditional stress update done) in every wavefront
   p2g_scatter<STEPS>(tile, esc, &esc_n, q, valid, ox, oy, oz, d, g);
+  WGT(g, 0, 4);  // wavefront 0 through its scatter
   __syncthreads();
+  WGT(g, 0, 5);  // every wavefront through its scatter
   if (esc_n > 0) {
     for (int e = threadIdx.x; e < esc_n; e += PT) {
       int ec = 0, es = 0;
@@ -1302,6 +1382,7 @@ __global__ __launch_bounds__(PT) void k_p2g(Bufs b, VAdj va, const ChunkRec *rec
     }
   }
   p2g_flush<JT>(tile, ox, oy, oz, d, g);
+  WGT(g, 0, 6);  // flush atomics of wavefront 0 acknowledged
   if (JT) {
     // held = one of the last js.n_t traditional particles in the caller's order, with the reference's range check
     int jq = -1;
@@ -1336,6 +1417,22 @@ __global__ __launch_bounds__(PT) void k_p2g(Bufs b, VAdj va, const ChunkRec *rec
       p2g_flush<false, true>(tile, ox, oy, oz, d, g);
     }
   }
+}
+
+// The chunk records come first in the argument list: the record load is the head of every workgroup's dependency chain.
+template <int STEPS, bool TRAD, bool JT>
+__global__ __launch_bounds__(PT) void k_p2g(const ChunkRec *recs, int n_chunks, Bufs b, VAdj va, Dims d, float rpic, float dt,
+                                             GridPtrs g, SplatArgs sa, TradParams tp) {
+  p2g_body<STEPS, TRAD, JT>(recs, n_chunks, b, va, d, rpic, dt, g, sa, tp);
+}
+// The cloth instantiation with six wavefronts per SIMD instead of the five its 90 VGPRs allow: 80 VGPRs + 9 spilled dwords.
+// A workgroup's life is a chain of memory latencies (record -> particles -> adjacency -> corner forces) followed by a
+// VALU-bound scatter; with 5 workgroups per CU the headline scene's 2,700 chunks need a third round of the 1,280 slots
+// (profiles/r03_wg_timeline.md), with 6 they fit two rounds of 1,536.  (The instantiation with the fused traditional stress
+// update would spill 216 bytes per lane and keeps its natural budget.)
+__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6)))
+void k_p2g_w6(const ChunkRec *recs, int n_chunks, Bufs b, VAdj va, Dims d, float rpic, float dt, GridPtrs g, SplatArgs sa, TradParams tp) {
+  p2g_body<3, false, false>(recs, n_chunks, b, va, d, rpic, dt, g, sa, tp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1518,7 +1615,7 @@ __device__ __forceinline__ void g2p_write(const Bufs &b, int cls, int s, V3 x, V
      // fit DRIFT_LOOKAHEAD substeps from now -- is raised by the next p2g, where x and v are in registers anyway; here
      // it cost hipcc 18-50 more VGPRs and an occupancy step.)
     int nbx = (int)(nx.x * d.inv_dx - 0.5f) - ox, nby = (int)(nx.y * d.inv_dx - 0.5f) - oy, nbz = (int)(nx.z * d.inv_dx - 0.5f) - oz;
-    if ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u) g.counters[6] = 1;
+    if ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u) raise_drift(g.counters, g.step_id);
   }
   if (cls == 1 && !NO_GRAD) g2p_write_grad(b, cls, s, d3, r.F, d, dt);
 }
@@ -1531,10 +1628,14 @@ __device__ __forceinline__ void g2p_write(const Bufs &b, int cls, int s, V3 x, V
 // latter only by wavefronts that hold elements or traditional particles.  12 + 9 instead of 21 accumulators at a time:
 // 95 instead of 114 VGPRs, a fifth wavefront per SIMD.  Pays when many lanes are vertices (cloth scenes: a third of the
 // particles skip the second sweep); traditional-only scenes read every node twice and keep the single sweep.
-template <bool FUSED, bool TWO_PASS>
-__global__ __launch_bounds__(PT) void k_g2p(Bufs b, const ChunkRec *recs, int n_chunks, Dims d, float dt, GridPtrs g,
-                                             GridParams gp, BCList bcl) {
+// MFLAG = false: the accumulators of all 27 overlapped blocks are loaded as soon as the chunk record is there, without first
+// asking m_flag which of them were scattered into (the ~70 % that were not read back zeros from L2).  One dependent memory
+// level less at the head of every workgroup for more L2 traffic; node values are identical (an unflagged block holds zeros).
+template <bool FUSED, bool TWO_PASS, bool MFLAG>
+__device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, const Bufs &b, const Dims &d, float dt, const GridPtrs &g,
+                                         const GridParams &gp, const BCList &bcl) {
   __shared__ float4 tile[TILE_PAD];  // node velocity, 16 bytes per node
+  WGT(g, 1, 0);
   int w = xcd_slice(blockIdx.x, n_chunks);
   if (w < 0) return;
   const ChunkRec cm = recs[w];
@@ -1543,14 +1644,34 @@ __global__ __launch_bounds__(PT) void k_g2p(Bufs b, const ChunkRec *recs, int n_
   int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
   int cls = 0, s = 0;
   bool valid = cm.map(chunk * CHUNK + (int)threadIdx.x, cls, s);
-  // particle loads first: their latency overlaps the tile staging below
-  V3 x = v3(0, 0, 0), d3 = v3(0, 0, 0);
-  bool escaped = false;
-  if (valid) {
-    x = ld3(b.all, A_X, s);
-    if (cls == 0) d3 = v3(b.el.at(E_D + 2, s), b.el.at(E_D + 5, s), b.el.at(E_D + 8, s));
-    int lx = (int)(x.x * d.inv_dx - 0.5f) - ox, ly = (int)(x.y * d.inv_dx - 0.5f) - oy, lz = (int)(x.z * d.inv_dx - 0.5f) - oz;
-    escaped = (unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u;  // drifted out of the tile margin
+  // Everything that depends on the chunk record alone is loaded NOW, back to back and without a branch in between: the
+  // particle's position (and director), and -- MFLAG = false -- the accumulators of this thread's two tile nodes.  (With the
+  // loads behind `if (valid)` / behind the flag ballots the compiler cannot issue them before the first wait, and every
+  // dependent memory level costs a workgroup 1.3-1.5 us: profiles/r03_wg_timeline.md.)
+  V3 x, d3;
+  {
+    int sx = valid ? s : 0, se = (valid && cls == 0) ? s : 0;
+    x = ld3(b.all, A_X, sx);
+    d3 = v3(b.el.at(E_D + 2, se), b.el.at(E_D + 5, se), b.el.at(E_D + 8, se));
+  }
+  constexpr int NPT = TILE3 / PT;  // tile nodes per thread
+  int nbk[NPT], nlk[NPT];
+  float am[NPT], apx[NPT], apy[NPT], apz[NPT];
+#pragma unroll
+  for (int u = 0; u < NPT; ++u) {
+    int t = (int)threadIdx.x + u * PT;
+    int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
+    int gx = ox + ti, gy = oy + tj, gz = oz + tk;
+    bool in = in_grid(gx, gy, gz, d.G);
+    nbk[u] = in ? blk_of(gx, gy, gz, d.NB) : -1;
+    nlk[u] = loc_of(gx, gy, gz);
+    am[u] = apx[u] = apy[u] = apz[u] = 0.0f;
+    if (FUSED && !MFLAG) {  // (all 27 overlapped blocks of a particle block are on the active list: cleared or loaded;
+                            // a node outside the grid reads this block's instead -- no branch around the loads -- and drops it)
+      const float *pm = g.mv + ((size_t)(in ? nbk[u] : blk) * GCH_MV) * 64 + nlk[u];
+      float a0 = pm[0], a1 = pm[64], a2 = pm[128], a3 = pm[192];
+      am[u] = in ? a0 : 0.0f; apx[u] = in ? a1 : 0.0f; apy[u] = in ? a2 : 0.0f; apz[u] = in ? a3 : 0.0f;
+    }
   }
   // tile-level shortcuts for the fused node evaluation (both wave-uniform): which of the 27 overlapped blocks may
   // carry body-collider data this substep (flags set by the splat), and which BCs can reach this tile at all
@@ -1561,27 +1682,38 @@ __global__ __launch_bounds__(PT) void k_g2p(Bufs b, const ChunkRec *recs, int n_
     if (l < 27) {
       int nx = bx + l / 9 - 1, ny = by + (l / 3) % 3 - 1, nz = bz + l % 3 - 1;
       if ((unsigned)nx < (unsigned)d.NB && (unsigned)ny < (unsigned)d.NB && (unsigned)nz < (unsigned)d.NB) {
-        fm = g.m_flag[(nx * d.NB + ny) * d.NB + nz];
+        if (MFLAG) fm = g.m_flag[(nx * d.NB + ny) * d.NB + nz];
         if (gp.has_col) fl = g.col_flag[(nx * d.NB + ny) * d.NB + nz];
       }
     }
-    col_mask = __ballot(fl != 0);
-    m_mask = __ballot(fm != 0);  // a block nobody scattered into: its nodes carry no mass, hence no weight in any gather
+    if (gp.has_col) col_mask = __ballot(fl != 0);
+    m_mask = MFLAG ? __ballot(fm != 0) : ~0ull;  // a block nobody scattered into: its nodes carry no mass, hence no weight in any gather
     for (int k = 0; k < bcl.n; ++k)
       if (bc_may_touch(bcl.bc[k], ox, oy, oz, ox + 7, oy + 7, oz + 7, d.G, d.dx, gp.time, gp.dt)) bc_mask |= 1u << k;
   }
+  bool escaped = false;
+  if (valid) {
+    int lx = (int)(x.x * d.inv_dx - 0.5f) - ox, ly = (int)(x.y * d.inv_dx - 0.5f) - oy, lz = (int)(x.z * d.inv_dx - 0.5f) - oz;
+    escaped = (unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u;  // drifted out of the tile margin
+  }
+  WGT(g, 1, 1);  // chunk record, particle positions, block flags (and, MFLAG = false, the accumulators) here
 #pragma unroll
-  for (int t = threadIdx.x; t < TILE3; t += PT) {
+  for (int u = 0; u < NPT; ++u) {
+    int t = (int)threadIdx.x + u * PT;
     int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
-    int gx = ox + ti, gy = oy + tj, gz = oz + tk;
     V3 v = v3(0, 0, 0);
-    if (in_grid(gx, gy, gz, d.G)) {
-      int nb = blk_of(gx, gy, gz, d.NB), nl = loc_of(gx, gy, gz);
+    if (nbk[u] >= 0) {
+      int nb = nbk[u], nl = nlk[u];
       if (FUSED) {
-        float m;
         int nc = 0, nm = 0;
-        int nidx = (((gx >> 2) - bx + 1) * 3 + ((gy >> 2) - by + 1)) * 3 + ((gz >> 2) - bz + 1);
-        if ((m_mask >> nidx) & 1ull) v = node_update<false>(nb, nl, d, g, gp, bcl, m, nc, nm, (col_mask >> nidx) & 1ull, bc_mask);
+        int nidx = ((((ox + ti) >> 2) - bx + 1) * 3 + (((oy + tj) >> 2) - by + 1)) * 3 + (((oz + tk) >> 2) - bz + 1);
+        bool uc = (col_mask >> nidx) & 1ull;
+        if (!MFLAG) {
+          v = node_finish<false>(nb, nl, am[u], apx[u], apy[u], apz[u], d, g, gp, bcl, nc, nm, uc, bc_mask);
+        } else if ((m_mask >> nidx) & 1ull) {
+          float m;
+          v = node_update<false>(nb, nl, d, g, gp, bcl, m, nc, nm, uc, bc_mask);
+        }
       } else {
         const float *p = g.vout + ((size_t)nb * GCH_VOUT) * 64 + nl;
         v = v3(p[0], p[64], p[128]);
@@ -1589,7 +1721,9 @@ __global__ __launch_bounds__(PT) void k_g2p(Bufs b, const ChunkRec *recs, int n_
     }
     tile[tile_idx(ti, tj, tk)] = make_float4(v.x, v.y, v.z, 0.0f);
   }
+  WGT(g, 1, 2);  // wavefront 0 has staged its nodes (accumulator loads + grid stage)
   __syncthreads();
+  WGT(g, 1, 3);  // tile complete
   {
     // lanes without a particle in the tile margin gather from the tile corner (in range, result unused)
     bool fit = valid && !escaped;
@@ -1607,6 +1741,7 @@ __global__ __launch_bounds__(PT) void k_g2p(Bufs b, const ChunkRec *recs, int n_
         g2p_gather_vC(tile, ox, oy, oz, xg, d, r.v, r.C);
         if (fit) g2p_write<true>(b, cls, s, x, d3, r, ox, oy, oz, d, dt, g);
       }
+      WGT(g, 1, 4);  // first sweep (v, C) of wavefront 0 stored
       if (__any(fit && cls != 2)) {  // elements and traditional particles also need grad v
         asm volatile("" : "+v"(xg.x), "+v"(xg.y), "+v"(xg.z));  // a fresh stencil: nothing of the first sweep stays live
         M3 rF = g2p_gather_grad(tile, ox, oy, oz, xg, d);
@@ -1626,10 +1761,22 @@ __global__ __launch_bounds__(PT) void k_g2p(Bufs b, const ChunkRec *recs, int n_
       atomicAdd(g.counters + 0, 1);
     }
   }
+  WGT(g, 1, 6);
+}
+template <bool FUSED, bool TWO_PASS, bool MFLAG>
+__global__ __launch_bounds__(PT) void k_g2p(const ChunkRec *recs, int n_chunks, Bufs b, Dims d, float dt, GridPtrs g, GridParams gp,
+                                             BCList bcl) {
+  g2p_body<FUSED, TWO_PASS, MFLAG>(recs, n_chunks, b, d, dt, g, gp, bcl);
+}
+// six wavefronts per SIMD for the fused two-pass form (94 VGPRs -> 80 + 12 spilled dwords), see k_p2g_w6
+template <bool MFLAG>
+__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6)))
+void k_g2p_w6(const ChunkRec *recs, int n_chunks, Bufs b, Dims d, float dt, GridPtrs g, GridParams gp, BCList bcl) {
+  g2p_body<true, true, MFLAG>(recs, n_chunks, b, d, dt, g, gp, bcl);
 }
 
 // second half of g2p_e (mpm_utils.py:838-857): x, v = mean of the three updated vertices; d1, d2 = edges
-__global__ void k_elem_finalize(Bufs b, const int *face_slot, const SortKey *skeys, int blk_bits, int *counters, Dims d) {
+__global__ void k_elem_finalize(Bufs b, const int *face_slot, const SortKey *skeys, int blk_bits, int *counters, Dims d, int step_id) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.n_e) return;
   if (b.sel[e] == 1) return;
@@ -1644,7 +1791,7 @@ __global__ void k_elem_finalize(Bufs b, const int *face_slot, const SortKey *ske
     int blk = key_block(skeys[e], blk_bits);
     int oz = 4 * (blk % d.NB) - 1, oy = 4 * ((blk / d.NB) % d.NB) - 1, ox = 4 * (blk / (d.NB * d.NB)) - 1;
     int nbx = (int)(xe.x * d.inv_dx - 0.5f) - ox, nby = (int)(xe.y * d.inv_dx - 0.5f) - oy, nbz = (int)(xe.z * d.inv_dx - 0.5f) - oz;
-    if (!ghost && ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u)) counters[6] = 1;
+    if (!ghost && ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u)) raise_drift(counters, step_id);
   }
   V3 d1 = x2 - x1, d2 = x3 - x1;
   b.el.at(E_D + 0, e) = d1.x; b.el.at(E_D + 3, e) = d1.y; b.el.at(E_D + 6, e) = d1.z;
@@ -1773,9 +1920,9 @@ __global__ void k_link_check(const unsigned *data, int n, const int *flag, int s
 
 // the all-reduced drift flag of the sharded loop -> pinned host memory: value first, then its sequence number
 __global__ void k_post_flag(const int *value, int *host_sig, int seq) {
-  __hip_atomic_store(host_sig + 2, *value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(host_sig + SIG_DFLAG, *value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __threadfence_system();
-  __hip_atomic_store(host_sig + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(host_sig + SIG_DSEQ, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ void k_link_verdict(int *counters) { counters[12] = (counters[10] != 0 || counters[11] != 0) ? 1 : 0; }
 
@@ -1961,7 +2108,10 @@ struct FastState {
   Dims d{};
   bool dist = false;  // multi-GPU: re-sorts only on request (all ranks re-sort together)
   bool dist_keep_cur = false;  // re-sort inside mpmhip_rccl_steps: the caller's mesh pointers are valid
-  bool g2p_two_pass = false;   // k_g2p<., true>: see there (default: scenes without traditional particles)
+  bool g2p_two_pass = false;   // k_g2p<., true, .>: see there (default: scenes without traditional particles)
+  bool w6 = false;             // six-wavefront builds of the cloth kernels (k_p2g_w6, k_g2p_w6): MPMHIP_W6
+  bool g2p_mflag = false;      // g2p asks m_flag before it loads a block's accumulators (one more dependent memory level at the head
+                               // of every workgroup; the default loads them with the particle positions): MPMHIP_G2P_MFLAG=1
   // adaptive collective re-sorts (mpmhip_rccl_steps with rebin_interval <= 0): the ranks' drift flags are max-reduced
   // every DIST_POLL substeps and read DIST_LAG substeps later, so every rank takes the same decision at the same substep
   int dist_since = 0;
@@ -2146,7 +2296,7 @@ int flush_elements(mpmhip_ctx *c) {
   FastState *f = c->fast;
   if (f->elem_pending && f->d.n_e)
     hipLaunchKernelGGL(k_elem_finalize, nblk(f->d.n_e), TPB, 0, c->stream, f->buf[f->cur], f->face_slot, f->keys[1],
-                       f->blk_bits, f->g.counters, f->d);
+                       f->blk_bits, f->g.counters, f->d, f->g.step_id);
   f->elem_pending = false;
   return MPMHIP_OK;
 }
@@ -2268,7 +2418,7 @@ int rebin(mpmhip_ctx *c) {
     MPM_HIP_CHECK(c, hipMemsetAsync(f->fb_cnt, 0, f->nblocks * sizeof(int), s));
     hipLaunchKernelGGL(k_face_bins, nblk(nf), TPB, 0, s, f->fkeys[1], nf, f->fb_start, f->fb_cnt);
     hipLaunchKernelGGL(k_face_sorted_idx, nblk(nf), TPB, 0, s, c->mesh_idx, f->forder, nf, f->fidx);
-    MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + 5, 0, sizeof(int), s));
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + CNT_FACE, 0, sizeof(int), s));
     f->rebins_since_face_sort = 0;
     f->face_flag_seen = false;
   } else if (with_faces) {
@@ -2343,7 +2493,8 @@ int rebin(mpmhip_ctx *c) {
     fprintf(stderr, "[mpmhip] re-sort %ld: %d particle blocks, %d active blocks, %zu chunks (<=32: %d, <=64: %d, <=128: %d, <256: %d, full: %d), lead %.1f\n",
             (long)f->rebins, f->n_P, f->n_A, hc.size(), hist[0], hist[1], hist[2], hist[3], hist[4], f->lead_steps);
   }
-  MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + 6, 0, sizeof(int), s));
+  MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + CNT_DRIFT, 0, sizeof(int), s));
+  MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + CNT_PAR0, 0, 4 * sizeof(int), s));  // (ring entries up to sig_at_rebin are ignored anyway)
   f->h_pin[24] = 0;
   f->flag_pending = false;
   f->sig_at_rebin = f->sig_seq;  // ring entries of earlier substeps speak about the old order
@@ -2394,7 +2545,7 @@ int fast_init(mpmhip_ctx *c) {
   }
   select_buffer(f, 0);
   if ((rc = dalloc(c, &f->g.vout, f->nblocks * GCH_VOUT * 64))) return rc;
-  if ((rc = dalloc(c, &f->g.counters, 16))) return rc;
+  if ((rc = dalloc(c, &f->g.counters, CNT_N))) return rc;
   // one allocation, one memset per re-sort: [particle-block flags | active-block flags | device counts]
   static_assert(RC_N <= 64, "device counts of a re-sort");
   if ((rc = dalloc(c, &f->pb_flag, 2 * f->nblocks + 64))) return rc;
@@ -2403,17 +2554,25 @@ int fast_init(mpmhip_ctx *c) {
   if ((rc = dalloc(c, &f->pb_index, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->ab_index, f->nblocks))) return rc;
   f->g.ab_flag = f->ab_flag;
-  if (const char *e = getenv("MPMHIP_DBG")) f->g.dbg = (int)strtoul(e, nullptr, 0);
+  if (const char *e = getenv("MPMHIP_DBG")) f->g.dbg = MPMHIP_DEBUG ? (int)strtoul(e, nullptr, 0) : ((int)strtoul(e, nullptr, 0) & 64);
   if (const char *e = getenv("MPMHIP_FUSE_GRID")) f->fuse_grid = atoi(e) != 0;
   f->g2p_two_pass = cfg.n_particles - cfg.n_elements - cfg.n_vertices == 0;
   if (const char *e = getenv("MPMHIP_G2P_TWO_PASS")) f->g2p_two_pass = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_FUSE_TRAD")) f->fuse_trad = atoi(e) != 0;
+  if (const char *e = getenv("MPMHIP_W6")) f->w6 = atoi(e) != 0;
+  f->g.stagger = 0; f->g.stagger_groups = 2; f->g.stagger_first = 0;
+  if (const char *e = getenv("MPMHIP_P2G_STAGGER")) {  // "units[,groups[,first]]": units of 1024 cycles per group step
+    int u = 0, gr = 2, first = 1280;
+    sscanf(e, "%d,%d,%d", &u, &gr, &first);
+    f->g.stagger = std::max(0, u); f->g.stagger_groups = std::max(1, gr); f->g.stagger_first = std::max(0, first);
+  }
+  if (const char *e = getenv("MPMHIP_G2P_MFLAG")) f->g2p_mflag = atoi(e) != 0;
   MPM_HIP_CHECK(c, hipHostMalloc((void **)&f->h_pin, 64 * sizeof(int), hipHostMallocDefault));
   MPM_HIP_CHECK(c, hipEventCreateWithFlags(&f->ev_flag, hipEventDisableTiming));
   {
     int *hs = nullptr, *ds = nullptr;
-    MPM_HIP_CHECK(c, hipHostMalloc((void **)&hs, 16 * sizeof(int), hipHostMallocMapped));
-    memset(hs, 0, 16 * sizeof(int));
+    MPM_HIP_CHECK(c, hipHostMalloc((void **)&hs, SIG_WORDS * sizeof(int), hipHostMallocMapped));
+    memset(hs, 0, SIG_WORDS * sizeof(int));
     MPM_HIP_CHECK(c, hipHostGetDevicePointer((void **)&ds, hs, 0));
     f->h_sig = hs;
     f->g.host_sig = getenv("MPMHIP_FLAG_COPY") ? nullptr : ds;  // MPMHIP_FLAG_COPY=1: the former copy + event poll (A/B)
@@ -2498,13 +2657,24 @@ int fast_pull(mpmhip_ctx *c) {
   do {                                                                           \
     if ((trad) && (jt)) hipLaunchKernelGGL((k_p2g<3, true, true>), __VA_ARGS__); \
     else if (trad) hipLaunchKernelGGL((k_p2g<3, true, false>), __VA_ARGS__);     \
+    else if (f->w6) hipLaunchKernelGGL(k_p2g_w6, __VA_ARGS__);                   \
     else hipLaunchKernelGGL((k_p2g<3, false, false>), __VA_ARGS__);              \
   } while (0)
 
-#define G2P_LAUNCH(fused, two, ...)                                             \
-  do {                                                                         \
-    if (two) hipLaunchKernelGGL((k_g2p<fused, true>), __VA_ARGS__);            \
-    else hipLaunchKernelGGL((k_g2p<fused, false>), __VA_ARGS__);               \
+#define G2P_LAUNCH(fused, two, ...)                                                              \
+  do {                                                                                          \
+    if (!(fused)) {                                                                             \
+      if (two) hipLaunchKernelGGL((k_g2p<false, true, true>), __VA_ARGS__);                     \
+      else hipLaunchKernelGGL((k_g2p<false, false, true>), __VA_ARGS__);                        \
+    } else if (f->g2p_mflag) {                                                                  \
+      if ((two) && f->w6) hipLaunchKernelGGL((k_g2p_w6<true>), __VA_ARGS__);                    \
+      else if (two) hipLaunchKernelGGL((k_g2p<true, true, true>), __VA_ARGS__);                 \
+      else hipLaunchKernelGGL((k_g2p<true, false, true>), __VA_ARGS__);                         \
+    } else {                                                                                    \
+      if ((two) && f->w6) hipLaunchKernelGGL((k_g2p_w6<false>), __VA_ARGS__);                   \
+      else if (two) hipLaunchKernelGGL((k_g2p<true, true, false>), __VA_ARGS__);                \
+      else hipLaunchKernelGGL((k_g2p<true, false, false>), __VA_ARGS__);                        \
+    }                                                                                           \
   } while (0)
 
 static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
@@ -2541,17 +2711,17 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       // host_lead substeps after the launch that posted it (the copy + event scheme: 8-16) -- inside the look-ahead.
       const unsigned e = f->sig_seq + 1u - (unsigned)f->host_lead;  // the substep whose ring entry decides now
       bool arrived = true;
-      for (long spins = 0; (int)((unsigned)f->h_sig[1] - e) < 0; ++spins) {
+      for (long spins = 0; (int)((unsigned)f->h_sig[SIG_PROGRESS] - e) < 0; ++spins) {
         if ((spins & 0x3ff) == 0x3ff) {
           hipError_t q = hipStreamQuery(s);
-          if (q == hipSuccess) { arrived = (int)((unsigned)f->h_sig[1] - e) >= 0; break; }  // nothing in flight any more
+          if (q == hipSuccess) { arrived = (int)((unsigned)f->h_sig[SIG_PROGRESS] - e) >= 0; break; }  // nothing in flight any more
           if (q != hipErrorNotReady) MPM_HIP_CHECK(c, q);
         }
         std::this_thread::yield();
       }
       std::atomic_thread_fence(std::memory_order_acquire);
       if (arrived && (int)(e - f->sig_at_rebin) > 0) {  // an entry written after the last re-sort
-        unsigned v = (unsigned)f->h_sig[8 + (e & 15u)];
+        unsigned v = (unsigned)f->h_sig[SIG_RING0 + (e & (unsigned)(SIG_RING_N - 1))];
         if ((v >> 2) == (e & 0x3fffffffu)) {
           if (v & 2u) f->face_flag_seen = true;
           if ((v & 1u) && f->adaptive_rebin) f->steps_since_rebin = 1 << 30;
@@ -2625,10 +2795,10 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     if (d.n_e) {
       if (f->elem_pending)
         hipLaunchKernelGGL(k_stress_elem<true>, nblk(d.n_e), TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff, f->face_slot,
-                           f->keys[1], f->blk_bits, f->g.counters);
+                           f->keys[1], f->blk_bits, f->g.counters, f->g.step_id);
       else
         hipLaunchKernelGGL(k_stress_elem<false>, nblk(d.n_e), TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff, f->face_slot,
-                           f->keys[1], f->blk_bits, f->g.counters);
+                           f->keys[1], f->blk_bits, f->g.counters, f->g.step_id);
       f->elem_pending = false;
     }
     if (d.n_t && !trad_fused) hipLaunchKernelGGL(k_stress_trad, nblk(d.n_t), TPB, 0, s, b, d, c->sc, dt);
@@ -2637,7 +2807,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     {
       ScopedPhase ph(c, "p2g");
       if (f->n_chunks)
-        P2G_LAUNCH(false, false, xcd_grid(f->n_chunks), PT, 0, s, b, f->va(), f->chunks, f->n_chunks, d,
+        P2G_LAUNCH(false, false, xcd_grid(f->n_chunks), PT, 0, s, f->chunks, f->n_chunks, b, f->va(), d,
                    c->sc.rpic_damping, dt, f->g, none, tp);
     }
     if (sa.n_fbins) {
@@ -2646,7 +2816,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       only.n_mov_wg = 0;
       only.n_extra = (only.n_fbins + 7) & ~7;
       only.z_first = 1 << 30;
-      P2G_LAUNCH(false, false, (unsigned)only.n_extra, PT, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only, tp);
+      P2G_LAUNCH(false, false, (unsigned)only.n_extra, PT, 0, s, f->chunks, 0, b, f->va(), d, c->sc.rpic_damping, dt, f->g, only, tp);
     }
     if (sa.n_mov_wg) {
       ScopedPhase ph(c, "apply_Particle_Moving_on_grid");
@@ -2654,13 +2824,13 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       only.n_fbins = 0;
       only.n_extra = (only.n_mov_wg + 7) & ~7;
       only.z_first = 1 << 30;
-      P2G_LAUNCH(false, false, (unsigned)only.n_extra, PT, 0, s, b, f->va(), f->chunks, 0, d, c->sc.rpic_damping, dt, f->g, only, tp);
+      P2G_LAUNCH(false, false, (unsigned)only.n_extra, PT, 0, s, f->chunks, 0, b, f->va(), d, c->sc.rpic_damping, dt, f->g, only, tp);
     }
   } else {
     ScopedPhase ph(c, "p2g");
     if (f->n_chunks || sa.n_extra || sa.z.n_wg)
-      P2G_LAUNCH(trad_fused, jt_tile, xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg), PT, 0, s, b, f->va(), f->chunks,
-                 f->n_chunks, d, c->sc.rpic_damping, dt, f->g, sa, tp);
+      P2G_LAUNCH(trad_fused, jt_tile, xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg), PT, 0, s, f->chunks,
+                 f->n_chunks, b, f->va(), d, c->sc.rpic_damping, dt, f->g, sa, tp);
   }
   return MPMHIP_OK;
 }
@@ -2695,9 +2865,9 @@ static int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
     ScopedPhase ph(c, "g2p_v");
     if (f->n_chunks_g) {
       if (fused)
-        G2P_LAUNCH(true, f->g2p_two_pass, xcd_grid(f->n_chunks_g), PT, 0, s, b, f->chunks_g, f->n_chunks_g, d, dt, f->g, gp, bcl);
+        G2P_LAUNCH(true, f->g2p_two_pass, xcd_grid(f->n_chunks_g), PT, 0, s, f->chunks_g, f->n_chunks_g, b, d, dt, f->g, gp, bcl);
       else
-        G2P_LAUNCH(false, f->g2p_two_pass, xcd_grid(f->n_chunks_g), PT, 0, s, b, f->chunks_g, f->n_chunks_g, d, dt, f->g, gp, bcl);
+        G2P_LAUNCH(false, f->g2p_two_pass, xcd_grid(f->n_chunks_g), PT, 0, s, f->chunks_g, f->n_chunks_g, b, d, dt, f->g, gp, bcl);
     }
   }
   if (fused) {
@@ -3115,17 +3285,17 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
     c->cur_f = (a.mesh_x && a.mesh_v) ? a.mesh_f : 0.0f;
     if (adaptive && f->dflag_pending && idx >= f->dflag_check_at) {
       if (f->g.host_sig) {  // posted by k_post_flag: wait for THIS reduction's sequence number, then read its value
-        for (long spins = 0; (unsigned)f->h_sig[3] != f->dflag_seq; ++spins) {
+        for (long spins = 0; (unsigned)f->h_sig[SIG_DSEQ] != f->dflag_seq; ++spins) {
           if ((spins & 0x3ff) == 0x3ff) {
             hipError_t e = hipStreamQuery(c->stream);
-            if (e == hipSuccess && (unsigned)f->h_sig[3] != f->dflag_seq)
+            if (e == hipSuccess && (unsigned)f->h_sig[SIG_DSEQ] != f->dflag_seq)
               return fail(c, MPMHIP_ERR_HIP, "rccl_steps: the reduced drift flag never reached host memory");
             if (e != hipSuccess && e != hipErrorNotReady) MPM_HIP_CHECK(c, e);
           }
           std::this_thread::yield();
         }
         std::atomic_thread_fence(std::memory_order_acquire);
-        if (f->h_sig[2]) f->dist_resort = true;
+        if (f->h_sig[SIG_DFLAG]) f->dist_resort = true;
       } else {
         MPM_HIP_CHECK(c, hipEventSynchronize(f->ev_flag));
         if (f->h_pin[26]) f->dist_resort = true;
@@ -3210,7 +3380,32 @@ int fast_export_grid(mpmhip_ctx *c, float *m, float *v_in, float *v_out) {
 }
 
 int fast_set_debug_flags(mpmhip_ctx *c, int flags) {
+  // bit 64 (stand-alone element finalize every substep; results stay right) is a host-side switch and exists in every build
+  if (!MPMHIP_DEBUG && (flags & ~64))
+    return fail(c, MPMHIP_ERR_INVALID, "set_debug_flags: this build carries no kernel ablation switches (build a variant with "
+                                       "-DMPMHIP_DEBUG=1, tools/build_variants.py, and select it with MPMHIP_LIB)");
   c->fast->g.dbg = flags;
+  return MPMHIP_OK;
+}
+// Per-workgroup timeline of the p2g (kernel 0) and g2p (kernel 1) launches, MPMHIP_DEBUG builds only.  out == nullptr: start
+// recording (stamps of earlier launches are cleared); otherwise copy the stamps of the newest launch of `kernel`:
+// out[wg * 8 + slot], slots as placed by WGT() in the kernels, in ticks of the 100 MHz constant clock.
+int fast_debug_wgtrace(mpmhip_ctx *c, int kernel, uint64_t *out, int max_wg) {
+  FastState *f = c->fast;
+  if (!MPMHIP_DEBUG) return fail(c, MPMHIP_ERR_INVALID, "debug_wgtrace: needs a -DMPMHIP_DEBUG=1 build of the library");
+  const size_t total = (size_t)WGT_KERNELS * WGT_MAX_WG * WGT_SLOTS;
+  if (!out) {
+    if (!f->g.trace) {
+      int rc = dalloc(c, &f->g.trace, total);
+      if (rc) return rc;
+    }
+    MPM_HIP_CHECK(c, hipMemsetAsync(f->g.trace, 0, total * sizeof(unsigned long long), c->stream));
+    return MPMHIP_OK;
+  }
+  if (kernel < 0 || kernel >= WGT_KERNELS || max_wg <= 0 || !f->g.trace) return fail(c, MPMHIP_ERR_INVALID, "debug_wgtrace: bad arguments");
+  MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  size_t n = (size_t)std::min(max_wg, WGT_MAX_WG) * WGT_SLOTS;
+  MPM_HIP_CHECK(c, hipMemcpy(out, f->g.trace + (size_t)kernel * WGT_MAX_WG * WGT_SLOTS, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return MPMHIP_OK;
 }
 int fast_debug_counter(mpmhip_ctx *c, int index, int64_t *out) {

@@ -147,6 +147,9 @@ class ShardedSim:
     static: dict = field(default_factory=dict)
     global_scene: Scene = None         # the unsharded scene this shard was cut from (positions as of the last partition)
     migrate_fraction: float = 0.10     # re-partition when more than this fraction of the particles left their slab (0: never)
+    migrate_check_every: int = 512     # ... looked at every this many substeps (one device-side count + one all-reduce)
+    migrate_checked_at: int = 0
+    migrate_warned: bool = False
     migrations: int = 0
 
 
@@ -194,7 +197,12 @@ def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int 
 
 
 # --------------------------------------------------------------------------------------------- migration
-_CARRY_FIELDS = ("particle_x", "particle_v", "particle_C", "particle_d", "particle_F", "particle_F_trial", "particle_stress")
+# per-particle state a re-partition carries over (particle_mass: reset_density(update_mass=True) after the initial build;
+# mu / lam / yield_stress below: set_E_nu* / prepare_mu_lam after the build and the plastic history).  NOT carried: edits of
+# particle_selection made after build_sharded, and the host-side state of grid BCs (a moving velocity cuboid's position) --
+# scenes with such a BC are not re-partitioned (maybe_repartition warns once and goes on).
+_CARRY_FIELDS = ("particle_x", "particle_v", "particle_C", "particle_d", "particle_F", "particle_F_trial", "particle_stress",
+                 "particle_mass")
 _CARRY_MODEL = ("mu", "lam", "yield_stress")
 
 
@@ -222,7 +230,7 @@ def owned_slices(local: dict, shard: Shard, sc: Scene) -> dict:
     for f, a in local.items():
         if f == "particle_d":
             out[f] = a[:shard.own_e.size]
-        elif f in _CARRY_MODEL or f in ("particle_x", "particle_v", "particle_C"):
+        elif f in _CARRY_MODEL or f in ("particle_x", "particle_v", "particle_C", "particle_mass"):
             assert a.shape[0] == n_loc, (f, a.shape, n_loc)
             out[f] = a[all_rows]
         else:
@@ -237,7 +245,7 @@ def assemble_global(parts, sc: Scene) -> dict:
     for f in _CARRY_FIELDS + _CARRY_MODEL:
         if f not in parts[0]:
             continue
-        whole = f in _CARRY_MODEL or f in ("particle_x", "particle_v", "particle_C")
+        whole = f in _CARRY_MODEL or f in ("particle_x", "particle_v", "particle_C", "particle_mass")
         n = n_p if whole else (n_e if f == "particle_d" else n_nv)
         g = np.zeros((n,) + parts[0][f].shape[1:], np.float32)
         filled = np.zeros(n, bool)
@@ -272,7 +280,7 @@ def _apply_carry(sim, shard: Shard, sc: Scene, carry: dict):
     nv_ids = np.concatenate([el, ne_g + shard.own_t])
     dev = st.particle_x.device
     put = lambda dst, a: dst.copy_(torch.as_tensor(np.ascontiguousarray(a, np.float32), device=dev).reshape(dst.shape)) if dst.numel() else None
-    for f in ("particle_C",):
+    for f in ("particle_C", "particle_mass"):
         put(getattr(st, f), carry[f][all_ids])
     for f in ("particle_F", "particle_F_trial", "particle_stress"):
         put(getattr(st, f), carry[f][nv_ids])
@@ -282,19 +290,22 @@ def _apply_carry(sim, shard: Shard, sc: Scene, carry: dict):
 
 
 def slab_leavers(ss: "ShardedSim") -> float:
-    """Collective: fraction of all vertices / traditional particles that sit outside the x-slab of the rank that owns them."""
+    """Collective: fraction of all vertices / traditional particles that sit outside the x-slab of the rank that owns them.
+    Counted on the device (no copy of the positions to the host); one two-element all-reduce."""
     import torch
     import torch.distributed as dist
-    sh, sc = ss.shard, ss.global_scene
-    x = ss.sim.state.particle_x.detach()[:, 0].cpu().numpy()
+    sh = ss.shard
+    x = ss.sim.state.particle_x.detach()[:, 0]
     ne_l = sh.own_e.size + sh.ghost_e.size
-    xs = np.concatenate([x[ne_l:ne_l + sh.own_t.size], x[ne_l + sh.own_t.size:ne_l + sh.own_t.size + sh.own_v.size]])
-    lo = -np.inf if sh.rank == 0 else sh.cuts[sh.rank - 1]
-    hi = np.inf if sh.rank == sh.world - 1 else sh.cuts[sh.rank]
+    n_own = sh.own_t.size + sh.own_v.size            # owned traditional particles, then owned vertices, contiguous rows
+    xs = x[ne_l:ne_l + n_own]
+    lo = -np.inf if sh.rank == 0 else float(sh.cuts[sh.rank - 1])
+    hi = np.inf if sh.rank == sh.world - 1 else float(sh.cuts[sh.rank])
+    out = ((xs < lo) | (xs >= hi)).sum().to(torch.float64)
     # (collectives run at world size 1 too: a tensor on the wrong device for the backend -- NCCL takes no CPU tensors --
     # then fails on a one-GPU test box and not first on the node)
-    t = torch.tensor([float(((xs < lo) | (xs >= hi)).sum()), float(xs.size)], dtype=torch.float64,
-                     device="cpu" if ss.backend == "gloo" else ss.sim.solver.device)
+    t = torch.stack([out, torch.tensor(float(n_own), dtype=torch.float64, device=out.device)])
+    t = t.cpu() if ss.backend == "gloo" else t
     dist.all_reduce(t)
     t = t.cpu()
     return float(t[0] / max(float(t[1]), 1.0))
@@ -302,28 +313,45 @@ def slab_leavers(ss: "ShardedSim") -> float:
 
 def repartition(ss: "ShardedSim") -> "ShardedSim":
     """Collective: new slabs at the particles' CURRENT positions; every rank rebuilds its shard and continues the same run
-    (state, solver time and substep count carried over).  Returns the new ShardedSim (the old one is released)."""
+    (state, solver time and substep count carried over).  The ShardedSim is updated IN PLACE (and returned): a caller that
+    keeps its reference without rebinding continues on the new shard.  The old solver context -- with its RCCL communicator
+    and peer-mapped arenas -- is destroyed before the new shard is built, so the two never coexist."""
     sc = ss.global_scene
-    if any(kind == "velocity_cuboid" for kind, _ in sc.bcs):
-        raise NotImplementedError("re-partition with a moving velocity cuboid (its host-side position is not carried over)")
     carry = gather_global_state(ss)
     carry["time"] = ss.sim.solver.time
     new_sc = replace(sc, x=carry["particle_x"], v=carry["particle_v"], d=carry["particle_d"])
     dev = str(ss.sim.solver.device)
-    keep = dict(steps_done=ss.steps_done, resorts=ss.resorts, rebin_interval=ss.rebin_interval,
-                migrate_fraction=ss.migrate_fraction, migrations=ss.migrations + 1)
-    rank, world = ss.shard.rank, ss.shard.world
-    del ss
-    new = build_sharded(new_sc, dev, rank, world, rebin_interval=keep["rebin_interval"], _carry=carry)
-    new.steps_done, new.resorts = keep["steps_done"], keep["resorts"]
-    new.migrate_fraction, new.migrations = keep["migrate_fraction"], keep["migrations"]
-    new.sim.steps_done = keep["steps_done"]
-    return new
+    keep = dict(steps_done=ss.steps_done, resorts=ss.resorts, migrate_fraction=ss.migrate_fraction, migrations=ss.migrations + 1,
+                migrate_check_every=ss.migrate_check_every, migrate_checked_at=ss.migrate_checked_at)
+    rank, world, rebin_interval = ss.shard.rank, ss.shard.world, ss.rebin_interval
+    old = ss.sim
+    ss.sim, ss.peers, ss.keep, ss.static = None, [], [], {}     # drop every tensor the old context was handed ...
+    for name in ("keep_body", "keep_jt", "keep_body_frame"):
+        ss.__dict__.pop(name, None)
+    old.solver.close()                                          # ... and the context itself (communicator, IPC arenas)
+    del old
+    new = build_sharded(new_sc, dev, rank, world, rebin_interval=rebin_interval, _carry=carry)
+    ss.__dict__.update(new.__dict__)
+    for k, v in keep.items():
+        setattr(ss, k, v)
+    ss.sim.steps_done = keep["steps_done"]
+    return ss
 
 
 def maybe_repartition(ss: "ShardedSim") -> "ShardedSim":
     import os
+    import sys
     if ss.migrate_fraction <= 0 or ss.shard.world == 1 or ss.steps_done == 0:
+        return ss
+    if ss.steps_done - ss.migrate_checked_at < ss.migrate_check_every:
+        return ss
+    ss.migrate_checked_at = ss.steps_done
+    if any(kind == "velocity_cuboid" for kind, _ in ss.global_scene.bcs):
+        # the cuboid's host-side position (set_velocity_on_cuboid's modify step) is not part of what a re-partition carries over
+        if not ss.migrate_warned and ss.shard.rank == 0:
+            print("[mpmavatar_amd.dist] scene has a moving velocity cuboid: particle migration is skipped (slabs stay as cut at "
+                  "the start)", file=sys.stderr, flush=True)
+        ss.migrate_warned = True
         return ss
     frac = slab_leavers(ss)
     if os.environ.get("MPMHIP_VERBOSE"):
@@ -465,8 +493,7 @@ def _held_local(ss: ShardedSim, step: int) -> int:
 
 
 def run(ss: ShardedSim, n_steps: int):
-    """Advance n substeps on every rank (collective).  NOTE: call as ``ss = run(ss, n)`` when migration is enabled -- a
-    re-partition replaces the ShardedSim (the argument stays valid otherwise and is returned)."""
+    """Advance n substeps on every rank (collective).  Returns ``ss`` (a re-partition updates it in place)."""
     import torch
     ss = maybe_repartition(ss)
     sim, sv, sc = ss.sim, ss.sim.solver, ss.sim.scene

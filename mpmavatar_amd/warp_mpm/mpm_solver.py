@@ -102,11 +102,16 @@ class MPMWARP(object):
             self.num_mesh_v, self.num_mesh_f = mv.shape[0], mf.size // 3
             self.mesh = _BodyMesh(id(self) & 0x7FFFFFFF, self.num_mesh_v, self.num_mesh_f)
 
+    def close(self):
+        """Destroy the solver context now (device memory, streams, the multi-GPU communicator).  Idempotent; the object is
+        unusable afterwards.  (Not in the reference, whose Warp arrays die with the Python object.)"""
+        if getattr(self, "_ctx", None):
+            self._lib.mpmhip_destroy(self._ctx)
+            self._ctx = None
+
     def __del__(self):
         try:
-            if getattr(self, "_ctx", None):
-                self._lib.mpmhip_destroy(self._ctx)
-                self._ctx = None
+            self.close()
         except Exception:
             pass
 

@@ -329,11 +329,18 @@ def test_export_particle_cov_to_torch(mode):
     sim.state.particle_F_trial.copy_(torch.as_tensor(Ft, device=dev))
     got = sim.solver.export_particle_cov_to_torch(sim.state, device="cuda:0")
     assert got.shape == (6 * n,) and rel(got.cpu().numpy(), want) < 2e-6
-    # one substep with zero gravity and zero velocity leaves F_trial = (I + dt * 0) F = the elastic part of the F_trial that was
-    # set (jelly: no return mapping): the export after it must read the solver's state, not a stale caller tensor
+    # after a substep the export must read the SOLVER's F_trial (written back first), not the tensor the caller filled
     harness.run(sim, 1)
-    got2 = sim.solver.export_particle_cov_to_torch(sim.state, device="cuda:0")
-    assert rel(got2.cpu().numpy(), want) < 1e-4
+    got2 = sim.solver.export_particle_cov_to_torch(sim.state, device="cuda:0").cpu().numpy()
+    F = sim.state.particle_F_trial.cpu().numpy().astype(np.float64).reshape(n, 3, 3)
+    assert np.abs(F - Ft).max() > 1e-7   # the strained blob moved
+    c = cov0.reshape(n, 6).astype(np.float64)
+    S = np.zeros((n, 3, 3))
+    S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2] = c.T
+    S = S + np.triu(S, 1).transpose(0, 2, 1)
+    w = np.einsum("nij,njk,nlk->nil", F, S, F)
+    want2 = np.stack([w[:, 0, 0], w[:, 0, 1], w[:, 0, 2], w[:, 1, 1], w[:, 1, 2], w[:, 2, 2]], 1).reshape(-1)
+    assert rel(got2, want2) < 2e-6
     # bare C ABI
     from mpmavatar_amd import _lib as L
     lib = L.load()

@@ -3,6 +3,7 @@
 
     python tools/build_variants.py name1:-DFOO=1,-DBAR=2 name2:-DFOO=0 ...
 
+`name:ALL,-flag` compiles every source of the library with the flags (e.g. nofma:ALL,-ffp-contract=off).
 Each variant lands in mpmavatar_amd/lib/variants/libmpmhip_<name>.so (git-ignored, travels with gpurun) and is selected
 at run time with MPMHIP_LIB=<path>.  The default library is untouched.
 """
@@ -21,10 +22,16 @@ def one(spec):
     defs = [d for d in defs.split(",") if d]
     vdir = os.path.join(B.LIBDIR, "variants")
     os.makedirs(vdir, exist_ok=True)
-    obj = os.path.join(vdir, f"fast_{name}.o")
-    cmd = [B.HIPCC] + B.FLAGS + defs + ["-c", os.path.join(B.CSRC, "fast.hip"), "-o", obj]
-    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
-    objs = [obj if s == "fast.hip" else os.path.join(B.OBJDIR, s.replace(".hip", ".o")) for s in B.SOURCES]
+    every = "ALL" in defs  # name:ALL,-flag,...  compiles every source with the flags (later flags override build.py's)
+    defs = [d for d in defs if d != "ALL"]
+    objs = []
+    for src in B.SOURCES:
+        if src != "fast.hip" and not every:
+            objs.append(os.path.join(B.OBJDIR, src.replace(".hip", ".o")))
+            continue
+        obj = os.path.join(vdir, f"{src[:-4]}_{name}.o")
+        subprocess.check_call([B.HIPCC] + B.FLAGS + defs + ["-c", os.path.join(B.CSRC, src), "-o", obj], stderr=subprocess.DEVNULL)
+        objs.append(obj)
     lib = os.path.join(vdir, f"libmpmhip_{name}.so")
     subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     return lib

@@ -19,6 +19,8 @@ cores = os.cpu_count() or 1
 o = oracle_from_scene(sc, omp=True, n_threads=cores)
 a = harness.build_solver(sc, "cuda:0", mode="fast")
 rel = lambda x, y: float(np.abs(x - y).max() / max(np.abs(y).max(), 1e-3))
+def rel_pp(a, b, floor):  # max_i |a_i - b_i| / max(|b_i|, floor), per-particle norms
+    return float((np.linalg.norm(a.astype(np.float64) - b, axis=1) / np.maximum(np.linalg.norm(b.astype(np.float64), axis=1), floor)).max())
 marks = sorted(set([1, 2, 5, 10, 20, 50] + list(range(100, n + 1, 100)) + [n]))
 rows, first = [], {"x": None, "v": None}
 done, t0 = 0, time.time()
@@ -33,11 +35,13 @@ for m in marks:
     dv = np.linalg.norm(v - o.v, axis=1)
     p999 = float(np.quantile(dv, 0.999) / max(np.abs(o.v).max(), 1e-3))
     st = a.solver.stats()
-    rows.append(dict(substep=m, rel_dx=ex, rel_dv=ev, rel_dv_p999=p999, max_v=float(np.abs(o.v).max()), rebins=int(st["rebins"]),
+    vmax = float(np.linalg.norm(o.v, axis=1).max())
+    ppx, ppv, ppvs = rel_pp(x, o.x, 1e-3), rel_pp(v, o.v, 1e-3), rel_pp(v, o.v, max(1e-3 * vmax, 1e-30))
+    rows.append(dict(substep=m, rel_dx=ex, rel_dv=ev, rel_dv_p999=p999, pp_dx=ppx, pp_dv_floor_1e-3=ppv, pp_dv_floor_1e-3_vmax=ppvs, max_v=float(np.abs(o.v).max()), rebins=int(st["rebins"]),
                      fallback=int(st["n_fallback_particles"]), dropped=int(st["n_dropped"])))
     if first["x"] is None and ex > 1e-4: first["x"] = m
     if first["v"] is None and ev > 1e-4: first["v"] = m
-    print(f"substep {m}: rel dx {ex:.2e}  rel dv {ev:.2e} (99.9% of particles within {p999:.2e})  max|v| {np.abs(o.v).max():.3f}  rebins {st['rebins']}  [{time.time() - t0:.0f} s]", flush=True)
+    print(f"substep {m}: rel dx {ex:.2e}  rel dv {ev:.2e} per-particle dv {ppv:.2e} / {ppvs:.2e} (99.9% of particles within {p999:.2e})  max|v| {np.abs(o.v).max():.3f}  rebins {st['rebins']}  [{time.time() - t0:.0f} s]", flush=True)
 out = dict(scene=name, n_particles=int(sc.n_particles), n_grid=int(sc.n_grid), substeps=done, oracle="OpenMP C restatement, %d threads" % cores,
            tolerance=1e-4, first_substep_over_tolerance=first, checkpoints=rows)
 os.makedirs("gpurun_out", exist_ok=True)
