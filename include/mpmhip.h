@@ -191,7 +191,8 @@ int mpmhip_set_time(mpmhip_ctx *ctx, double t);
 int mpmhip_set_host_dt(mpmhip_ctx *ctx, double dt_host);
 
 /* ---- multi-GPU (one process and one context per GPU; not in the reference) --------------------
- * Particles are sharded across ranks by the caller (mpmavatar_amd/dist.py: static spatial slabs); every rank runs
+ * Particles are sharded across ranks by the caller (mpmavatar_amd/dist.py: spatial x-slabs, re-cut at the particles' current positions when more than a
+ * tenth of them have left their slab); every rank runs
  * its own context on its particles plus ghost copies (particle_selection == 2: stress yes, transfers no).  The
  * substep is split in three so that the caller can run its two neighbour exchanges (RCCL send/recv through
  * torch.distributed) between the phases:
@@ -257,6 +258,12 @@ int mpmhip_dist_halo_bytes(mpmhip_ctx *ctx, int64_t *out);
  * mapping is the default and is used only if a four-round handshake over every link of every rank succeeded (max-reduced);
  * MPMHIP_DIST_HALO=rccl keeps send/recv.  No counterpart in the reference (single GPU). */
 int mpmhip_dist_halo_transport(mpmhip_ctx *ctx, int32_t *out);
+/* substeps of mpmhip_rccl_steps so far that had NO halo kernels: with peer-mapped halos the pack rides in the p2g launch as
+ * trailing workgroups (they wait until every scattering workgroup of that launch has counted itself done) and g2p adds the
+ * neighbour's share to the shared blocks while it stages its tile.  Falls back to the pack / add kernels for an interval in
+ * which a block is shared with more than one neighbour, a pair's arena is too small, or profiling brackets the launches;
+ * MPMHIP_DIST_FUSED_HALO=0 switches it off. */
+int mpmhip_dist_fused_halo_steps(mpmhip_ctx *ctx, int64_t *out);
 int mpmhip_rccl_steps(mpmhip_ctx *ctx, float dt, int32_t n, int64_t step_index, int32_t rebin_interval,
                       const float *mesh_x, const float *mesh_v, const float *joint_traditional_v, int32_t n_joint_t,
                       const float *joint_verts_v, const float *joint_faces_v);

@@ -115,6 +115,7 @@ SIGNATURES = {
     "mpmhip_debug_wgtrace": (C.c_int, [vp, C.c_int32, vp, C.c_int32]),
     "mpmhip_dist_halo_bytes": (C.c_int, [vp, C.POINTER(C.c_int64)]),
     "mpmhip_dist_halo_transport": (C.c_int, [vp, C.POINTER(C.c_int32)]),
+    "mpmhip_dist_fused_halo_steps": (C.c_int, [vp, C.POINTER(C.c_int64)]),
     "mpmhip_export_grid": (C.c_int, [vp, vp, vp, vp]),
     "mpmhip_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
     "mpmhip_profile_enable": (C.c_int, [vp, C.c_int32]),

@@ -58,5 +58,33 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(name: str, flags, every: bool = False) -> str:
+    """Another build of the same sources with extra compiler flags, in lib/variants/libmpmhip_<name>.so (selected at run time with
+    MPMHIP_LIB=<path>; the default library is untouched).  every = False compiles only fast.hip with the flags.  Used for the
+    contraction-free witness build (tests/test_gpu_ref_golden.py) and for kernel A/B experiments (tools/build_variants.py)."""
+    build()
+    vdir = os.path.join(LIBDIR, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for src in SOURCES:
+        if src != "fast.hip" and not every:
+            objs.append(os.path.join(OBJDIR, src.replace(".hip", ".o")))
+            continue
+        obj = os.path.join(vdir, f"{src[:-4]}_{name}.o")
+        if _stale(obj, [os.path.join(CSRC, src)] + hdrs):
+            r = subprocess.run([HIPCC] + FLAGS + list(flags) + ["-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        objs.append(obj)
+    lib = os.path.join(vdir, f"libmpmhip_{name}.so")
+    if _stale(lib, objs):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
+NOFMA = ("nofma", ["-ffp-contract=off"], True)  # every source without FMA contraction: the strict-rounding witness build
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -544,6 +544,13 @@ int mpmhip_dist_halo_transport(mpmhip_ctx *c, int32_t *out) {
   return MPMHIP_OK;
 }
 
+int mpmhip_dist_fused_halo_steps(mpmhip_ctx *c, int64_t *out) {
+  if (!c || !out) return MPMHIP_ERR_INVALID;
+  if (!fast_mode(c) || !c->fast) return fail(c, MPMHIP_ERR_INVALID, "dist_fused_halo_steps: fast mode only");
+  *out = fast_dist_fused_halo_steps(c);
+  return MPMHIP_OK;
+}
+
 int mpmhip_debug_counter(mpmhip_ctx *c, int32_t index, int64_t *out) {
   CHECK_CTX(c);
   if (!fast_mode(c) || !c->fast) return fail(c, MPMHIP_ERR_INVALID, "debug_counter: fast mode only");

@@ -175,6 +175,7 @@ int fast_dist_ghosts(mpmhip_ctx *ctx, int send);
 int fast_dist_num_blocks(const mpmhip_ctx *ctx);
 int64_t fast_dist_halo_bytes(const mpmhip_ctx *ctx);
 int fast_dist_halo_transport(const mpmhip_ctx *ctx);
+int64_t fast_dist_fused_halo_steps(const mpmhip_ctx *ctx);
 int fast_dist_drift_flag(mpmhip_ctx *ctx, int32_t *out);
 int fast_dist_rebin(mpmhip_ctx *ctx, unsigned char *active_map);
 int fast_dist_set_peers(mpmhip_ctx *ctx, int n, const mpmhip_dist_peer *peers);

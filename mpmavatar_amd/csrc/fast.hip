@@ -387,6 +387,17 @@ static_assert(SIG_RING0 + SIG_RING_N <= SIG_WORDS && (SIG_RING_N & (SIG_RING_N -
 // snapshot of the sticky flags raced with the workgroups of the posting launch that raise them)
 enum { CNT_FACE = 5, CNT_DRIFT = 6, CNT_PAR0 = 16, CNT_N = 32 };
 
+// Fused halo add (multi-GPU, peer-mapped halos): k_g2p<.., HALO = true> adds the neighbour rank's contribution to a shared
+// block while it stages its tile -- own accumulator + the value the neighbour's pack stored into this rank's arena -- instead
+// of a separate add kernel between p2g and g2p.  slot == nullptr: off.
+constexpr int PEER_TAB = 8;
+struct HaloIn {
+  const int *slot;             // [blocks] -1, or (peer << 24) | index of the block in that peer's shared-block list
+  const float *buf[PEER_TAB];  // this substep's receive buffer of each peer (arena of parity halo_seq & 1)
+  const int *sig[PEER_TAB];    // its flag: reaches `seq` when the neighbour's pack of this substep has landed
+  int n_peers, seq, ch;        // ch = 4 (m, momentum) or 8 (+ mover channels)
+};
+
 struct GridPtrs {
   float *mv;        // [block][4][64]: m, momentum xyz
   float *vout;      // [block][4][64]: v_out xyz, m (copy kept for introspection)
@@ -400,6 +411,7 @@ struct GridPtrs {
   int step_id;      // (step_id & 15)] the flags of substep step_id - 1 (see k_p2g); [SIG_DFLAG], [SIG_DSEQ] the sharded loop's
                     // reduced flag and its sequence number (k_post_flag)
   float lookahead;  // substeps the early warning of the adaptive re-sort looks ahead (k_p2g)
+  HaloIn halo;      // multi-GPU: see HaloIn
   int stagger, stagger_groups, stagger_first;  // p2g: first-round workgroups wait (wave slot % groups) * stagger * 1024 cycles
   unsigned long long *trace;  // per-workgroup timeline (MPMHIP_DEBUG builds, mpmhip_debug_wgtrace); null otherwise
   int dbg;          // MPMHIP_DBG bitmask (MPMHIP_DEBUG builds only; perf experiments, results are wrong): 1 skip p2g flush, 2 skip the p2g
@@ -435,7 +447,7 @@ __device__ __forceinline__ void raise_face(int *counters, int step_id) {
 template <bool ZERO>
 __device__ __forceinline__ V3 node_finish(int blk, int l, float m, float px, float py, float pz, const Dims &d, const GridPtrs &g,
                                           const GridParams &gp, const BCList &bcl, int &ncol, int &nmov, bool use_col,
-                                          unsigned bc_mask) {
+                                          unsigned bc_mask, const float *rem_mov = nullptr) {
   V3 v = v3(0, 0, 0);
   if (m > 1e-15f) {
     float inv = 1.0f / m;
@@ -458,9 +470,10 @@ __device__ __forceinline__ V3 node_finish(int blk, int l, float m, float px, flo
   }
   if (gp.has_mov && gp.mov_on) {
     float *pv = g.mov + ((size_t)blk * GCH_MOV) * 64 + l;
-    float wv = pv[0];
+    float wv = pv[0], mx = 0.0f, my = 0.0f, mz = 0.0f;
+    if (rem_mov) { wv += rem_mov[0]; mx = rem_mov[64]; my = rem_mov[128]; mz = rem_mov[192]; }  // the neighbour rank's share
     if (wv != 0.0f) {
-      if (wv > 1e-15f) { v = (1.0f / wv) * v3(pv[64], pv[128], pv[192]); nmov = 1; }
+      if (wv > 1e-15f) { v = (1.0f / wv) * v3(pv[64] + mx, pv[128] + my, pv[192] + mz); nmov = 1; }
       if (ZERO) { pv[0] = 0.0f; pv[64] = 0.0f; pv[128] = 0.0f; pv[192] = 0.0f; }
     }
   }
@@ -702,6 +715,130 @@ __global__ __launch_bounds__(1024) void k_build_chunks(const int *plist, const i
   }
 }
 
+// ---- multi-GPU exchange helpers (mpmavatar_amd/dist.py drives them) ---------------------------------------
+// halo: the (m, momentum) and mover channels of the grid blocks two ranks both have on their active lists
+// One launch serves up to PEER_TAB neighbours: workgroups [wg_off[p], wg_off[p+1]) belong to peer p.
+struct HaloTab {
+  int n, with_mov;
+  int wg_off[PEER_TAB + 1];
+  const int *blocks[PEER_TAB];
+  int n_blocks[PEER_TAB];
+  float *buf[PEER_TAB];
+  // peer-mapped halos (see "peer links" below): pack stores straight into the neighbour's receive buffer and the last
+  // workgroup raises sig (a flag in the neighbour's memory) to seq; add waits for its own flag to reach seq.  null: none
+  int *sig[PEER_TAB];
+  int *cnt[PEER_TAB];
+  int seq;
+};
+struct GhostTab {
+  int n;
+  int wg_off[PEER_TAB + 1];
+  const int *ids_p[PEER_TAB], *ids_e[PEER_TAB];
+  int n_p[PEER_TAB], n_e[PEER_TAB];
+  float *buf[PEER_TAB];
+};
+template <class Tab>
+__device__ __forceinline__ int tab_peer(const Tab &t, int wg) {
+  int p = 0;
+  while (p + 1 < t.n && wg >= t.wg_off[p + 1]) ++p;
+  return p;
+}
+// ---- peer links: flags and data in fine-grained memory of the RECEIVING rank, mapped into the sender with HIP IPC ----------
+// Producer: every thread fences its stores at system scope, the workgroup counts itself done, the last one to do so stores
+// the flag with release semantics.  Consumer: one thread per workgroup polls the flag (acquire, system scope) with a
+// wall-clock bound, so that a lost signal fails the run (counters[10]) instead of hanging the GPU.
+constexpr long long LINK_TIMEOUT_TICKS = 20ll * 100000000ll;    // wall_clock64() ticks at 100 MHz: 20 s in a substep,
+constexpr long long LINK_HANDSHAKE_TICKS = 3ll * 100000000ll;   // 3 s in the set-up handshake (failure = fall back to send/recv)
+__device__ __forceinline__ void link_signal(int *cnt, int n_wg, int *flag, int seq) {
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == n_wg - 1) {
+      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+__device__ __forceinline__ void link_wait(const int *flag, int seq, int *err, long long ticks = LINK_TIMEOUT_TICKS) {
+  if (threadIdx.x == 0) {
+    long long t0 = wall_clock64();
+    while ((int)((unsigned)__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - (unsigned)seq) < 0) {  // wraps
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > ticks) { *err = 1; break; }
+    }
+  }
+  __syncthreads();
+  (void)__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);  // every thread orders its reads after the flag
+}
+
+// the pack of one workgroup.  L2 = true: the accumulators are read with agent-scope atomic loads (the caller runs in the
+// SAME launch as the workgroups that scattered into them, see PackArgs: nothing may come from this CU's L1)
+template <bool L2>
+__device__ __forceinline__ void halo_pack_wg(const HaloTab &tb, const GridPtrs &g, int wg) {
+  int p = tab_peer(tb, wg);
+  int t = (wg - tb.wg_off[p]) * (int)blockDim.x + (int)threadIdx.x;
+  int CH = tb.with_mov ? 8 : 4;
+  if (t < tb.n_blocks[p] * CH * 64) {
+    int l = t & 63, ch = (t >> 6) % CH, i = t / (CH * 64);
+    int blk = tb.blocks[p][i];
+    const float *src = ch < 4 ? g.mv + ((size_t)blk * GCH_MV + ch) * 64 + l : g.mov + ((size_t)blk * GCH_MOV + (ch - 4)) * 64 + l;
+    tb.buf[p][t] = L2 ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+  }
+  if (tb.sig[p]) link_signal(tb.cnt[p], tb.wg_off[p + 1] - tb.wg_off[p], tb.sig[p], tb.seq);
+}
+// Halo pack INSIDE the p2g launch (multi-GPU, peer-mapped halos): the launch carries pack workgroups after its clearing
+// workgroups.  Every workgroup in front of them (splats, chunks, XCD padding) counts itself done when its atomics are out; a pack
+// workgroup waits for that count -- they are dispatched in order, so everything it waits for is resident or finished, no
+// deadlock -- and then stores the shared blocks into the neighbour's arena and raises the neighbour's flag.  One launch
+// (4-5 us at its floor) less per substep and rank than k_halo_pack.
+struct PackArgs {
+  HaloTab tb;
+  unsigned *done;   // running count of finished workgroups (wraps)
+  unsigned target;  // value it reaches when this launch's are all done
+  int first, n_wg;  // pack workgroups: blockIdx in [first, first + n_wg); n_wg == 0: none, nobody counts
+};
+__device__ __forceinline__ void wg_done(const PackArgs &pk) {
+  if (pk.n_wg == 0) return;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(pk.done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pack_wait(const PackArgs &pk, int *err) {
+  if (threadIdx.x == 0) {
+    long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(pk.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - pk.target) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > LINK_TIMEOUT_TICKS) { *err = 1; break; }
+    }
+  }
+  __syncthreads();
+}
+// one lane waits for a peer's flag (g2p's out-of-margin path; the tile path waits per workgroup, link_wait)
+__device__ __forceinline__ void link_wait_lane(const int *flag, int seq, int *err) {
+  long long t0 = wall_clock64();
+  while ((int)((unsigned)__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - (unsigned)seq) < 0) {
+    __builtin_amdgcn_s_sleep(4);
+    if (wall_clock64() - t0 > LINK_TIMEOUT_TICKS) { *err = 1; break; }
+  }
+}
+// the neighbour rank's share of node l of block blk (HaloIn): added to (m, px, py, pz); returns its mover channels or null
+__device__ __forceinline__ const float *halo_add_node(const HaloIn &h, int hs, int l, float &m, float &px, float &py, float &pz) {
+  int k = hs >> 24, idx = hs & 0xffffff;
+  const float *base = h.buf[0];
+#pragma unroll
+  for (int q = 1; q < PEER_TAB; ++q) base = (k == q) ? h.buf[q] : base;
+  const float *rp = base + ((size_t)idx * h.ch) * 64 + l;
+  m += rp[0]; px += rp[64]; py += rp[128]; pz += rp[192];
+  return h.ch == 8 ? rp + 256 : nullptr;
+}
+__device__ __forceinline__ const int *halo_sig(const HaloIn &h, int k) {
+  const int *sg = h.sig[0];
+#pragma unroll
+  for (int q = 1; q < PEER_TAB; ++q) sg = (k == q) ? h.sig[q] : sg;
+  return sg;
+}
+
 // ------------------------------------------------------------------------------------------------
 // body-face splat (compute_mesh, mpm_solver.py:829-880) and joint splat (:677-788) into active blocks
 // ------------------------------------------------------------------------------------------------
@@ -823,6 +960,7 @@ struct SplatArgs {
   int n_extra;             // n_fbins + n_mov_wg rounded up to a multiple of 8 (keeps the XCD mapping of the chunks)
   ZeroArgs z;              // workgroups [z_first, z_first + z.n_wg), after the chunk workgroups: clear the other
   int z_first;             // accumulator buffer
+  PackArgs pack;           // workgroups [pack.first, ...) after those: multi-GPU halo pack (see PackArgs)
 };
 
 // PASS 0: weight + weight*velocity (collider channels 0..3), PASS 1: weight*normal (channels 4..6); both passes use
@@ -1327,15 +1465,21 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
     if (e < sa.n_fbins) { if (!DBG(g, 8192)) col_splat_wg(tile, sa, e, d, g); }   // (8192 / 16384: ablation switches)
     else if (e < sa.n_fbins + sa.n_mov_wg) { if (!DBG(g, 16384)) mover_splat_wg(b, sa.js, e - sa.n_fbins, d, g); }
     WGT(g, 0, 6);
+    wg_done(sa.pack);
     return;
   }
   if ((int)blockIdx.x >= sa.z_first) {  // ... and the clearing workgroups last: they fill the tail of the launch
+    if (sa.pack.n_wg && (int)blockIdx.x >= sa.pack.first) {  // (multi-GPU) halo pack, once everything in front has scattered
+      pack_wait(sa.pack, g.counters + 10);
+      halo_pack_wg<true>(sa.pack.tb, g, (int)blockIdx.x - sa.pack.first);
+      return;
+    }
     if (!DBG(g, 2048)) zero_blocks_wg(sa.z, (int)blockIdx.x - sa.z_first);
     WGT(g, 0, 6);
     return;
   }
   int w = xcd_slice((int)blockIdx.x - sa.n_extra, n_chunks);
-  if (w < 0) return;
+  if (w < 0) { wg_done(sa.pack); return; }
   if (g.stagger > 0 && (int)blockIdx.x < g.stagger_first) {
     // The workgroups of the first round all start within a microsecond, load together and then scatter together: memory
     // system and VALU / LDS pipelines take turns idling, and a first-round workgroup lives 12.4 us against 9.0 us for one
@@ -1417,6 +1561,7 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
       p2g_flush<false, true>(tile, ox, oy, oz, d, g);
     }
   }
+  wg_done(sa.pack);
 }
 
 // The chunk records come first in the argument list: the record load is the head of every workgroup's dependency chain.
@@ -1553,7 +1698,7 @@ __device__ __forceinline__ M3 g2p_gather_grad(const float4 *tile, int ox, int oy
 
 // same sums for a particle that drifted out of its tile margin: rolled loop over the global grid (zero outside
 // active blocks); kept small so that it does not set the kernel's register budget
-template <bool FUSED>
+template <bool FUSED, bool HALO = false>
 __device__ __forceinline__ G2PResult g2p_gather_global(V3 x, const Dims &d, const GridPtrs &g, const GridParams &gp,
                                                        const BCList &bcl) {
   Stencil s = make_stencil(x, d.inv_dx);
@@ -1569,7 +1714,18 @@ __device__ __forceinline__ G2PResult g2p_gather_global(V3 x, const Dims &d, cons
     if (in_grid(x_, y_, z_, d.G)) {
       int blk = blk_of(x_, y_, z_, d.NB);
       if (g.ab_flag[blk]) {
-        if (FUSED) {
+        if (FUSED && HALO) {
+          int nc = 0, nm = 0, l_ = loc_of(x_, y_, z_);
+          const float *pm = g.mv + ((size_t)blk * GCH_MV) * 64 + l_;
+          float m = pm[0], px = pm[64], py = pm[128], pz = pm[192];
+          const float *rem_mov = nullptr;
+          int hs = g.halo.slot[blk];
+          if (hs >= 0) {
+            link_wait_lane(halo_sig(g.halo, hs >> 24), g.halo.seq, g.counters + 10);
+            rem_mov = halo_add_node(g.halo, hs, l_, m, px, py, pz);
+          }
+          u = node_finish<false>(blk, l_, m, px, py, pz, d, g, gp, bcl, nc, nm, true, 0xffffffffu, rem_mov);
+        } else if (FUSED) {
           float m;
           int nc = 0, nm = 0;
           u = node_update<false>(blk, loc_of(x_, y_, z_), d, g, gp, bcl, m, nc, nm);
@@ -1631,7 +1787,9 @@ __device__ __forceinline__ void g2p_write(const Bufs &b, int cls, int s, V3 x, V
 // MFLAG = false: the accumulators of all 27 overlapped blocks are loaded as soon as the chunk record is there, without first
 // asking m_flag which of them were scattered into (the ~70 % that were not read back zeros from L2).  One dependent memory
 // level less at the head of every workgroup for more L2 traffic; node values are identical (an unflagged block holds zeros).
-template <bool FUSED, bool TWO_PASS, bool MFLAG>
+// HALO = true (multi-GPU, needs MFLAG = false): blocks shared with a neighbour rank get its contribution added on the way
+// (HaloIn), after the workgroup has seen the neighbour's flag for this substep.
+template <bool FUSED, bool TWO_PASS, bool MFLAG, bool HALO = false>
 __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, const Bufs &b, const Dims &d, float dt, const GridPtrs &g,
                                          const GridParams &gp, const BCList &bcl) {
   __shared__ float4 tile[TILE_PAD];  // node velocity, 16 bytes per node
@@ -1655,7 +1813,7 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
     d3 = v3(b.el.at(E_D + 2, se), b.el.at(E_D + 5, se), b.el.at(E_D + 8, se));
   }
   constexpr int NPT = TILE3 / PT;  // tile nodes per thread
-  int nbk[NPT], nlk[NPT];
+  int nbk[NPT], nlk[NPT], hsl[NPT];
   float am[NPT], apx[NPT], apy[NPT], apz[NPT];
 #pragma unroll
   for (int u = 0; u < NPT; ++u) {
@@ -1672,6 +1830,8 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
       float a0 = pm[0], a1 = pm[64], a2 = pm[128], a3 = pm[192];
       am[u] = in ? a0 : 0.0f; apx[u] = in ? a1 : 0.0f; apy[u] = in ? a2 : 0.0f; apz[u] = in ? a3 : 0.0f;
     }
+    hsl[u] = -1;
+    if (HALO) { int hs = g.halo.slot[in ? nbk[u] : blk]; hsl[u] = in ? hs : -1; }
   }
   // tile-level shortcuts for the fused node evaluation (both wave-uniform): which of the 27 overlapped blocks may
   // carry body-collider data this substep (flags set by the splat), and which BCs can reach this tile at all
@@ -1690,6 +1850,16 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
     m_mask = MFLAG ? __ballot(fm != 0) : ~0ull;  // a block nobody scattered into: its nodes carry no mass, hence no weight in any gather
     for (int k = 0; k < bcl.n; ++k)
       if (bc_may_touch(bcl.bc[k], ox, oy, oz, ox + 7, oy + 7, oz + 7, d.G, d.dx, gp.time, gp.dt)) bc_mask |= 1u << k;
+    if (HALO) {  // wait for the flag of every neighbour rank this tile shares a block with (the same set in every wavefront)
+      int hs27 = -1;
+      if (l < 27) {
+        int nx = bx + l / 9 - 1, ny = by + (l / 3) % 3 - 1, nz = bz + l % 3 - 1;
+        if ((unsigned)nx < (unsigned)d.NB && (unsigned)ny < (unsigned)d.NB && (unsigned)nz < (unsigned)d.NB)
+          hs27 = g.halo.slot[(nx * d.NB + ny) * d.NB + nz];
+      }
+      for (int k = 0; k < g.halo.n_peers; ++k)
+        if (__any(hs27 >= 0 && (hs27 >> 24) == k)) link_wait(halo_sig(g.halo, k), g.halo.seq, g.counters + 10);
+    }
   }
   bool escaped = false;
   if (valid) {
@@ -1709,7 +1879,9 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
         int nidx = ((((ox + ti) >> 2) - bx + 1) * 3 + (((oy + tj) >> 2) - by + 1)) * 3 + (((oz + tk) >> 2) - bz + 1);
         bool uc = (col_mask >> nidx) & 1ull;
         if (!MFLAG) {
-          v = node_finish<false>(nb, nl, am[u], apx[u], apy[u], apz[u], d, g, gp, bcl, nc, nm, uc, bc_mask);
+          const float *rem_mov = nullptr;
+          if (HALO && hsl[u] >= 0) rem_mov = halo_add_node(g.halo, hsl[u], nl, am[u], apx[u], apy[u], apz[u]);
+          v = node_finish<false>(nb, nl, am[u], apx[u], apy[u], apz[u], d, g, gp, bcl, nc, nm, uc, bc_mask, rem_mov);
         } else if ((m_mask >> nidx) & 1ull) {
           float m;
           v = node_update<false>(nb, nl, d, g, gp, bcl, m, nc, nm, uc, bc_mask);
@@ -1756,7 +1928,7 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
   if (__any(escaped)) {
     asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(s), "+v"(cls), "+v"(d3.x), "+v"(d3.y), "+v"(d3.z));
     if (escaped) {
-      G2PResult r = g2p_gather_global<FUSED>(x, d, g, gp, bcl);
+      G2PResult r = g2p_gather_global<FUSED, HALO>(x, d, g, gp, bcl);
       g2p_write(b, cls, s, x, d3, r, ox, oy, oz, d, dt, g);
       atomicAdd(g.counters + 0, 1);
     }
@@ -1767,6 +1939,12 @@ template <bool FUSED, bool TWO_PASS, bool MFLAG>
 __global__ __launch_bounds__(PT) void k_g2p(const ChunkRec *recs, int n_chunks, Bufs b, Dims d, float dt, GridPtrs g, GridParams gp,
                                              BCList bcl) {
   g2p_body<FUSED, TWO_PASS, MFLAG>(recs, n_chunks, b, d, dt, g, gp, bcl);
+}
+// multi-GPU: fused halo add (see HaloIn)
+template <bool TWO_PASS>
+__global__ __launch_bounds__(PT) void k_g2p_halo(const ChunkRec *recs, int n_chunks, Bufs b, Dims d, float dt, GridPtrs g, GridParams gp,
+                                                  BCList bcl) {
+  g2p_body<true, TWO_PASS, false, true>(recs, n_chunks, b, d, dt, g, gp, bcl);
 }
 // six wavefronts per SIMD for the fused two-pass form (94 VGPRs -> 80 + 12 spilled dwords), see k_p2g_w6
 template <bool MFLAG>
@@ -1848,63 +2026,6 @@ __global__ void k_count_active(const int *alist, int n_A, GridPtrs g, int *out) 
   if ((threadIdx.x & 63) == 0 && bal) atomicAdd(out, __popcll(bal));
 }
 
-// ---- multi-GPU exchange helpers (mpmavatar_amd/dist.py drives them) ---------------------------------------
-// halo: the (m, momentum) and mover channels of the grid blocks two ranks both have on their active lists
-// One launch serves up to PEER_TAB neighbours: workgroups [wg_off[p], wg_off[p+1]) belong to peer p.
-constexpr int PEER_TAB = 8;
-struct HaloTab {
-  int n, with_mov;
-  int wg_off[PEER_TAB + 1];
-  const int *blocks[PEER_TAB];
-  int n_blocks[PEER_TAB];
-  float *buf[PEER_TAB];
-  // peer-mapped halos (see "peer links" below): pack stores straight into the neighbour's receive buffer and the last
-  // workgroup raises sig (a flag in the neighbour's memory) to seq; add waits for its own flag to reach seq.  null: none
-  int *sig[PEER_TAB];
-  int *cnt[PEER_TAB];
-  int seq;
-};
-struct GhostTab {
-  int n;
-  int wg_off[PEER_TAB + 1];
-  const int *ids_p[PEER_TAB], *ids_e[PEER_TAB];
-  int n_p[PEER_TAB], n_e[PEER_TAB];
-  float *buf[PEER_TAB];
-};
-template <class Tab>
-__device__ __forceinline__ int tab_peer(const Tab &t, int wg) {
-  int p = 0;
-  while (p + 1 < t.n && wg >= t.wg_off[p + 1]) ++p;
-  return p;
-}
-// ---- peer links: flags and data in fine-grained memory of the RECEIVING rank, mapped into the sender with HIP IPC ----------
-// Producer: every thread fences its stores at system scope, the workgroup counts itself done, the last one to do so stores
-// the flag with release semantics.  Consumer: one thread per workgroup polls the flag (acquire, system scope) with a
-// wall-clock bound, so that a lost signal fails the run (counters[10]) instead of hanging the GPU.
-constexpr long long LINK_TIMEOUT_TICKS = 20ll * 100000000ll;    // wall_clock64() ticks at 100 MHz: 20 s in a substep,
-constexpr long long LINK_HANDSHAKE_TICKS = 3ll * 100000000ll;   // 3 s in the set-up handshake (failure = fall back to send/recv)
-__device__ __forceinline__ void link_signal(int *cnt, int n_wg, int *flag, int seq) {
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == n_wg - 1) {
-      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-}
-__device__ __forceinline__ void link_wait(const int *flag, int seq, int *err, long long ticks = LINK_TIMEOUT_TICKS) {
-  if (threadIdx.x == 0) {
-    long long t0 = wall_clock64();
-    while ((int)((unsigned)__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - (unsigned)seq) < 0) {  // wraps
-      __builtin_amdgcn_s_sleep(4);
-      if (wall_clock64() - t0 > ticks) { *err = 1; break; }
-    }
-  }
-  __syncthreads();
-  (void)__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);  // every thread orders its reads after the flag
-}
 // handshake at link set-up: `n` pattern words through the link's data area, checked on the other side (rccl_link_setup)
 __device__ __forceinline__ unsigned link_pattern(int seq, int i) { return (unsigned)i * 2654435761u ^ ((unsigned)seq * 0x9E3779B9u); }
 __global__ void k_link_ping(unsigned *data, int n, int *cnt, int *flag, int seq) {
@@ -1926,17 +2047,7 @@ __global__ void k_post_flag(const int *value, int *host_sig, int seq) {
 }
 __global__ void k_link_verdict(int *counters) { counters[12] = (counters[10] != 0 || counters[11] != 0) ? 1 : 0; }
 
-__global__ void k_halo_pack(HaloTab tb, GridPtrs g) {
-  int p = tab_peer(tb, blockIdx.x);
-  int t = ((int)blockIdx.x - tb.wg_off[p]) * blockDim.x + threadIdx.x;
-  int CH = tb.with_mov ? 8 : 4;
-  if (t < tb.n_blocks[p] * CH * 64) {
-    int l = t & 63, ch = (t >> 6) % CH, i = t / (CH * 64);
-    int blk = tb.blocks[p][i];
-    tb.buf[p][t] = ch < 4 ? g.mv[((size_t)blk * GCH_MV + ch) * 64 + l] : g.mov[((size_t)blk * GCH_MOV + (ch - 4)) * 64 + l];
-  }
-  if (tb.sig[p]) link_signal(tb.cnt[p], tb.wg_off[p + 1] - tb.wg_off[p], tb.sig[p], tb.seq);
-}
+__global__ void k_halo_pack(HaloTab tb, GridPtrs g) { halo_pack_wg<false>(tb, g, (int)blockIdx.x); }
 // a block can be shared with more than one peer (slabs thinner than two blocks): atomic adds
 __global__ void k_halo_add(HaloTab tb, GridPtrs g) {
   int p = tab_peer(tb, blockIdx.x);
@@ -1984,6 +2095,14 @@ __global__ void k_ghost_unpack(GhostTab tb, const int *inv, Bufs b) {
     const float *o = in + 6 * (size_t)n_p_ids + 3 * (size_t)i;
     b.el.at(E_D + 2, s) = o[0]; b.el.at(E_D + 5, s) = o[1]; b.el.at(E_D + 8, s) = o[2];
   }
+}
+// halo_slot[b] = (peer << 24) | index of block b in that peer's shared-block list; *multi = 1 if a block is shared with
+// more than one peer (slabs thinner than two blocks: those intervals keep the separate add kernel with its atomics)
+__global__ void k_halo_slots(const int *flag, const int *index, int n, int peer, int *slot, int *multi) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n || !flag[b]) return;
+  if (slot[b] != -1) *multi = 1;
+  else slot[b] = (peer << 24) | index[b];
 }
 __global__ void k_shared_flags(const unsigned char *a, const unsigned char *b, int n, int *flag) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2065,6 +2184,8 @@ struct Rccl {  // entry points resolved with dlsym: libmpmhip.so itself does not
     if (over && *over) {
       h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
       if (!h) { err = std::string("dlopen MPMHIP_RCCL_LIB=") + over + ": " + dlerror(); return false; }
+      // never silently: the collective library of a production run must be RCCL
+      fprintf(stderr, "[mpmhip] WARNING: MPMHIP_RCCL_LIB is set -- the multi-GPU exchange uses %s INSTEAD OF librccl.so (test hook)\n", over);
     }
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -2103,6 +2224,13 @@ struct FastState {
   std::vector<RcclPeer> rpeers;
   unsigned char *map_all = nullptr;  // [world][nblocks] active-block byte maps
   bool link_want = true, link_decided = false, link_on = false;  // peer-mapped halos: asked for / decided collectively / in use
+  // fused halo (peer-mapped halos only): pack workgroups ride in the p2g launch, g2p adds the neighbour's share while it
+  // stages its tile (PackArgs, HaloIn) -- no pack / add kernels in the substep.  Decided per collective re-sort (local decision:
+  // what goes over the links is the same either way).  MPMHIP_DIST_FUSED_HALO=0: keep the two kernels.
+  bool fused_want = true, fused_halo = false;
+  int *halo_slot = nullptr, *halo_multi = nullptr;
+  unsigned *pack_done = nullptr, pack_target = 0;
+  int64_t fused_halo_steps = 0;  // substeps that ran without pack / add kernels (mpmhip_dist_fused_halo_steps)
   unsigned halo_seq = 0;             // substeps exchanged so far (+ handshake rounds): flag value and buffer parity (wraps: the
                                      // kernels compare (int)(flag - seq), long trainings run billions of substeps)
   Dims d{};
@@ -2559,6 +2687,7 @@ int fast_init(mpmhip_ctx *c) {
   f->g2p_two_pass = cfg.n_particles - cfg.n_elements - cfg.n_vertices == 0;
   if (const char *e = getenv("MPMHIP_G2P_TWO_PASS")) f->g2p_two_pass = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_FUSE_TRAD")) f->fuse_trad = atoi(e) != 0;
+  if (const char *e = getenv("MPMHIP_DIST_FUSED_HALO")) f->fused_want = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_W6")) f->w6 = atoi(e) != 0;
   f->g.stagger = 0; f->g.stagger_groups = 2; f->g.stagger_first = 0;
   if (const char *e = getenv("MPMHIP_P2G_STAGGER")) {  // "units[,groups[,first]]": units of 1024 cycles per group step
@@ -2666,6 +2795,9 @@ int fast_pull(mpmhip_ctx *c) {
     if (!(fused)) {                                                                             \
       if (two) hipLaunchKernelGGL((k_g2p<false, true, true>), __VA_ARGS__);                     \
       else hipLaunchKernelGGL((k_g2p<false, false, true>), __VA_ARGS__);                        \
+    } else if (f->g.halo.slot) {                                                                \
+      if (two) hipLaunchKernelGGL((k_g2p_halo<true>), __VA_ARGS__);                             \
+      else hipLaunchKernelGGL((k_g2p_halo<false>), __VA_ARGS__);                                \
     } else if (f->g2p_mflag) {                                                                  \
       if ((two) && f->w6) hipLaunchKernelGGL((k_g2p_w6<true>), __VA_ARGS__);                    \
       else if (two) hipLaunchKernelGGL((k_g2p<true, true, true>), __VA_ARGS__);                 \
@@ -2789,6 +2921,27 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   }
   sa.n_extra = (sa.n_fbins + sa.n_mov_wg + 7) & ~7;
   sa.z_first = sa.n_extra + (int)xcd_grid(f->n_chunks);
+  const bool fused_halo_now = f->dist && f->fused_halo && !c->profiling && !c->prof_fused;
+  if (fused_halo_now) {  // (multi-GPU) the halo pack rides in this launch, behind the clearing workgroups: see PackArgs
+    HaloTab &tb = sa.pack.tb;
+    tb.with_mov = c->movers.empty() ? 0 : 1;
+    const int CH = tb.with_mov ? 8 : 4, par = (int)(f->halo_seq & 1u);
+    for (auto &q : f->peers) {
+      if (!q.n_blocks) continue;
+      int k = tb.n++;
+      tb.blocks[k] = q.blocks; tb.n_blocks[k] = q.n_blocks;
+      tb.buf[k] = q.link_remote + LINK_DATA0 + (size_t)par * q.link_cap * 8 * 64;
+      tb.sig[k] = (int *)q.link_remote + par * LINK_FLAG_STRIDE;
+      tb.cnt[k] = q.link_cnt;
+      tb.wg_off[k + 1] = tb.wg_off[k] + (int)(((size_t)q.n_blocks * CH * 64 + PT - 1) / PT);
+    }
+    tb.seq = (int)f->halo_seq;
+    sa.pack.n_wg = tb.wg_off[tb.n];
+    sa.pack.first = sa.z_first + sa.z.n_wg;
+    sa.pack.done = f->pack_done;
+    f->pack_target += (unsigned)sa.z_first;  // every workgroup in front of the clearing ones counts itself done
+    sa.pack.target = f->pack_target;
+  }
   f->g.step_id = (int)++f->sig_seq;
   if (d.n_e || (d.n_t && !trad_fused)) {  // (no empty event bracket when the stress update rides in p2g)
     ScopedPhase ph(c, "compute_stress_from_F_trial");
@@ -2828,8 +2981,8 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     }
   } else {
     ScopedPhase ph(c, "p2g");
-    if (f->n_chunks || sa.n_extra || sa.z.n_wg)
-      P2G_LAUNCH(trad_fused, jt_tile, xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg), PT, 0, s, f->chunks,
+    if (f->n_chunks || sa.n_extra || sa.z.n_wg || sa.pack.n_wg)
+      P2G_LAUNCH(trad_fused, jt_tile, xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg + sa.pack.n_wg), PT, 0, s, f->chunks,
                  f->n_chunks, b, f->va(), d, c->sc.rpic_damping, dt, f->g, sa, tp);
   }
   return MPMHIP_OK;
@@ -3019,16 +3172,35 @@ int fast_dist_phase(mpmhip_ctx *c, int phase, const StepArgs &a) {
   if (phase == 0) {
     f->dist_args = a;
     if ((rc = step_phase_a(c, a))) return rc;
-    {
+    const bool fused_halo_now = f->fused_halo && !c->profiling && !c->prof_fused;   // (the pack rode in the p2g launch)
+    if (!fused_halo_now) {
       ScopedPhase ph(c, "halo_pack");  // (profiling only) with peer links: the stores into the neighbour's memory + its flag
       launch_halo(c, true);
     }
   } else if (phase == 1) {
-    {
+    const bool fused_halo_now = f->fused_halo && !c->profiling && !c->prof_fused;
+    if (!fused_halo_now) {
       ScopedPhase ph(c, "halo_add");   // (profiling only) with peer links: includes the wait for the neighbour's flag
       launch_halo(c, false);
+    } else {  // g2p adds the neighbours' shares itself: this substep's receive buffers and flags
+      f->fused_halo_steps += 1;
+      HaloIn &h = f->g.halo;
+      h = HaloIn{};
+      h.slot = f->halo_slot;
+      h.n_peers = (int)f->peers.size();
+      h.seq = (int)f->halo_seq;
+      h.ch = c->movers.empty() ? 4 : 8;
+      const int par = (int)(f->halo_seq & 1u);
+      for (size_t i = 0; i < f->peers.size(); ++i) {
+        const DistPeer &q = f->peers[i];
+        if (!q.n_blocks || !q.link_local) continue;
+        h.buf[i] = q.link_local + LINK_DATA0 + (size_t)par * q.link_cap * 8 * 64;
+        h.sig[i] = (const int *)q.link_local + par * LINK_FLAG_STRIDE;
+      }
     }
-    if ((rc = step_phase_b(c, f->dist_args))) return rc;
+    rc = step_phase_b(c, f->dist_args);
+    f->g.halo.slot = nullptr;
+    if (rc) return rc;
     if (!f->ghost_g2p) launch_ghosts(c, true);
   } else {
     if (!f->ghost_g2p) launch_ghosts(c, false);
@@ -3244,6 +3416,28 @@ static int rccl_rebin(mpmhip_ctx *c) {
     DistPeer &q = f->peers[i];
     q.link_local = p.link_local; q.link_remote = p.link_remote; q.link_cap = p.link_cap; q.link_cnt = p.link_cnt;
   }
+  // fused halo for this interval?
+  f->fused_halo = false;
+  if (f->fused_want && f->link_on && f->g2p_mflag == false && f->fuse_grid && f->peers.size() <= (size_t)PEER_TAB) {
+    bool all = true, any = false;
+    for (auto &q : f->peers)
+      if (q.n_blocks) { any = true; all = all && peer_linked(f, q); }
+    if (all && any) {
+      if (!f->halo_slot) {
+        if ((rc = dalloc(c, &f->halo_slot, f->nblocks + 1, false))) return rc;
+        f->halo_multi = f->halo_slot + f->nblocks;
+        if ((rc = dalloc(c, &f->pack_done, 1))) return rc;
+      }
+      MPM_HIP_CHECK(c, hipMemsetAsync(f->halo_slot, 0xff, f->nblocks * sizeof(int), s));
+      MPM_HIP_CHECK(c, hipMemsetAsync(f->halo_multi, 0, sizeof(int), s));
+      for (size_t i = 0; i < f->peers.size(); ++i)
+        if (f->peers[i].n_blocks)
+          hipLaunchKernelGGL(k_halo_slots, nblk(nb), TPB, 0, s, f->rpeers[i].flag, f->rpeers[i].index, nb, (int)i, f->halo_slot, f->halo_multi);
+      MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 30, f->halo_multi, sizeof(int), hipMemcpyDeviceToHost, s));
+      MPM_HIP_CHECK(c, hipStreamSynchronize(s));
+      f->fused_halo = f->h_pin[30] == 0;
+    }
+  }
   return MPMHIP_OK;
 }
 
@@ -3356,6 +3550,7 @@ int fast_rccl_steps(mpmhip_ctx *c, float dt, int n, int64_t step_index, int rebi
   return MPMHIP_OK;
 }
 int fast_dist_halo_transport(const mpmhip_ctx *c) { return c->fast->link_on ? 1 : 0; }
+int64_t fast_dist_fused_halo_steps(const mpmhip_ctx *c) { return c->fast->fused_halo_steps; }
 
 // the drift flag of this rank (set by the kernels when a particle is about to leave its tile margin); synchronous
 int fast_dist_drift_flag(mpmhip_ctx *c, int32_t *out) {

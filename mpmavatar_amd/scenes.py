@@ -206,6 +206,24 @@ def sheet(n=408, n_grid=256, collider_subdiv=5, n_steps=1000, seed=1, name=None,
                         n_steps=n_steps)
 
 
+def sheet_stack(layers, n=408, n_grid=256, dy=0.08, collider_subdiv=5, n_steps=1000, seed=1) -> Scene:
+    """Weak-scaling workload for the slab decomposition: `layers` copies of the S4 sheet (497,762 particles each) stacked dy
+    apart above the same sphere, in the same 256^3 grid.  x-slabs cut every layer, so N ranks on N layers own one sheet's worth
+    of particles each, whatever N (bench.py reports it beside the strong-scaling headline for N > 1)."""
+    vs, fs = [], []
+    rng = np.random.default_rng(seed)
+    for k in range(layers):
+        v, f = garment.grid_sheet(n, n, 0.2, 1.8, 0.2, 1.8, 1.2 + dy * k)
+        v[:, 1] += rng.uniform(-1e-4, 1e-4, v.shape[0]).astype(np.float32)
+        fs.append(f + sum(a.shape[0] for a in vs))
+        vs.append(v)
+    verts, faces = np.concatenate(vs, 0), np.concatenate(fs, 0)
+    mv, mf = garment.icosphere(collider_subdiv, 0.3, (1.0, 0.9, 1.0))
+    return _cloth_scene(f"sheet-{faces.shape[0] + verts.shape[0]}-x{layers}", verts, faces, n_grid, mesh_vertices=mv,
+                        mesh_faces=mf, mesh_v=np.zeros_like(mv), mesh_friction=0.5, bcs=[("bounding_box", {})],
+                        n_steps=n_steps)
+
+
 def demo_mix(n_grid=64, n_sheet=24, sand=(24, 4, 12), n_steps=200, seed=3, hold=None) -> Scene:
     """Reduced stand-in of the run_demo.py scene: cloth sheet + sand block (material 2)
     + floor plane (sticky surface collider) + body mesh collider + particle mover that pins the first sheet row and

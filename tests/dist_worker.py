@@ -101,8 +101,11 @@ def main():
         ss = mdist.build_sharded(sc, dev, rank, world, rebin_interval=int(os.environ.get("MPMHIP_TEST_REBIN", "8")))
         ss.migrate_fraction = float(os.environ.get("MPMHIP_TEST_MIGRATE", "0"))
         chunk = int(os.environ.get("MPMHIP_TEST_RUN_CHUNK", str(steps)))
-        for k0 in range(0, steps, chunk):  # migration is checked at the start of every run() call
+        ss.migrate_check_every = 1  # look at every run() call (production: every 512 substeps)
+        held = ss
+        for k0 in range(0, steps, chunk):  # migration is checked at the start of a run() call
             ss = mdist.run(ss, min(chunk, steps - k0))
+        ok &= ss is held                # a re-partition updates the ShardedSim in place: a caller that never rebinds is fine
         if os.environ.get("MPMHIP_DIST_TRANSPORT") == "rccl" and (torch.cuda.device_count() >= world or os.environ.get("MPMHIP_RCCL_LIB")):
             ok &= ss.transport == "rccl"   # the test asked for the in-library loop: falling back silently is a failure
         if float(os.environ.get("MPMHIP_TEST_MIGRATE", "0")) > 0:
@@ -124,6 +127,9 @@ def main():
             t = ctypes.c_int32(-1)
             ss.sim.solver._call("mpmhip_dist_halo_transport", ctypes.byref(t))
             halo = ", halos: " + ("peer-mapped" if t.value == 1 else "send/recv")
+            nf = ctypes.c_int64(0)
+            ss.sim.solver._call("mpmhip_dist_fused_halo_steps", ctypes.byref(nf))
+            halo += f", fused halo substeps {nf.value}"
         print(f"dist[{scene_name}] rank {rank}: {n_resorts} collective re-sorts in {steps} substeps ({ss.transport}{halo})", flush=True)
         got = mdist.gather_positions(ss)
         parts = [None] * world

@@ -153,7 +153,7 @@ def _mock_rccl_env(**kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("halo", ["peer", "rccl"])
+@pytest.mark.parametrize("halo", ["peer", "peer-unfused", "rccl"])
 @pytest.mark.parametrize("world,scene,steps,rebin,ghost_g2p", [
     (2, "garment", 60, 8, 1), (2, "garment", 40, 8, 0), (2, "sheet", 100, 8, 1), (3, "sheet", 60, 8, 1), (3, "demo", 60, 8, 1),
     (2, "demo", 30, 8, 0), (2, "cube", 30, 8, 1), (2, "fastcube", 200, 0, 1), (2, "sheet", 60, 0, 1), (2, "demohold", 60, 8, 1),
@@ -166,12 +166,20 @@ def test_in_library_loop_with_several_ranks(world, scene, steps, rebin, ghost_g2
     re-synchronisation at collective re-sorts, the all-reduced drift flag (rebin 0), staged release.  Result: the single
     context's trajectory.
     halo = "peer": the halos go through peer-mapped buffers (HIP IPC between the processes, flags in the receiver's
-    fine-grained memory, handshake at set-up); "rccl": through the send/recv groups."""
+    fine-grained memory, handshake at set-up) and the substep has NO halo kernels: the pack rides in the p2g launch, g2p adds
+    the neighbour's share while it stages its tile (PackArgs / HaloIn in csrc/fast.hip); "peer-unfused": the same buffers with
+    the separate pack / add kernels (MPMHIP_DIST_FUSED_HALO=0); "rccl": through the send/recv groups."""
     import re
     out = _launch(world, "gpu", scene, steps, extra_env=_mock_rccl_env(MPMHIP_TEST_REBIN=rebin, MPMHIP_DIST_GHOST_G2P=ghost_g2p,
-                                                                        MPMHIP_DIST_HALO=halo, MPMHIP_VERBOSE=1))
+                                                                        MPMHIP_DIST_HALO=halo.split("-")[0], MPMHIP_VERBOSE=1,
+                                                                        MPMHIP_DIST_FUSED_HALO=0 if halo == "peer-unfused" else 1))
     assert "max rel dx" in out and "(rccl, halos: " in out
-    assert out.count("halos: peer-mapped" if halo == "peer" else "halos: send/recv") == world, out[-2000:]
+    assert out.count("halos: peer-mapped" if halo.startswith("peer") else "halos: send/recv") == world, out[-2000:]
+    fused = [int(x) for x in re.findall(r"fused halo substeps (\d+)", out)]
+    if halo == "peer" and ghost_g2p:
+        assert len(fused) == world and min(fused) > 0, out[-2000:]   # the fused path really ran on every rank
+    elif halo != "peer":
+        assert not fused or max(fused) == 0
     n = [int(x) for x in re.findall(r"rank \d+: (\d+) collective re-sorts", out)]
     assert len(n) == world and len(set(n)) == 1          # every rank took the same decisions
     if rebin == 0:

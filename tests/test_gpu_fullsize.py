@@ -5,7 +5,7 @@ collider + mover + swaying body): 50 substeps, OpenMP oracle on all host threads
 workload): 20 substeps, OpenMP oracle.  The oracle is pinned by the reference's own source (tests/test_ref_golden.py);
 here it carries that to the sizes the reference fixtures cannot reach.  Bounds: x and v within 1e-4 (north star); for S3
 the cloth rests on the return mapping's R22 = 1 discontinuity from the first substep on, so its v bound is the reference's
-own sensitivity there (3 x the self-distance, in m/s, of the reference's garment sequence, tests/golden/ref_seq_garment.npz)."""
+own sensitivity there (1.5 x the self-distance, in m/s, of the reference's garment sequence, tests/golden/ref_seq_garment.npz)."""
 import os
 
 import numpy as np
@@ -51,7 +51,21 @@ def test_s3_garment_120k_anisotropic_with_collider_50_substeps(oracle_lib):
     envelope = max(float(np.abs(z[f"alt_s{c}_particle_v"] - z[f"s{c}_particle_v"]).max()) for c in (40, 80))
     assert rg.rel(x, o.x) < 1e-4
     dv = float(np.abs(v - o.v).max())
-    assert dv < 3.0 * envelope, (dv, envelope)
+    assert dv < 1.5 * envelope, (dv, envelope)
+
+
+def test_s3_one_frame_of_the_reference_cadence_400_fused_substeps(oracle_lib):
+    """One frame as the reference's drivers run it: 400 substeps in one fused call (train_material_params.py:616-626, body
+    advected by mesh_x + k dt mesh_v inside the library) on the full-size garment with collider, mover and swaying body,
+    against the OpenMP oracle.  x within 1e-4; v within the reference's own sensitivity at the return mapping's R22 = 1
+    discontinuity (in m/s, see the 50-substep test above) -- since the cloth QR is the oracle's bit for bit, the two take
+    the same branch on the same input and differ only through the rounding of the transfers."""
+    sc, o, x, v = _pair("garment-120k-aniso", 400, omp=True)
+    z = rg.load("ref_seq_garment")
+    envelope = max(float(np.abs(z[f"alt_s{c}_particle_v"] - z[f"s{c}_particle_v"]).max()) for c in (40, 80))
+    assert rg.rel(x, o.x) < 1e-4 and rg.rel_pp(x, o.x) < 1e-4
+    dv = float(np.abs(v - o.v).max())
+    assert dv < 1.5 * envelope, (dv, envelope)
 
 
 def test_s4_sheet_500k_20_substeps(oracle_lib):

@@ -20,21 +20,8 @@ from mpmavatar_amd import build as B  # noqa: E402
 def one(spec):
     name, _, defs = spec.partition(":")
     defs = [d for d in defs.split(",") if d]
-    vdir = os.path.join(B.LIBDIR, "variants")
-    os.makedirs(vdir, exist_ok=True)
     every = "ALL" in defs  # name:ALL,-flag,...  compiles every source with the flags (later flags override build.py's)
-    defs = [d for d in defs if d != "ALL"]
-    objs = []
-    for src in B.SOURCES:
-        if src != "fast.hip" and not every:
-            objs.append(os.path.join(B.OBJDIR, src.replace(".hip", ".o")))
-            continue
-        obj = os.path.join(vdir, f"{src[:-4]}_{name}.o")
-        subprocess.check_call([B.HIPCC] + B.FLAGS + defs + ["-c", os.path.join(B.CSRC, src), "-o", obj], stderr=subprocess.DEVNULL)
-        objs.append(obj)
-    lib = os.path.join(vdir, f"libmpmhip_{name}.so")
-    subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
-    return lib
+    return B.build_variant(name, [d for d in defs if d != "ALL"], every)
 
 
 if __name__ == "__main__":

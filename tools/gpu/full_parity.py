@@ -37,7 +37,7 @@ for m in marks:
     st = a.solver.stats()
     vmax = float(np.linalg.norm(o.v, axis=1).max())
     ppx, ppv, ppvs = rel_pp(x, o.x, 1e-3), rel_pp(v, o.v, 1e-3), rel_pp(v, o.v, max(1e-3 * vmax, 1e-30))
-    rows.append(dict(substep=m, rel_dx=ex, rel_dv=ev, rel_dv_p999=p999, pp_dx=ppx, pp_dv_floor_1e-3=ppv, pp_dv_floor_1e-3_vmax=ppvs, max_v=float(np.abs(o.v).max()), rebins=int(st["rebins"]),
+    rows.append(dict(substep=m, rel_dx=ex, rel_dv=ev, rel_dv_p999=p999, pp_dx=ppx, pp_dv=ppv, pp_dv_floor_scaled=ppvs, max_v=float(np.abs(o.v).max()), rebins=int(st["rebins"]),
                      fallback=int(st["n_fallback_particles"]), dropped=int(st["n_dropped"])))
     if first["x"] is None and ex > 1e-4: first["x"] = m
     if first["v"] is None and ev > 1e-4: first["v"] = m
