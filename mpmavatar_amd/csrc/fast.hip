@@ -958,6 +958,7 @@ struct SplatArgs {
   JointSplatArgs js;       // workgroups [n_fbins, n_fbins + n_mov_wg): joints
   int n_mov_wg;
   int n_extra;             // n_fbins + n_mov_wg rounded up to a multiple of 8 (keeps the XCD mapping of the chunks)
+  int e0;                  // first workgroup of the splats: 0 (in front of the chunks) or xcd_grid(n_chunks) (behind them)
   ZeroArgs z;              // workgroups [z_first, z_first + z.n_wg), after the chunk workgroups: clear the other
   int z_first;             // accumulator buffer
   PackArgs pack;           // workgroups [pack.first, ...) after those: multi-GPU halo pack (see PackArgs)
@@ -1361,6 +1362,7 @@ __device__ __forceinline__ void col_splat_flush(const double *tile, int ox, int 
   }
 }
 
+constexpr int SPLAT_SMALL = 32;  // faces per bin up to which the splat workgroup maps lanes to (face, node) pairs
 __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, int bin, const Dims &d, const GridPtrs &g) {
   const FaceBin fb = sa.fbins[bin];
   int blk = fb.blk;
@@ -1377,6 +1379,72 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
   }
   unsigned long long act_mask = __ballot(nb_act);
   const int end = fb.start + fb.cnt;
+  if (fb.cnt <= SPLAT_SMALL) {
+    // SMALL BIN (the common case once the cloth has draped: ~740 bins of ~27 faces): lane = (face, stencil node), 8 faces x 32
+    // lanes (27 used) per step, <= 4 steps -- instead of lane = face with a 27-trip node loop of dependent DPP scans that 230
+    // of the 256 lanes sit out.  Such a workgroup used to live 10-17 us (two 3 us scatter passes, profiles/r03_wg_timeline.md);
+    // what is left is its chain of loads and the two flushes.  The per-step weights and normals stay in registers for the
+    // second (normal) pass through the four-channel tile.
+    const int fi = l >> 5, n = l & 31;
+    const int ni = n / 9, nj = (n / 3) % 3, nk = n % 3;
+    float wk[SPLAT_SMALL / 8];
+    V3 fnk[SPLAT_SMALL / 8];
+    int basek[SPLAT_SMALL / 8];
+    for (int t = l; t < 4 * TILE_PAD; t += PT) tile[t] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < SPLAT_SMALL / 8; ++it) {
+      const int q = it * 8 + fi;
+      const bool have = q < fb.cnt && n < 27;
+      const int jq = q < fb.cnt ? fb.start + q : fb.start;
+      int i0 = sa.fidx[3 * jq], i1 = sa.fidx[3 * jq + 1], i2 = sa.fidx[3 * jq + 2];
+      V3 p0 = mesh_point(sa.pts, sa.vel, sa.adv, i0), p1 = mesh_point(sa.pts, sa.vel, sa.adv, i1), p2 = mesh_point(sa.pts, sa.vel, sa.adv, i2);
+      V3 u0 = load_v3(sa.vel + 3 * i0), u1 = load_v3(sa.vel + 3 * i1), u2 = load_v3(sa.vel + 3 * i2);
+      V3 fp = v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
+      V3 a = v3((u0.x + u1.x + u2.x) / 3.0f, (u0.y + u1.y + u2.y) / 3.0f, (u0.z + u1.z + u2.z) / 3.0f);
+      V3 fn = normalize(cross(p1 - p0, p2 - p0));  // wp.mesh_eval_face_normal
+      Stencil s = make_stencil(fp, d.inv_dx);
+      const bool ok = have && splat_ok(d.G, s);  // mpm_solver.py:858
+      const int lx = s.bx - ox, ly = s.by - oy, lz = s.bz - oz;
+      const bool in_tile = !((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u);
+      const float w = sel3(ni, s.w0.x, s.w1.x, s.w2.x) * sel3(nj, s.w0.y, s.w1.y, s.w2.y) * sel3(nk, s.w0.z, s.w1.z, s.w2.z);
+      wk[it] = 0.0f; fnk[it] = fn; basek[it] = 0;
+      if (ok && in_tile) {
+        wk[it] = w;
+        basek[it] = tile_idx(lx + ni, ly + nj, lz + nk);
+        double *p = tile + basek[it];
+        atomicAdd(p, (double)w);
+        atomicAdd(p + TILE_PAD, (double)(w * a.x)); atomicAdd(p + 2 * TILE_PAD, (double)(w * a.y)); atomicAdd(p + 3 * TILE_PAD, (double)(w * a.z));
+      } else if (ok) {  // drifted out of the tile margin since the faces were binned: this lane's node through global atomics
+        raise_drift(g.counters, g.step_id);
+        raise_face(g.counters, g.step_id);
+        int x = s.bx + ni, y = s.by + nj, z = s.bz + nk;
+        int nb = blk_of(x, y, z, d.NB);
+        if (g.ab_flag[nb]) {
+          float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
+          g.col_flag[nb] = 1;
+          atomicAdd(p, w);
+          atomicAdd(p + 64, w * a.x); atomicAdd(p + 128, w * a.y); atomicAdd(p + 192, w * a.z);
+          atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
+        }
+      }
+    }
+    __syncthreads();
+    col_splat_flush<0>(tile, ox, oy, oz, bx, by, bz, act_mask, d, g);
+    __syncthreads();
+    for (int t = l; t < 3 * TILE_PAD; t += PT) tile[t] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < SPLAT_SMALL / 8; ++it)
+      if (wk[it] != 0.0f) {
+        double *p = tile + basek[it];
+        atomicAdd(p, (double)(wk[it] * fnk[it].x)); atomicAdd(p + TILE_PAD, (double)(wk[it] * fnk[it].y));
+        atomicAdd(p + 2 * TILE_PAD, (double)(wk[it] * fnk[it].z));
+      }
+    __syncthreads();
+    col_splat_flush<1>(tile, ox, oy, oz, bx, by, bz, act_mask, d, g);
+    return;
+  }
   for (int j0 = fb.start; j0 < end; j0 += PT) {  // workgroup-uniform trip count: barriers and DPP need converged lanes
     for (int t = l; t < 4 * TILE_PAD; t += PT) tile[t] = 0.0;
     int jj = j0 + l;
@@ -1459,8 +1527,11 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
     __hip_atomic_store(g.host_sig + SIG_RING0 + (g.step_id & (SIG_RING_N - 1)), (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(g.host_sig + SIG_PROGRESS, g.step_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  if ((int)blockIdx.x < sa.n_extra) {  // extra workgroups first: they are the long-latency ones
-    int e = blockIdx.x;
+  // The splat workgroups go in front of the chunks (e0 = 0: the longest workgroups of the launch start first) or behind them
+  // (e0 = xcd_grid(n_chunks), MPMHIP_SPLAT_FIRST_MAX): measured the same to 1 % early and in the draped state, where ~740 of them
+  // take more than half of the first-round slots -- the dispatcher evens it out.
+  if ((int)blockIdx.x >= sa.e0 && (int)blockIdx.x < sa.e0 + sa.n_extra) {
+    int e = (int)blockIdx.x - sa.e0;
     if (DBG(g, 256)) return;
     if (e < sa.n_fbins) { if (!DBG(g, 8192)) col_splat_wg(tile, sa, e, d, g); }   // (8192 / 16384: ablation switches)
     else if (e < sa.n_fbins + sa.n_mov_wg) { if (!DBG(g, 16384)) mover_splat_wg(b, sa.js, e - sa.n_fbins, d, g); }
@@ -1478,7 +1549,7 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
     WGT(g, 0, 6);
     return;
   }
-  int w = xcd_slice((int)blockIdx.x - sa.n_extra, n_chunks);
+  int w = xcd_slice((int)blockIdx.x - (sa.e0 == 0 ? sa.n_extra : 0), n_chunks);
   if (w < 0) { wg_done(sa.pack); return; }
   if (g.stagger > 0 && (int)blockIdx.x < g.stagger_first) {
     // The workgroups of the first round all start within a microsecond, load together and then scatter together: memory
@@ -2237,6 +2308,8 @@ struct FastState {
   bool dist = false;  // multi-GPU: re-sorts only on request (all ranks re-sort together)
   bool dist_keep_cur = false;  // re-sort inside mpmhip_rccl_steps: the caller's mesh pointers are valid
   bool g2p_two_pass = false;   // k_g2p<., true, .>: see there (default: scenes without traditional particles)
+  int splat_first_max = 1 << 30;  // more splat workgroups than this go behind the chunk workgroups (MPMHIP_SPLAT_FIRST_MAX; measured
+                                  // neutral early and late -- profiles/r03_experiments.md -- so they stay in front)
   bool w6 = false;             // six-wavefront builds of the cloth kernels (k_p2g_w6, k_g2p_w6): MPMHIP_W6
   bool g2p_mflag = false;      // g2p asks m_flag before it loads a block's accumulators (one more dependent memory level at the head
                                // of every workgroup; the default loads them with the particle positions): MPMHIP_G2P_MFLAG=1
@@ -2689,6 +2762,7 @@ int fast_init(mpmhip_ctx *c) {
   if (const char *e = getenv("MPMHIP_FUSE_TRAD")) f->fuse_trad = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_DIST_FUSED_HALO")) f->fused_want = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_W6")) f->w6 = atoi(e) != 0;
+  if (const char *e = getenv("MPMHIP_SPLAT_FIRST_MAX")) f->splat_first_max = atoi(e);
   f->g.stagger = 0; f->g.stagger_groups = 2; f->g.stagger_first = 0;
   if (const char *e = getenv("MPMHIP_P2G_STAGGER")) {  // "units[,groups[,first]]": units of 1024 cycles per group step
     int u = 0, gr = 2, first = 1280;
@@ -2921,6 +2995,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   }
   sa.n_extra = (sa.n_fbins + sa.n_mov_wg + 7) & ~7;
   sa.z_first = sa.n_extra + (int)xcd_grid(f->n_chunks);
+  sa.e0 = (sa.n_extra > f->splat_first_max && !c->profiling) ? (int)xcd_grid(f->n_chunks) : 0;
   const bool fused_halo_now = f->dist && f->fused_halo && !c->profiling && !c->prof_fused;
   if (fused_halo_now) {  // (multi-GPU) the halo pack rides in this launch, behind the clearing workgroups: see PackArgs
     HaloTab &tb = sa.pack.tb;

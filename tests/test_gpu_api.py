@@ -350,3 +350,26 @@ def test_export_particle_cov_to_torch(mode):
     torch.cuda.synchronize()
     assert rel(out.cpu().numpy(), want) < 2e-6
     assert lib.mpmhip_cov_from_F(0, None, None, b.data_ptr(), n, out.data_ptr()) != 0
+
+
+def test_write_through_a_view_is_never_lost_silently():
+    """A VIEW of a solver-written field kept across substeps: either it has been kept current -- then the write through
+    it takes effect exactly like a write into the freshly read field -- or the next substep refuses it loudly (RuntimeError
+    "stale view").  What must not happen is the third thing: the solver's newer state silently written over the caller's edit."""
+    sc = scenes.small_sheet()
+    ref = harness.build_solver(sc, "cuda:0", mode="fast")
+    harness.run(ref, 3, fused=True)
+    ref.state.particle_v[:10].mul_(0.5)       # the documented way: read again, then modify
+    harness.run(ref, 2, fused=True)
+    want = ref.state.particle_v.cpu().numpy()
+
+    sim = harness.build_solver(sc, "cuda:0", mode="fast")
+    view = sim.state.particle_v[:10]          # kept across the substeps
+    harness.run(sim, 3, fused=True)
+    view.mul_(0.5)
+    try:
+        harness.run(sim, 2, fused=True)
+    except RuntimeError as e:
+        assert "stale view" in str(e)
+        return
+    assert rel(sim.state.particle_v.cpu().numpy(), want) < 1e-6

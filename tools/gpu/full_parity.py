@@ -7,7 +7,7 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from mpmavatar_amd import harness, scenes
-from oracle.scene_adapter import oracle_from_scene, run_scene
+from oracle.scene_adapter import omp_threads, oracle_from_scene, run_scene
 
 name = sys.argv[1] if len(sys.argv) > 1 else "sheet-500k"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -15,7 +15,7 @@ gamma0 = name.endswith("@gamma0")   # the same scene without the shear-friction 
 sc = scenes.REGISTRY[name.split("@")[0]]()
 if gamma0:
     sc.gamma = 0.0
-cores = os.cpu_count() or 1
+cores = omp_threads()
 o = oracle_from_scene(sc, omp=True, n_threads=cores)
 a = harness.build_solver(sc, "cuda:0", mode="fast")
 rel = lambda x, y: float(np.abs(x - y).max() / max(np.abs(y).max(), 1e-3))
