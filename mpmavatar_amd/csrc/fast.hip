@@ -796,19 +796,31 @@ struct PackArgs {
   HaloTab tb;
   unsigned *done;   // running count of finished workgroups (wraps)
   unsigned target;  // value it reaches when this launch's are all done
-  int first, n_wg;  // pack workgroups: blockIdx in [first, first + n_wg); n_wg == 0: none, nobody counts
+  int first, n_wg;  // pack workgroups: blockIdx in [first, first + n_wg); n_wg == 0: none
+  int count;        // the scattering workgroups count themselves done (pack workgroups wait for them)
 };
+// What the waiting side reads are the accumulators, and those are only ever touched by device-scope atomics (performed at the
+// memory side, coherent across the XCDs' L2s) -- so "done" needs no cache write-back: a workgroup waits until its own atomics
+// are acknowledged (s_waitcnt vmcnt(0)) and then bumps a RELAXED counter.  (A release fence at agent scope instead costs an L2
+// write-back per workgroup and those serialise: a launch of 5,100 workgroups took 427 us instead of 30, profiles/r03_experiments.md.)
+// The count is spread over DONE_SHARDS addresses 64 bytes apart: arrivals on one address serialise too.
+constexpr int DONE_SHARDS = 64, DONE_STRIDE = 16;
 __device__ __forceinline__ void wg_done(const PackArgs &pk) {
-  if (pk.n_wg == 0) return;
-  __threadfence();
+  if (!pk.count) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(pk.done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0)
+    __hip_atomic_fetch_add(pk.done + (blockIdx.x & (DONE_SHARDS - 1)) * DONE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void pack_wait(const PackArgs &pk, int *err) {
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {  // wavefront 0: lane l reads shard l, the wavefront sums
     long long t0 = wall_clock64();
-    while ((int)(__hip_atomic_load(pk.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - pk.target) < 0) {
-      __builtin_amdgcn_s_sleep(2);
+    for (;;) {
+      unsigned v = __hip_atomic_load(pk.done + (threadIdx.x & (DONE_SHARDS - 1)) * DONE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if ((int)(v - pk.target) >= 0) break;
+      __builtin_amdgcn_s_sleep(32);
       if (wall_clock64() - t0 > LINK_TIMEOUT_TICKS) { *err = 1; break; }
     }
   }
@@ -1358,7 +1370,7 @@ __device__ __forceinline__ void col_splat_flush(const double *tile, int ox, int 
     if (!((act_mask >> nidx) & 1ull)) continue;  // inactive block: never read by g2p, never re-zeroed
     float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z) + (PASS == 0 ? 0 : 256);
     atomicAdd(p, c0); atomicAdd(p + 64, c1); atomicAdd(p + 128, c2);
-    if (PASS == 0) { atomicAdd(p + 192, c3); g.col_flag[nb] = 1; }
+    if (PASS == 0) { atomicAdd(p + 192, c3); __hip_atomic_store(&g.col_flag[nb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   }
 }
 
@@ -1422,7 +1434,7 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
         int nb = blk_of(x, y, z, d.NB);
         if (g.ab_flag[nb]) {
           float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
-          g.col_flag[nb] = 1;
+          __hip_atomic_store(&g.col_flag[nb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           atomicAdd(p, w);
           atomicAdd(p + 64, w * a.x); atomicAdd(p + 128, w * a.y); atomicAdd(p + 192, w * a.z);
           atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
@@ -1484,7 +1496,7 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
         int nb = blk_of(x, y, z, d.NB);
         if (g.ab_flag[nb]) {
           float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
-          g.col_flag[nb] = 1;
+          __hip_atomic_store(&g.col_flag[nb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           atomicAdd(p, w);
           atomicAdd(p + 64, w * a.x); atomicAdd(p + 128, w * a.y); atomicAdd(p + 192, w * a.z);
           atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
@@ -1508,10 +1520,8 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
 // second pass through the same LDS tile by the chunk that owns them instead of 27 x 4 scattered global atomics each.
 template <int STEPS, bool TRAD, bool JT>
 __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, const Bufs &b, const VAdj &va, const Dims &d, float rpic,
-                                         float dt, const GridPtrs &g, const SplatArgs &sa, const TradParams &tp) {
-  __shared__ double tile[4 * TILE_PAD];
-  __shared__ int esc[CHUNK];
-  __shared__ int esc_n;
+                                         float dt, const GridPtrs &g, const SplatArgs &sa, const TradParams &tp, double *tile, int *esc,
+                                         int &esc_n) {
   WGT(g, 0, 0);
   if (blockIdx.x == 0 && threadIdx.x == 0 && g.host_sig) {
     // progress + drift flag for the host (plain stores into pinned host memory instead of a copy + event every few
@@ -1639,7 +1649,10 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
 template <int STEPS, bool TRAD, bool JT>
 __global__ __launch_bounds__(PT) void k_p2g(const ChunkRec *recs, int n_chunks, Bufs b, VAdj va, Dims d, float rpic, float dt,
                                              GridPtrs g, SplatArgs sa, TradParams tp) {
-  p2g_body<STEPS, TRAD, JT>(recs, n_chunks, b, va, d, rpic, dt, g, sa, tp);
+  __shared__ double tile[4 * TILE_PAD];
+  __shared__ int esc[CHUNK];
+  __shared__ int esc_n;
+  p2g_body<STEPS, TRAD, JT>(recs, n_chunks, b, va, d, rpic, dt, g, sa, tp, tile, esc, esc_n);
 }
 // The cloth instantiation with six wavefronts per SIMD instead of the five its 90 VGPRs allow: 80 VGPRs + 9 spilled dwords.
 // A workgroup's life is a chain of memory latencies (record -> particles -> adjacency -> corner forces) followed by a
@@ -1648,7 +1661,10 @@ __global__ __launch_bounds__(PT) void k_p2g(const ChunkRec *recs, int n_chunks, 
 // update would spill 216 bytes per lane and keeps its natural budget.)
 __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6)))
 void k_p2g_w6(const ChunkRec *recs, int n_chunks, Bufs b, VAdj va, Dims d, float rpic, float dt, GridPtrs g, SplatArgs sa, TradParams tp) {
-  p2g_body<3, false, false>(recs, n_chunks, b, va, d, rpic, dt, g, sa, tp);
+  __shared__ double tile[4 * TILE_PAD];
+  __shared__ int esc[CHUNK];
+  __shared__ int esc_n;
+  p2g_body<3, false, false>(recs, n_chunks, b, va, d, rpic, dt, g, sa, tp, tile, esc, esc_n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1862,10 +1878,9 @@ __device__ __forceinline__ void g2p_write(const Bufs &b, int cls, int s, V3 x, V
 // (HaloIn), after the workgroup has seen the neighbour's flag for this substep.
 template <bool FUSED, bool TWO_PASS, bool MFLAG, bool HALO = false>
 __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, const Bufs &b, const Dims &d, float dt, const GridPtrs &g,
-                                         const GridParams &gp, const BCList &bcl) {
-  __shared__ float4 tile[TILE_PAD];  // node velocity, 16 bytes per node
+                                         const GridParams &gp, const BCList &bcl, float4 *tile, int wg) {
   WGT(g, 1, 0);
-  int w = xcd_slice(blockIdx.x, n_chunks);
+  int w = xcd_slice(wg, n_chunks);
   if (w < 0) return;
   const ChunkRec cm = recs[w];
   int blk = cm.blk, chunk = cm.chunk;
@@ -2009,19 +2024,22 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
 template <bool FUSED, bool TWO_PASS, bool MFLAG>
 __global__ __launch_bounds__(PT) void k_g2p(const ChunkRec *recs, int n_chunks, Bufs b, Dims d, float dt, GridPtrs g, GridParams gp,
                                              BCList bcl) {
-  g2p_body<FUSED, TWO_PASS, MFLAG>(recs, n_chunks, b, d, dt, g, gp, bcl);
+  __shared__ float4 tile[TILE_PAD];  // node velocity, 16 bytes per node
+  g2p_body<FUSED, TWO_PASS, MFLAG>(recs, n_chunks, b, d, dt, g, gp, bcl, tile, (int)blockIdx.x);
 }
 // multi-GPU: fused halo add (see HaloIn)
 template <bool TWO_PASS>
 __global__ __launch_bounds__(PT) void k_g2p_halo(const ChunkRec *recs, int n_chunks, Bufs b, Dims d, float dt, GridPtrs g, GridParams gp,
                                                   BCList bcl) {
-  g2p_body<true, TWO_PASS, false, true>(recs, n_chunks, b, d, dt, g, gp, bcl);
+  __shared__ float4 tile[TILE_PAD];
+  g2p_body<true, TWO_PASS, false, true>(recs, n_chunks, b, d, dt, g, gp, bcl, tile, (int)blockIdx.x);
 }
 // six wavefronts per SIMD for the fused two-pass form (94 VGPRs -> 80 + 12 spilled dwords), see k_p2g_w6
 template <bool MFLAG>
 __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6)))
 void k_g2p_w6(const ChunkRec *recs, int n_chunks, Bufs b, Dims d, float dt, GridPtrs g, GridParams gp, BCList bcl) {
-  g2p_body<true, true, MFLAG>(recs, n_chunks, b, d, dt, g, gp, bcl);
+  __shared__ float4 tile[TILE_PAD];
+  g2p_body<true, true, MFLAG>(recs, n_chunks, b, d, dt, g, gp, bcl, tile, (int)blockIdx.x);
 }
 
 // second half of g2p_e (mpm_utils.py:838-857): x, v = mean of the three updated vertices; d1, d2 = edges
@@ -2747,6 +2765,7 @@ int fast_init(mpmhip_ctx *c) {
   select_buffer(f, 0);
   if ((rc = dalloc(c, &f->g.vout, f->nblocks * GCH_VOUT * 64))) return rc;
   if ((rc = dalloc(c, &f->g.counters, CNT_N))) return rc;
+  if ((rc = dalloc(c, &f->pack_done, (size_t)DONE_SHARDS * DONE_STRIDE))) return rc;
   // one allocation, one memset per re-sort: [particle-block flags | active-block flags | device counts]
   static_assert(RC_N <= 64, "device counts of a re-sort");
   if ((rc = dalloc(c, &f->pb_flag, 2 * f->nblocks + 64))) return rc;
@@ -3013,6 +3032,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     tb.seq = (int)f->halo_seq;
     sa.pack.n_wg = tb.wg_off[tb.n];
     sa.pack.first = sa.z_first + sa.z.n_wg;
+    sa.pack.count = 1;
     sa.pack.done = f->pack_done;
     f->pack_target += (unsigned)sa.z_first;  // every workgroup in front of the clearing ones counts itself done
     sa.pack.target = f->pack_target;
@@ -3063,6 +3083,19 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   return MPMHIP_OK;
 }
 
+// grid-stage parameters of this substep (the BC list as it stands BEFORE this substep's bc_host_modify)
+static void grid_stage_params(mpmhip_ctx *c, const StepArgs &a, GridParams &gp, BCList &bcl) {
+  const bool mov_on = a.joint_v_v && a.joint_f_v && !c->movers.empty();
+  gp = GridParams{a.dt, c->sc.g[0], c->sc.g[1], c->sc.g[2], c->sc.grid_v_damping_scale, (float)c->time,
+                  (c->colliders.empty() || !c->num_mesh_f) ? 0 : 1, c->movers.empty() ? 0 : 1, mov_on ? 1 : 0,
+                  c->colliders.empty() ? 0.0f : c->colliders[0].friction, 0};
+  gp.n_col_more = std::max(0, std::min(3, (int)c->colliders.size() - 1));
+  for (int k = 0; k < gp.n_col_more; ++k) gp.col_friction_more[k] = c->colliders[k + 1].friction;
+  bcl = BCList{};
+  bcl.n = (int)c->bcs.size();
+  for (int k = 0; k < bcl.n; ++k) bcl.bc[k] = c->bcs[k];
+}
+
 static int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
   FastState *f = c->fast;
   const Dims &d = f->d;
@@ -3071,15 +3104,9 @@ static int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
   (void)rc; (void)d; (void)s;
   const float dt = a.dt;
   Bufs &b = f->buf[f->cur];
-  bool mov_on = a.joint_v_v && a.joint_f_v && !c->movers.empty();
-  GridParams gp{dt, c->sc.g[0], c->sc.g[1], c->sc.g[2], c->sc.grid_v_damping_scale, (float)c->time,
-                (c->colliders.empty() || !c->num_mesh_f) ? 0 : 1, c->movers.empty() ? 0 : 1, mov_on ? 1 : 0,
-                c->colliders.empty() ? 0.0f : c->colliders[0].friction, 0};
-  gp.n_col_more = std::max(0, std::min(3, (int)c->colliders.size() - 1));
-  for (int k = 0; k < gp.n_col_more; ++k) gp.col_friction_more[k] = c->colliders[k + 1].friction;
-  BCList bcl{};
-  bcl.n = (int)c->bcs.size();
-  for (int k = 0; k < bcl.n; ++k) bcl.bc[k] = c->bcs[k];
+  GridParams gp;
+  BCList bcl;
+  grid_stage_params(c, a, gp, bcl);
   const bool fused = f->fuse_grid && !c->profiling;
   if (!fused) {
     ScopedPhase ph(c, "grid_update");
@@ -3501,7 +3528,6 @@ static int rccl_rebin(mpmhip_ctx *c) {
       if (!f->halo_slot) {
         if ((rc = dalloc(c, &f->halo_slot, f->nblocks + 1, false))) return rc;
         f->halo_multi = f->halo_slot + f->nblocks;
-        if ((rc = dalloc(c, &f->pack_done, 1))) return rc;
       }
       MPM_HIP_CHECK(c, hipMemsetAsync(f->halo_slot, 0xff, f->nblocks * sizeof(int), s));
       MPM_HIP_CHECK(c, hipMemsetAsync(f->halo_multi, 0, sizeof(int), s));
