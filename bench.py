@@ -82,17 +82,17 @@ def cpu_baseline(sc, budget_s=15.0, serial_budget_s=8.0):
     """Time the CPU oracle (OpenMP build, all host cores) on a bounded number of substeps of the same scene."""
     from oracle.scene_adapter import omp_threads, oracle_from_scene, run_scene
     # The thread count is probed, not taken from os.cpu_count(): the oracle's parallel regions are short and atomics-heavy, and on
-    # the MI355X box 256 threads run 20x slower than 16 (profiles/r03_oracle_threads.txt).  One substep each, the fastest is timed.
+    # the MI355X box 256 threads run 20x slower than 16 (profiles/r03_oracle_threads.txt).  Three substeps each, the fastest is timed.
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     best = None
-    for th in sorted({t for t in (8, omp_threads(), 32, 64) if t <= avail} or {1}):
+    for th in sorted({t for t in (8, omp_threads(), 32) if t <= avail} or {1}):
         oc = oracle_from_scene(sc, omp=True, n_threads=th)
         run_scene(oc, sc, 1)  # warm caches / page in the dense grids
         t0 = time.perf_counter()
-        run_scene(oc, sc, 1, k0=1)
+        run_scene(oc, sc, 3, k0=1)
         el = time.perf_counter() - t0
         if best is None or el < best[0]:
             best = (el, th, oc)
@@ -100,7 +100,7 @@ def cpu_baseline(sc, budget_s=15.0, serial_budget_s=8.0):
     del best, oc
     n, t0 = 0, time.perf_counter()
     while True:
-        run_scene(o, sc, 1, k0=n + 1)
+        run_scene(o, sc, 1, k0=n + 4)
         n += 1
         el = time.perf_counter() - t0
         if el > budget_s or n >= 400:
