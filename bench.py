@@ -154,6 +154,9 @@ def _main(out_stream):
     ap.add_argument("--weak", action="store_true", help="N > 1: time ONLY the weak-scaling workload (N stacked copies of the headline "
                     "sheet, one sheet's worth of particles per rank) instead of the strong-scaling headline")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the additional weak-scaling measurement")
+    ap.add_argument("--weak-n", type=int, default=0, help="diagnostics / tests: vertices per side of the stacked sheets of the "
+                    "weak-scaling workload (default: the headline sheet's 408) -- also runs it beside scenes other than sheet-500k")
+    ap.add_argument("--weak-grid", type=int, default=256)
     ap.add_argument("--force-dist", action="store_true", help="diagnostics: run the sharded driver even with one rank "
                     "(launch under torch.distributed.run --nproc-per-node 1)")
     args = ap.parse_args()
@@ -193,7 +196,8 @@ def _main(out_stream):
     dev = f"cuda:{local_rank}"
 
     weak_only = args.weak and world > 1 and args.scene == "sheet-500k"
-    sc = scenes.sheet_stack(world) if weak_only else scenes.REGISTRY[args.scene]()
+    weak_scene = lambda: scenes.sheet_stack(world, n=args.weak_n or 408, n_grid=args.weak_grid)
+    sc = weak_scene() if weak_only else scenes.REGISTRY[args.scene]()
     sharded = world > 1 or args.force_dist
     if sharded:
         import torch.distributed as dist
@@ -376,11 +380,11 @@ def _main(out_stream):
                            "channels_per_node": ch, "peers_of_rank0": len(box["ss"].static) - 1,
                            "halo_exchange_us": next((k["ms"] * 1e3 for k in kernels if k["phase"] == "halo_exchange"), None),
                            "re_partitions": box["ss"].migrations}
-    if sharded and world > 1 and not weak_only and not args.no_weak and args.scene == "sheet-500k":
+    if sharded and world > 1 and not weak_only and not args.no_weak and (args.scene == "sheet-500k" or args.weak_n):
         # the regime the slab decomposition is made for: the same per-rank work at every N (one sheet's worth of particles per
         # rank: N stacked copies of the headline sheet in the same grid).  Reported beside the strong-scaling headline value.
         try:
-            wsc = scenes.sheet_stack(world)
+            wsc = weak_scene()
             wbox = {"ss": mdist.build_sharded(wsc, dev, rank, world, rebin_interval=args.rebin_interval)}
             wbox["ss"] = mdist.run(wbox["ss"], args.warmup)
             barrier(); torch.cuda.synchronize()

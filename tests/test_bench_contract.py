@@ -30,8 +30,12 @@ def _check(o, n_gpus=1, with_cpu=True):
 
 
 def test_committed_bench_line_follows_the_contract():
-    o = json.load(open(os.path.join(ROOT, "profiles", "r02b_sheet-500k_bench.json")))
+    o = json.load(open(os.path.join(ROOT, "profiles", "r03_sheet-500k_bench.json")))
     _check(o)
+    # round 3: traffic-based fractions beside the algorithmic ones, the CPU baseline at a probed thread count and on one thread
+    assert 0 < o["roofline"]["traffic_frac"] < 1 and all("traffic_frac" in k for k in o["kernels"] if "alg_bytes" in k)
+    assert 0 < o["substep_roofline"]["traffic_frac"] < 1
+    assert o["cpu_baseline"]["cores"] <= 64 and o["cpu_baseline"]["serial"]["cores"] == 1 and o["cpu_baseline"]["serial"]["value"] > 0
     assert o["config"]["workload"] == "sheet-500k" and o["config"]["n_particles"] == 497762 and o["config"]["n_grid"] == 256
     # round 2: the roofline's kernel is one of the launches of the timed (fused) loop, and the steady state is reported
     assert o["kernels_mode"] == "fused-loop" and o["roofline"]["kernel"] in {k["name"] for k in o["kernels"]}
@@ -58,7 +62,7 @@ def test_bench_gpus_n_without_a_launcher():
     import torch
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scene", "cube-8k", "--steps", "20", "--warmup", "5",
-            "--advance", "0", "--no-cpu-baseline"]
+            "--advance", "0", "--no-cpu-baseline", "--weak-n", "48", "--weak-grid", "64"]
     r = subprocess.run(base, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     if torch.cuda.device_count() >= 2:
         assert r.returncode == 0, r.stderr[-2000:]
@@ -78,6 +82,10 @@ def test_bench_gpus_n_without_a_launcher():
     # N > 1 lines carry the per-rank roofline and what the exchange moves
     assert o["roofline"]["bound"] == "hbm" and 0 < o["roofline"]["frac"] < 1 and o["kernels_mode"].startswith("fused-loop, rank 0")
     assert o["exchange"]["transport"] in ("torch", "rccl") and o["exchange"]["halo_bytes_per_substep_sent_by_rank0"] > 0
+    # ... and the weak-scaling workload measured in the same run (two stacked sheets cut into two slabs; here a small one)
+    w = o["weak_scaling"]
+    assert "error" not in w, w
+    assert w["value"] > 0 and w["n_particles"] == 2 * w["particles_per_rank"] and w["unit"] == "substeps/s"
     assert o["config"]["exchange"] == o["exchange"]["transport"]
     # the in-library loop (what a multi-GPU node runs), its RCCL entry points bound to the shared-memory stand-in
     sys.path.insert(0, os.path.join(ROOT, "tests", "mock_rccl"))
