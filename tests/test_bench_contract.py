@@ -97,3 +97,6 @@ def test_bench_gpus_n_without_a_launcher():
     _check(o, n_gpus=2, with_cpu=False)
     assert o["exchange"]["transport"] == "rccl" and o["exchange"]["halo"].startswith("peer-mapped")
     assert 0 < o["roofline"]["frac"] < 1
+    # the weak-scaling measurement builds a second sharded simulation (second communicator, second set of peer links) in the
+    # same processes while the first is alive
+    assert "error" not in o["weak_scaling"] and o["weak_scaling"]["value"] > 0, o["weak_scaling"]
