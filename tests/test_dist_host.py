@@ -74,3 +74,22 @@ def test_held_share_is_a_suffix_of_the_owned_particles():
                 assert set(sh.own_t[sh.own_t.size - h:].tolist()) == held_global & set(sh.own_t.tolist())
                 tot += h
             assert tot == len(held_global)
+
+
+def test_weak_scaling_workload_gives_every_rank_one_sheets_worth():
+    """bench.py's weak-scaling scene (N stacked copies of the sheet, cut into N x-slabs): every rank owns 1/N of EVERY layer,
+    i.e. one sheet's worth of particles, whatever N."""
+    import numpy as np
+    from mpmavatar_amd import dist as mdist, scenes
+    for world in (2, 3):
+        sc = scenes.sheet_stack(world, n=24, n_grid=32)
+        one = scenes.sheet(n=24, n_grid=32)
+        assert sc.n_particles == world * one.n_particles and sc.n_elements == world * one.n_elements
+        shards = mdist.partition(sc, world)
+        owned = [s.own_e.size + s.own_t.size + s.own_v.size for s in shards]
+        assert sum(owned) == sc.n_particles
+        assert max(owned) - min(owned) <= 0.1 * one.n_particles, owned          # balanced: about one sheet each
+        nv1 = one.n_vertices
+        for s in shards:                                                        # ... made of a strip of every layer
+            layers = np.unique(s.own_v // nv1)
+            assert layers.size == world, (world, layers)
