@@ -303,6 +303,11 @@ int mpmhip_debug_counter(mpmhip_ctx *ctx, int32_t index, int64_t *out); /* devic
  * -DMPMHIP_DEBUG=1 carry the stamps (and the kernel switches of mpmhip_set_debug_flags); the production build returns
  * MPMHIP_ERR_INVALID.  tools/gpu/wgtrace.py. */
 int mpmhip_debug_wgtrace(mpmhip_ctx *ctx, int32_t kernel, uint64_t *out, int32_t max_wg);
+/* the sort of the re-sort on its own (tests/test_gpu_sort.py): stable sort of n 32-bit keys by their low `bits` bits
+ * ([dev] keys_in; bits above `bits` must be zero) -> [dev] keys_out (sorted), order_out (source index of each sorted key).
+ * Uses the path the context's re-sorts use (csrc/fast.hip k_rs_*; rocPRIM with MPMHIP_SORT=rocprim or n > 2^21).
+ * Synchronous; fast mode only. */
+int mpmhip_debug_sort(mpmhip_ctx *ctx, const uint32_t *keys_in, int32_t n, int32_t bits, uint32_t *keys_out, int32_t *order_out);
 /* counts for the algorithmic-bytes formula; synchronous, runs small count kernels */
 int mpmhip_get_stats(mpmhip_ctx *ctx, mpmhip_stats *out);
 /* MPMWARP.time_profile / print_time_profile, mpm_solver.py:16,538-541: when enabled every phase is

@@ -113,6 +113,7 @@ SIGNATURES = {
     "mpmhip_set_debug_flags": (C.c_int, [vp, C.c_int32]),
     "mpmhip_debug_counter": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_int64)]),
     "mpmhip_debug_wgtrace": (C.c_int, [vp, C.c_int32, vp, C.c_int32]),
+    "mpmhip_debug_sort": (C.c_int, [vp, vp, C.c_int32, C.c_int32, vp, vp]),
     "mpmhip_dist_halo_bytes": (C.c_int, [vp, C.POINTER(C.c_int64)]),
     "mpmhip_dist_halo_transport": (C.c_int, [vp, C.POINTER(C.c_int32)]),
     "mpmhip_dist_fused_halo_steps": (C.c_int, [vp, C.POINTER(C.c_int64)]),

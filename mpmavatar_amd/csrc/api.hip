@@ -563,6 +563,14 @@ int mpmhip_debug_wgtrace(mpmhip_ctx *c, int32_t kernel, uint64_t *out, int32_t m
   return fast_debug_wgtrace(c, kernel, out, max_wg);
 }
 
+int mpmhip_debug_sort(mpmhip_ctx *c, const uint32_t *keys_in, int32_t n, int32_t bits, uint32_t *keys_out, int32_t *order_out) {
+  CHECK_CTX(c);
+  if (!fast_mode(c) || !c->fast) return fail(c, MPMHIP_ERR_INVALID, "debug_sort: fast mode only");
+  if (n < 0 || bits < 1 || bits > 32 || (n > 0 && (!keys_in || !keys_out || !order_out)))
+    return fail(c, MPMHIP_ERR_INVALID, "debug_sort: bad arguments");
+  return fast_debug_sort(c, keys_in, n, bits, keys_out, order_out);
+}
+
 int mpmhip_get_stats(mpmhip_ctx *c, mpmhip_stats *out) {
   CHECK_CTX(c);
   if (!out) return fail(c, MPMHIP_ERR_INVALID, "get_stats: null");

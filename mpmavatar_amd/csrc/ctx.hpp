@@ -166,6 +166,7 @@ int fast_stats(mpmhip_ctx *ctx, mpmhip_stats *out);
 int fast_set_debug_flags(mpmhip_ctx *ctx, int flags);
 int fast_debug_counter(mpmhip_ctx *ctx, int index, int64_t *out);
 int fast_debug_wgtrace(mpmhip_ctx *ctx, int kernel, uint64_t *out, int max_wg);
+int fast_debug_sort(mpmhip_ctx *ctx, const uint32_t *keys_in, int n, int bits, uint32_t *keys_out, int32_t *order_out);
 int fast_add_collider_storage(mpmhip_ctx *ctx, MeshCollider &mc);
 int fast_add_mover_storage(mpmhip_ctx *ctx, Mover &mv);
 

@@ -255,6 +255,9 @@ __global__ void k_export(mpmhip_state_ptrs st, mpmhip_model_ptrs md, Bufs b, VAd
 typedef unsigned SortKey;  // class | state | block | tile cell: 2 + 2 + 18 + 8 = 30 bits at 256^3
 __device__ __forceinline__ int kf_blk(int kf) { return kf & 255; }
 __device__ __forceinline__ int kf_cell(int kf) { return kf >> 8; }
+__device__ __forceinline__ int key_block(SortKey k, int kf) { return (int)((k >> kf_cell(kf)) & ((1u << kf_blk(kf)) - 1u)); }
+__device__ __forceinline__ int key_state(SortKey k, int kf) { return (int)((k >> (kf_blk(kf) + kf_cell(kf))) & 3u); }
+__device__ __forceinline__ bool key_inactive(SortKey k, int blk_bits) { return key_state(k, blk_bits) >= 2; }
 __device__ __forceinline__ SortKey make_key(V3 x, V3 v, float lead, int cls, int state, const Dims &d, int kf) {
   int bb = kf_blk(kf), cb = kf_cell(kf);
   int cx = (int)(x.x * d.inv_dx - 0.5f), cy = (int)(x.y * d.inv_dx - 0.5f), cz = (int)(x.z * d.inv_dx - 0.5f);
@@ -278,14 +281,138 @@ __device__ __forceinline__ SortKey make_key(V3 x, V3 v, float lead, int cls, int
   return ((SortKey)cls << (bb + cb + 2)) | ((SortKey)state << (bb + cb)) | (blk << cb) | cell;
 }
 
-__global__ void k_keys(Bufs b, Dims d, int kf, float lead, int ghost_g2p, SortKey *keys, int *iota) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= d.n_p) return;
-  int cls = s < d.n_e ? 0 : (s < d.n_nv ? 1 : 2);
-  V3 x = ld3(b.all, A_X, s), v = ld3(b.all, A_V, s);
-  int sel = b.sel[s];
-  keys[s] = make_key(x, v, lead, cls, sel == 0 ? 0 : ((sel == 2 && ghost_g2p && cls != 1) ? 1 : 2), d, kf);
-  iota[s] = s;
+// ---- the sort of the re-sort: LSD radix sort of (key, index) pairs, 8 bits a pass ----------------------------------------------
+// rocPRIM sorts up to 2^20 pairs with a block sort + ~20 merge launches (115-135 us for the headline scene's 500k keys, half
+// of a re-sort) and its Onesweep is slower still at this size: its decoupled look-back is a serial chain over the tiles
+// (profiles/r02_experiments.md).  At this size every launch costs its 4-5 us of dispatch whatever it does, so a pass is TWO
+// launches and nothing in them is a chain:
+//   k_rs_hist     per-tile digit histogram [tile][digit], plus the same counts summed per GROUP of RS_GROUP tiles (integer atomics:
+//                 the order of the adds does not matter);
+//   k_rs_scatter  every workgroup works out by itself where its tile's pairs of each digit start -- pairs of smaller digits (a
+//                 block scan over the digit totals) + pairs of this digit in earlier groups + in earlier tiles of its group:
+//                 <= groups + RS_GROUP coalesced loads per thread instead of a scan launch -- and scatters.
+// A tile is RS_TILE consecutive pairs, taken RS_TPB at a time in index order; the rank of a pair inside its tile = pairs of the
+// same digit in earlier slices (run[]) + in earlier wavefronts of its slice (cnt[][]) + in lower lanes of its wavefront (ballot
+// match).  Stable: the same permutation as rocPRIM's sort, bit for bit (tests/test_gpu_sort.py; MPMHIP_SORT=rocprim selects the
+// library path).
+#ifndef MPMHIP_RS_IPT
+#define MPMHIP_RS_IPT 4
+#endif
+constexpr int RS_BITS = 8, RS_BINS = 1 << RS_BITS, RS_TPB = 256, RS_IPT = MPMHIP_RS_IPT, RS_TILE = RS_TPB * RS_IPT, RS_GROUP = 16;
+static_assert(RS_TPB == RS_BINS, "one thread per digit value");
+
+// lanes of this wavefront that hold the same 9-bit value (bit 8 = "no pair in this lane")
+__device__ __forceinline__ unsigned long long rs_peers(int dg) {
+  unsigned long long peers = ~0ull;
+#pragma unroll
+  for (int b = 0; b <= RS_BITS; ++b) {
+    bool bit = (dg >> b) & 1;
+    unsigned long long m = __ballot(bit);
+    peers &= bit ? m : ~m;
+  }
+  return peers;
+}
+
+__global__ __launch_bounds__(RS_TPB) void k_rs_hist(const unsigned *keys, int n, int shift, int *hist, int *gsum) {
+  __shared__ int h[RS_BINS];
+  const int t = threadIdx.x, lane = t & 63;
+  h[t] = 0;
+  __syncthreads();
+  const int base = (int)blockIdx.x * RS_TILE;
+  unsigned kk[RS_IPT];
+#pragma unroll
+  for (int j = 0; j < RS_IPT; ++j) {
+    int i = base + j * RS_TPB + t;
+    kk[j] = i < n ? keys[i] : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < RS_IPT; ++j) {
+    bool in = base + j * RS_TPB + t < n;
+    int dg = in ? (int)((kk[j] >> shift) & (RS_BINS - 1)) : RS_BINS;
+    unsigned long long peers = rs_peers(dg);
+    if (in && (peers & ((1ull << lane) - 1)) == 0) atomicAdd(&h[dg], __popcll(peers));
+  }
+  __syncthreads();
+  int v = h[t];
+  hist[(size_t)blockIdx.x * RS_BINS + t] = v;
+  if (v) atomicAdd(gsum + (size_t)(blockIdx.x / RS_GROUP) * RS_BINS + t, v);
+}
+
+// IOTA: the values going in are 0, 1, 2, ... (first pass).  gsum_next: the group sums the NEXT pass accumulates, cleared here.
+template <bool IOTA>
+__global__ __launch_bounds__(RS_TPB) void k_rs_scatter(const unsigned *kin, const int *vin, unsigned *kout, int *vout, int n, int shift,
+                                                       int n_tiles, const int *hist, const int *gsum, int *gsum_next, int clear_groups, int *mark, int mark_kf) {
+  __shared__ int run[RS_BINS];          // where this tile's next pair of each digit goes
+  __shared__ int cnt[2][4][RS_BINS];    // pairs of each digit in each wavefront of the current slice (double-buffered)
+  __shared__ int ws[4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int T = (int)blockIdx.x, base = T * RS_TILE, n_groups = (n_tiles + RS_GROUP - 1) / RS_GROUP, g0 = T / RS_GROUP;
+  unsigned kk[RS_IPT];
+  int vv[RS_IPT];
+#pragma unroll
+  for (int j = 0; j < RS_IPT; ++j) {
+    int i = base + j * RS_TPB + t;
+    kk[j] = i < n ? kin[i] : 0u;
+    vv[j] = IOTA ? i : (i < n ? vin[i] : 0);
+  }
+  {  // thread t = digit t: start of this tile's pairs of that digit.  Fixed-size predicated batches: all loads of a batch are in
+     // flight together (a loop with a run-time trip count issues them one latency after the other: +2 us per launch)
+    int total = 0, pre = 0;
+    for (int gb = 0; gb < n_groups; gb += 32) {
+      int x[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) x[u] = gb + u < n_groups ? gsum[(size_t)(gb + u) * RS_BINS + t] : 0;
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        total += x[u];
+        pre += gb + u < g0 ? x[u] : 0;
+      }
+    }
+    {
+      int y[RS_GROUP - 1];
+#pragma unroll
+      for (int u = 0; u < RS_GROUP - 1; ++u) y[u] = g0 * RS_GROUP + u < T ? hist[(size_t)(g0 * RS_GROUP + u) * RS_BINS + t] : 0;
+#pragma unroll
+      for (int u = 0; u < RS_GROUP - 1; ++u) pre += y[u];
+    }
+    int inc = total;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int a = __shfl_up(inc, o);
+      if (lane >= o) inc += a;
+    }
+    if (lane == 63) ws[wv] = inc;
+    __syncthreads();
+    int below = inc - total + (wv > 0 ? ws[0] : 0) + (wv > 1 ? ws[1] : 0) + (wv > 2 ? ws[2] : 0);
+    run[t] = below + pre;
+    for (int g = T; g < clear_groups; g += (int)gridDim.x) gsum_next[(size_t)g * RS_BINS + t] = 0;  // (every row: sorts of other sizes share the buffer)
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) (&cnt[0][0][0])[q * RS_TPB + t] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < RS_IPT; ++j) {
+    bool in = base + j * RS_TPB + t < n;
+    int dg = in ? (int)((kk[j] >> shift) & (RS_BINS - 1)) : RS_BINS;
+    unsigned long long peers = rs_peers(dg);
+    int rank = __popcll(peers & ((1ull << lane) - 1));
+    int(*c)[RS_BINS] = cnt[j & 1];
+    if (in && rank == 0) c[wv][dg] = __popcll(peers);
+    __syncthreads();
+    if (in) {
+      int off = run[dg] + rank;
+      if (wv > 0) off += c[0][dg];
+      if (wv > 1) off += c[1][dg];
+      if (wv > 2) off += c[2][dg];
+      kout[off] = kk[j];
+      vout[off] = vv[j];
+      // (last pass of the particle sort: flag the block of every transferred particle -- what k_mark_blocks would do next)
+      if (mark && !key_inactive(kk[j], mark_kf)) mark[key_block(kk[j], mark_kf)] = 1;
+    }
+    __syncthreads();
+    run[t] += c[0][t] + c[1][t] + c[2][t] + c[3][t];  // (read by the next slice after its first barrier)
+    c[0][t] = 0; c[1][t] = 0; c[2][t] = 0; c[3][t] = 0;  // (written again two slices on: two barriers in between)
+  }
 }
 
 __global__ void k_permute(Bufs src, Bufs dst, const int *order, const int *perm_src, int *perm_dst, int *inv, Dims d) {
@@ -308,17 +435,22 @@ __global__ void k_permute(Bufs src, Bufs dst, const int *order, const int *perm_
   }
 }
 
-// sorted slot (vertex-local) of each element's three vertices
-__global__ void k_face_slots(Bufs b, const int *inv, int *face_slot, Dims d) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= d.n_e) return;
-  for (int c = 0; c < 3; ++c) face_slot[c * d.n_e + e] = inv[d.n_nv + b.face_orig[c * d.n_e + e]] - d.n_nv;
+// cloth topology in sorted slots, one launch: thread i < n_e files the sorted (vertex-local) slots of element i's three
+// vertices, thread i < n_v the sorted (element, corner) adjacency of vertex i
+__global__ void k_topology_sorted(Bufs b, const int *inv, int *face_slot, const int *adj_o, int *adj_s, const int *perm, int K, Dims d) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d.n_e)
+    for (int c = 0; c < 3; ++c) face_slot[c * d.n_e + i] = inv[d.n_nv + b.face_orig[c * d.n_e + i]] - d.n_nv;
+  if (i < d.n_v && adj_o) {
+    int o = perm[d.n_nv + i] - d.n_nv;
+    for (int k = 0; k < K; ++k) {
+      int ent = adj_o[(size_t)k * d.n_v + o];
+      adj_s[(size_t)k * d.n_v + i] = ent < 0 ? -1 : ((inv[ent >> 2] << 2) | (ent & 3));
+    }
+  }
 }
 
 // (the parameter named blk_bits below is the packed key format kf)
-__device__ __forceinline__ int key_block(SortKey k, int kf) { return (int)((k >> kf_cell(kf)) & ((1u << kf_blk(kf)) - 1u)); }
-__device__ __forceinline__ int key_state(SortKey k, int kf) { return (int)((k >> (kf_blk(kf) + kf_cell(kf))) & 3u); }
-__device__ __forceinline__ bool key_inactive(SortKey k, int blk_bits) { return key_state(k, blk_bits) >= 2; }
 
 __global__ void k_mark_blocks(const SortKey *keys, int n, int blk_bits, int *pb_flag) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -331,14 +463,83 @@ __global__ void k_mark_blocks(const SortKey *keys, int n, int blk_bits, int *pb_
 // (the host reads them once, at the end): [0] particle blocks, [1] active blocks, [2] chunks, [3] chunks incl. ghost copies,
 // [4] any ghost copy, [5] capacity overflow bits (1 plist / ranges, 2 alist, 4 chunk records, 8 face bins), [6] face bins
 enum { RC_NP = 0, RC_NA = 1, RC_NCH = 2, RC_NCHG = 3, RC_GHOST = 4, RC_OVER = 5, RC_NFB = 6, RC_N = 8 };
-__global__ void k_flag_total(const int *flag, const int *index, int n, int *rc, int slot, int cap, int over_bit) {
-  int tot = index[n - 1] + flag[n - 1];
-  rc[slot] = tot;
-  if (tot > cap) atomicOr(rc + RC_OVER, over_bit);
-}
-__global__ void k_compact(const int *flag, const int *index, int n, int *list, int cap) {
+// compaction of the flagged blocks onto a list; thread 0 also files the total (rc[slot], overflow bit) and every thread
+// clears its share of `clear` (the ranges table k_ranges fills next) -- both used to be launches of their own
+__global__ void k_compact(const int *flag, const int *index, int n, int *list, int cap, int *rc, int slot, int over_bit, int *clear,
+                          int n_clear) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = b; i < n_clear; i += (int)(gridDim.x * blockDim.x)) clear[i] = 0;
+  if (b == 0 && rc) {
+    int tot = index[n - 1] + flag[n - 1];
+    rc[slot] = tot;
+    if (tot > cap) atomicOr(rc + RC_OVER, over_bit);
+  }
   if (b < n && flag[b] && index[b] < cap) list[index[b]] = b;
+}
+
+// The same compaction without a scan launch in front (the re-sort's two block lists; rocPRIM's scan is two launches): k_flag_count
+// files the flagged blocks per tile of FC_TILE flags and per group of FC_GROUP tiles, k_compact_tiles works out every tile's start
+// from those (uniform loads: <= groups + FC_GROUP scalars) and scans inside the tile.  index[] is filled as the exclusive scan
+// would have filled it.
+constexpr int FC_TILE = 1024, FC_GROUP = 16;
+__global__ __launch_bounds__(256) void k_flag_count(const int *flag, int n, int *tcount, int *gsum) {
+  __shared__ int ws[4];
+  const int t = threadIdx.x, b0 = (int)blockIdx.x * FC_TILE + t * 4;
+  int c = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) c += (b0 + u < n && flag[b0 + u]) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((t & 63) == 0) ws[t >> 6] = c;
+  __syncthreads();
+  if (t == 0) {
+    int tot = ws[0] + ws[1] + ws[2] + ws[3];
+    tcount[blockIdx.x] = tot;
+    if (tot) atomicAdd(gsum + blockIdx.x / FC_GROUP, tot);
+  }
+}
+__global__ __launch_bounds__(256) void k_compact_tiles(const int *flag, int n, const int *tcount, const int *gsum, int n_tiles, int *index,
+                                                       int *list, int cap, int *rc, int slot, int over_bit, int *clear, int n_clear) {
+  __shared__ int ws[4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, T = (int)blockIdx.x, g0 = T / FC_GROUP;
+  const int n_groups = (n_tiles + FC_GROUP - 1) / FC_GROUP;
+  for (int i = T * 256 + t; i < n_clear; i += (int)gridDim.x * 256) clear[i] = 0;
+  int total = 0, pre = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    int x = gsum[g];
+    total += x;
+    pre += g < g0 ? x : 0;
+  }
+  for (int q = g0 * FC_GROUP; q < T; ++q) pre += tcount[q];
+  if (T == 0 && t == 0) {
+    rc[slot] = total;
+    if (total > cap) atomicOr(rc + RC_OVER, over_bit);
+  }
+  const int b0 = T * FC_TILE + t * 4;
+  int fl[4], c = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    fl[u] = (b0 + u < n && flag[b0 + u]) ? 1 : 0;
+    c += fl[u];
+  }
+  int inc = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int a = __shfl_up(inc, o);
+    if (lane >= o) inc += a;
+  }
+  if (lane == 63) ws[wv] = inc;
+  __syncthreads();
+  int idx = pre + inc - c + (wv > 0 ? ws[0] : 0) + (wv > 1 ? ws[1] : 0) + (wv > 2 ? ws[2] : 0);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (b0 + u >= n) break;
+    index[b0 + u] = idx;
+    if (fl[u]) {
+      if (idx < cap) list[idx] = b0 + u;
+      idx += 1;
+    }
+  }
 }
 
 // ranges[(cls*2+0)*n_P + slot] = first sorted index, [(cls*2+1)*n_P + slot] = one past the last
@@ -557,6 +758,48 @@ __device__ __forceinline__ void zero_blocks_wg(const ZeroArgs &z, int wg) {
 }
 __global__ __launch_bounds__(TPB) void k_zero_blocks(ZeroArgs z) { zero_blocks_wg(z, blockIdx.x); }
 
+// Sort keys of all particles.  Tile-shaped like the sort's kernels (a workgroup = RS_TILE particles) because it also does the
+// sort's first launch -- the digit histogram of the lowest RS_BITS bits (hist != nullptr) -- on the keys it has in registers,
+// and clears the block flags and counts the table build starts from: two launches less per re-sort (a launch costs 4-5 us here
+// whatever it does).
+__global__ __launch_bounds__(RS_TPB) void k_keys(Bufs b, Dims d, int kf, float lead, int ghost_g2p, SortKey *keys, int *iota, int *clear,
+                                                 int n_clear, int *hist, int *gsum, int n_tiles, ZeroArgs z) {
+  __shared__ int h[RS_BINS];
+  if ((int)blockIdx.x >= n_tiles) {  // behind the key workgroups: the grid accumulators of the OLD active list are cleared
+    zero_blocks_wg(z, (int)blockIdx.x - n_tiles);  // (independent of everything else in a re-sort until the new list exists)
+    return;
+  }
+  const int t = threadIdx.x, lane = t & 63, base = (int)blockIdx.x * RS_TILE;
+  for (int i = (int)blockIdx.x * RS_TPB + t; i < n_clear; i += n_tiles * RS_TPB) clear[i] = 0;
+  h[t] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < RS_IPT; ++j) {
+    int s = base + j * RS_TPB + t;
+    bool in = s < d.n_p;
+    SortKey k = 0;
+    if (in) {
+      int cls = s < d.n_e ? 0 : (s < d.n_nv ? 1 : 2);
+      V3 x = ld3(b.all, A_X, s), v = ld3(b.all, A_V, s);
+      int sel = b.sel[s];
+      k = make_key(x, v, lead, cls, sel == 0 ? 0 : ((sel == 2 && ghost_g2p && cls != 1) ? 1 : 2), d, kf);
+      keys[s] = k;
+      iota[s] = s;
+    }
+    if (hist) {
+      int dg = in ? (int)(k & (RS_BINS - 1)) : RS_BINS;
+      unsigned long long peers = rs_peers(dg);
+      if (in && (peers & ((1ull << lane) - 1)) == 0) atomicAdd(&h[dg], __popcll(peers));
+    }
+  }
+  if (!hist) return;
+  __syncthreads();
+  int v = h[t];
+  hist[(size_t)blockIdx.x * RS_BINS + t] = v;
+  if (v) atomicAdd(gsum + (size_t)(blockIdx.x / RS_GROUP) * RS_BINS + t, v);
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // stress (compute_stress_from_F_trial, mpm_utils.py:1017-1105) on the sorted SoA state
 // ------------------------------------------------------------------------------------------------
@@ -661,57 +904,67 @@ struct ChunkRec {
 // Chunk records of all particle blocks, built on the device (one workgroup: a few thousand blocks at most): block p
 // contributes ceil(particles / CHUNK) records to the p2g list and ceil((particles + ghost copies) / CHUNK) to the g2p list,
 // in block order (neighbouring records = neighbouring tiles, what the XCD mapping wants).
+// Thread t takes blocks t, t + 1024, ... (coalesced table reads), BC_R rounds at a time with all their loads in flight together:
+// as one workgroup the kernel is a chain of memory latencies, and with one block after the other per thread it took 19-25 us.
+constexpr int BC_R = 4;
 __global__ __launch_bounds__(1024) void k_build_chunks(const int *plist, const int *ranges, int stride, int *rc, ChunkRec *recs,
-                                                       ChunkRec *recs_g, int cap) {
-  __shared__ int sc[1024], sg[1024];
+                                                       ChunkRec *recs_g, int cap, int *counters) {
+  __shared__ int sc[16], sg[16];
   __shared__ int any_ghost;
   const int t = threadIdx.x, n_P = min(rc[RC_NP], stride);
-  const int per = (n_P + 1023) / 1024, p0 = min(t * per, n_P), p1 = min(p0 + per, n_P);
-  auto R = [&](int k, int p) { return ranges[(size_t)k * stride + p]; };
-  int c = 0, cg = 0, gh = 0;
-  for (int p = p0; p < p1; ++p) {
-    int tot = (R(1, p) - R(0, p)) + (R(3, p) - R(2, p)) + (R(5, p) - R(4, p));
-    int g = (R(7, p) - R(6, p)) + (R(9, p) - R(8, p));
-    c += (tot + CHUNK - 1) / CHUNK;
-    cg += (tot + g + CHUNK - 1) / CHUNK;
-    gh |= g > 0;
-  }
-  if (t == 0) any_ghost = 0;
-  // inclusive scan over the 1024 threads: inside each wavefront with shuffles, then over the 16 wavefront totals
-  // (three barriers instead of the twenty of a Hillis-Steele scan through LDS)
-  int ic = c, ig = cg;
   const int lane = t & 63, wv = t >> 6;
+  if (t == 0) any_ghost = 0;
+  int base_c = 0, base_g = 0, gh = 0;  // records in front of the current round
+  for (int p0 = 0; p0 < n_P; p0 += BC_R * 1024) {
+    int R[BC_R][10], blk[BC_R];
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int a = __shfl_up(ic, o), b = __shfl_up(ig, o);
-    if (lane >= o) { ic += a; ig += b; }
-  }
-  if (lane == 63) { sc[wv] = ic; sg[wv] = ig; }
-  __syncthreads();
-  if (gh) any_ghost = 1;
-  if (t < 16) {
-    int a = sc[t], b = sg[t];
+    for (int r = 0; r < BC_R; ++r) {
+      int p = p0 + r * 1024 + t;
+      bool in = p < n_P;
+      blk[r] = in ? plist[p] : 0;
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      int ua = __shfl_up(a, o), ub = __shfl_up(b, o);
-      if (t >= o) { a += ua; b += ub; }
+      for (int k = 0; k < 10; ++k) R[r][k] = in ? ranges[(size_t)k * stride + p] : 0;
     }
-    sc[32 + t] = a; sg[32 + t] = b;  // inclusive totals of wavefronts 0..t
+#pragma unroll
+    for (int r = 0; r < BC_R; ++r) {
+      if (p0 + r * 1024 >= n_P) break;  // (uniform)
+      ChunkRec q{blk[r], 0, R[r][0], R[r][1] - R[r][0], R[r][2], R[r][3] - R[r][2], R[r][4], R[r][5] - R[r][4], 0, 0, 0, 0};
+      int tot = q.ne + q.nt + q.nv, g = (R[r][7] - R[r][6]) + (R[r][9] - R[r][8]);
+      int c = (tot + CHUNK - 1) / CHUNK, cg = (tot + g + CHUNK - 1) / CHUNK;
+      gh |= g > 0;
+      // inclusive scan over the 1024 threads: inside each wavefront with shuffles, then over the 16 wavefront totals
+      int ic = c, ig = cg;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        int a = __shfl_up(ic, o), b = __shfl_up(ig, o);
+        if (lane >= o) { ic += a; ig += b; }
+      }
+      __syncthreads();
+      if (lane == 63) { sc[wv] = ic; sg[wv] = ig; }
+      __syncthreads();
+      int tc = 0, tg = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        int a = sc[w], b = sg[w];
+        if (w < wv) { ic += a; ig += b; }
+        tc += a; tg += b;
+      }
+      int o = base_c + ic - c, og = base_g + ig - cg;
+      for (int k = 0; k * CHUNK < tot; ++k, ++o) { q.chunk = k; if (o < cap) recs[o] = q; }
+      q.ge0 = R[r][6]; q.gne = R[r][7] - R[r][6]; q.gv0 = R[r][8]; q.gnv = R[r][9] - R[r][8];
+      tot += q.gne + q.gnv;
+      for (int k = 0; k * CHUNK < tot; ++k, ++og) { q.chunk = k; if (og < cap) recs_g[og] = q; }
+      base_c += tc; base_g += tg;
+    }
   }
+  if (gh) any_ghost = 1;
   __syncthreads();
-  if (wv > 0) { ic += sc[32 + wv - 1]; ig += sg[32 + wv - 1]; }
-  int o = ic - c, og = ig - cg;
-  for (int p = p0; p < p1; ++p) {
-    ChunkRec r{plist[p], 0, R(0, p), R(1, p) - R(0, p), R(2, p), R(3, p) - R(2, p), R(4, p), R(5, p) - R(4, p), 0, 0, 0, 0};
-    int tot = r.ne + r.nt + r.nv;
-    for (int k = 0; k * CHUNK < tot; ++k, ++o) { r.chunk = k; if (o < cap) recs[o] = r; }
-    r.ge0 = R(6, p); r.gne = R(7, p) - R(6, p); r.gv0 = R(8, p); r.gnv = R(9, p) - R(8, p);
-    tot += r.gne + r.gnv;
-    for (int k = 0; k * CHUNK < tot; ++k, ++og) { r.chunk = k; if (og < cap) recs_g[og] = r; }
-  }
-  if (t == 1023) {
-    rc[RC_NCH] = ic; rc[RC_NCHG] = ig; rc[RC_GHOST] = any_ghost;
-    if (ic > cap || ig > cap) atomicOr(rc + RC_OVER, 4);
+  if (t == 0) {
+    rc[RC_NCH] = base_c; rc[RC_NCHG] = base_g; rc[RC_GHOST] = any_ghost;
+    if (base_c > cap || base_g > cap) atomicOr(rc + RC_OVER, 4);
+    // the new order starts with no drift warning pending (two memsets after the host's wait before: 2 x 8 us of idle queue)
+    counters[CNT_DRIFT] = 0;
+    counters[CNT_PAR0] = 0; counters[CNT_PAR0 + 1] = 0; counters[CNT_PAR0 + 2] = 0; counters[CNT_PAR0 + 3] = 0;
   }
 }
 
@@ -2217,17 +2470,6 @@ __global__ void k_max_int(const int *a, int n, int *out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) atomicMax(out, a[i]);
 }
-// ELL adjacency in sorted slots: vertex slot vs <- original vertex perm[n_nv+vs]-n_nv, element ids through inv[]
-__global__ void k_adj_sorted(const int *adj_o, int *adj_s, const int *perm, const int *inv, int K, Dims d) {
-  int vs = blockIdx.x * blockDim.x + threadIdx.x;
-  if (vs >= d.n_v) return;
-  int o = perm[d.n_nv + vs] - d.n_nv;
-  for (int k = 0; k < K; ++k) {
-    int ent = adj_o[(size_t)k * d.n_v + o];
-    adj_s[(size_t)k * d.n_v + vs] = ent < 0 ? -1 : ((inv[ent >> 2] << 2) | (ent & 3));
-  }
-}
-
 __global__ void k_iota(int *p, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
@@ -2365,8 +2607,16 @@ struct FastState {
   int *order = nullptr, *iota = nullptr;
   void *sort_tmp = nullptr, *scan_tmp = nullptr;
   size_t sort_tmp_bytes = 0, scan_tmp_bytes = 0;
+  int *rs_hist = nullptr;      // [tiles][RS_BINS] digit counts of the radix sort (see k_rs_hist)
+  int rs_tiles = 0;
+  int *rs_gsum = nullptr;      // [2][groups][RS_BINS] the same counts per group of tiles: the pass in flight / the next one
+  int rs_groups = 0;
+  unsigned rs_seq = 0;
+  bool sort_rocprim = false;   // MPMHIP_SORT=rocprim: the library's sort instead (same permutation)
   GridPtrs g{};
   int *pb_flag = nullptr, *pb_index = nullptr, *ab_flag = nullptr, *ab_index = nullptr;
+  int *fc_gsum = nullptr, *fc_tcount = nullptr;  // [2][fc_groups], [2][fc_tiles]: flagged blocks per group / tile (k_flag_count)
+  int fc_tiles = 0, fc_groups = 0, n_clear = 0;  // n_clear: ints from pb_flag on that a re-sort starts from zeroed
   int *plist = nullptr, *alist = nullptr, *ranges = nullptr;
   ChunkRec *chunks = nullptr, *chunks_g = nullptr;  // p2g list, g2p list (= p2g list unless there are ghost copies)
   int n_chunks_g = 0;
@@ -2584,35 +2834,93 @@ static void materialize_grid(mpmhip_ctx *c, bool count) {
   hipLaunchKernelGGL(k_grid<false>, xcd_grid((f->n_A + 3) / 4), TPB, 0, c->stream, f->alist, f->n_A, f->d, f->g, gp, f->last_bcl);
 }
 
+// Stable sort of n (key, index) pairs by the low `bits` bits of the keys: sorted keys in keys[1], the indices in order[] (= the
+// source position of each sorted key); vtmp is scratch (n ints).  The caller writes the unsorted keys into
+// keys[sort_input(...)]: the radix passes ping-pong between the two key buffers and must end in keys[1].
+constexpr int RS_MAX_N = 1 << 21;  // above: the library (its Onesweep is made for large inputs)
+static bool sort_custom(const FastState *f, int n) { return !f->sort_rocprim && n <= RS_MAX_N; }
+static int sort_passes(int bits) { return (bits + RS_BITS - 1) / RS_BITS; }
+static int sort_input(const FastState *f, int n, int bits) { return sort_custom(f, n) ? 1 - (sort_passes(bits) & 1) : 0; }
+// room for the histograms of a sort of n pairs
+static int sort_reserve(mpmhip_ctx *c, int n) {
+  FastState *f = c->fast;
+  const int tiles = (n + RS_TILE - 1) / RS_TILE, groups = (tiles + RS_GROUP - 1) / RS_GROUP;
+  if (tiles > f->rs_tiles) {
+    int rc;
+    if ((rc = dalloc(c, &f->rs_hist, (size_t)RS_BINS * tiles, false))) return rc;
+    if ((rc = dalloc(c, &f->rs_gsum, (size_t)2 * RS_BINS * groups))) return rc;  // zeroed here; from then on by k_rs_scatter
+    f->rs_tiles = tiles;
+    f->rs_groups = groups;
+  }
+  return MPMHIP_OK;
+}
+// the group sums the next pass adds into (the two sets alternate with every pass of every sort: a pass clears the set the one
+// after it uses)
+static int *sort_gsum(FastState *f, int next) { return f->rs_gsum + (size_t)((f->rs_seq + next) & 1) * RS_BINS * f->rs_groups; }
+// hist0_done: the caller's key kernel has already filed the first pass's histogram (k_keys: into f->rs_hist / sort_gsum(f, 0))
+static int sort_pairs(mpmhip_ctx *c, unsigned *const keys[2], int *vtmp, int *order, int n, int bits, bool hist0_done = false,
+                      int *mark = nullptr, int mark_kf = 0) {
+  FastState *f = c->fast;
+  hipStream_t s = c->stream;
+  if (n <= 0) return MPMHIP_OK;
+  if (!sort_custom(f, n)) {  // vtmp holds 0, 1, 2, ... (written with the keys)
+    size_t need = 0;
+    MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(nullptr, need, keys[0], keys[1], vtmp, order, (size_t)n, 0u, (unsigned)bits, s));
+    if (need > f->sort_tmp_bytes) {
+      MPM_HIP_CHECK(c, hipMalloc(&f->sort_tmp, need));
+      f->allocs.push_back(f->sort_tmp);
+      f->sort_tmp_bytes = need;
+    }
+    MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(f->sort_tmp, need, keys[0], keys[1], vtmp, order, (size_t)n, 0u, (unsigned)bits, s));
+    return MPMHIP_OK;
+  }
+  int rc;
+  if ((rc = sort_reserve(c, n))) return rc;
+  const int tiles = (n + RS_TILE - 1) / RS_TILE, P = sort_passes(bits), s0 = 1 - (P & 1);
+  int *vb[2] = {vtmp, order};
+  for (int p = 0; p < P; ++p) {
+    const unsigned *kin = keys[(s0 + p) & 1];
+    unsigned *kout = keys[(s0 + p + 1) & 1];
+    const int *vin = vb[(s0 + p) & 1];
+    int *vout = vb[(s0 + p + 1) & 1];
+    int *gs = sort_gsum(f, 0), *gs_next = sort_gsum(f, 1);
+    f->rs_seq += 1;
+    if (p > 0 || !hist0_done) hipLaunchKernelGGL(k_rs_hist, (unsigned)tiles, RS_TPB, 0, s, kin, n, p * RS_BITS, f->rs_hist, gs);
+    int *mk = p == P - 1 ? mark : nullptr;
+    if (p == 0) hipLaunchKernelGGL(k_rs_scatter<true>, (unsigned)tiles, RS_TPB, 0, s, kin, vin, kout, vout, n, p * RS_BITS, tiles, f->rs_hist, gs, gs_next, f->rs_groups, mk, mark_kf);
+    else hipLaunchKernelGGL(k_rs_scatter<false>, (unsigned)tiles, RS_TPB, 0, s, kin, vin, kout, vout, n, p * RS_BITS, tiles, f->rs_hist, gs, gs_next, f->rs_groups, mk, mark_kf);
+  }
+  return MPMHIP_OK;
+}
+
 int rebin(mpmhip_ctx *c) {
   FastState *f = c->fast;
   const Dims &d = f->d;
   hipStream_t s = c->stream;
   int cur = f->cur, alt = 1 - cur;
-  flush_grid(c);
-  if (d.n_p == 0) { f->n_P = f->n_A = f->n_chunks = f->n_chunks_g = 0; f->steps_since_rebin = 0; return MPMHIP_OK; }
+  int rc;
+  if (d.n_p == 0) { flush_grid(c); f->n_P = f->n_A = f->n_chunks = f->n_chunks_g = 0; f->steps_since_rebin = 0; return MPMHIP_OK; }
   flush_elements(c);
-  hipLaunchKernelGGL(k_keys, nblk(d.n_p), TPB, 0, s, f->buf[cur], d, f->blk_bits, f->lead_steps * f->last_dt,
-                     f->ghost_g2p ? 1 : 0, f->keys[0], f->iota);
-  size_t need = 0;
-  MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(nullptr, need, f->keys[0], f->keys[1], f->iota, f->order, (size_t)d.n_p, 0u,
-                                             (unsigned)f->key_bits, s));
-  if (need > f->sort_tmp_bytes) {
-    MPM_HIP_CHECK(c, hipMalloc(&f->sort_tmp, need));
-    f->allocs.push_back(f->sort_tmp);
-    f->sort_tmp_bytes = need;
-  }
-  MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(f->sort_tmp, need, f->keys[0], f->keys[1], f->iota, f->order, (size_t)d.n_p,
-                                             0u, (unsigned)f->key_bits, s));
+  // k_keys: the keys (written where the sort wants its input, so that the sorted keys end up in keys[1] and the order in f->order),
+  // the sort's first histogram, the zeroing of the block flags / counts, and -- as extra workgroups -- the clearing of the grid
+  // accumulators of the old active list (flush_grid)
+  const bool fused_hist = sort_custom(f, d.n_p);
+  if (fused_hist && (rc = sort_reserve(c, d.n_p))) return rc;
+  const ZeroArgs z = take_zero(f);
+  const int key_tiles = (d.n_p + RS_TILE - 1) / RS_TILE;
+  hipLaunchKernelGGL(k_keys, (unsigned)(key_tiles + z.n_wg), RS_TPB, 0, s, f->buf[cur], d, f->blk_bits, f->lead_steps * f->last_dt,
+                     f->ghost_g2p ? 1 : 0, f->keys[sort_input(f, d.n_p, f->key_bits)], f->iota, f->pb_flag, f->n_clear,
+                     fused_hist ? f->rs_hist : nullptr, fused_hist ? sort_gsum(f, 0) : nullptr, key_tiles, z);
+  // (custom sort: its last pass also flags the particle blocks, k_mark_blocks below)
+  if ((rc = sort_pairs(c, f->keys, f->iota, f->order, d.n_p, f->key_bits, fused_hist, f->pb_flag, f->blk_bits))) return rc;
   hipLaunchKernelGGL(k_permute, nblk(d.n_p), TPB, 0, s, f->buf[cur], f->buf[alt], f->order, f->perm[cur], f->perm[alt],
                      f->inv, d);
   f->cur = cur = alt;
-  if (d.n_e) hipLaunchKernelGGL(k_face_slots, nblk(d.n_e), TPB, 0, s, f->buf[cur], f->inv, f->face_slot, d);
-  if (d.n_e && d.n_v)
-    hipLaunchKernelGGL(k_adj_sorted, nblk(d.n_v), TPB, 0, s, f->adj_o, f->adj_s, f->perm[cur], f->inv, f->adj_K, d);
+  if (d.n_e)
+    hipLaunchKernelGGL(k_topology_sorted, nblk(std::max(d.n_e, d.n_v)), TPB, 0, s, f->buf[cur], f->inv, f->face_slot,
+                       d.n_v ? f->adj_o : nullptr, f->adj_s, f->perm[cur], f->adj_K, d);
   const SortKey *skeys = f->keys[1];
   int nb = (int)f->nblocks;
-  int rc;
   const bool with_faces = !c->colliders.empty() && c->num_mesh_f;
   const int nf = c->num_mesh_f;
   // The face bins survive a particle re-sort (they do not depend on the particle tables; only their compaction onto the
@@ -2623,17 +2931,9 @@ int rebin(mpmhip_ctx *c) {
       !getenv("MPMHIP_FACE_SORT_ALWAYS"))
     face_sort = false;
   if (face_sort) {  // body faces: sort by block, per-block ranges (independent of the particle tables)
-    hipLaunchKernelGGL(k_face_keys, nblk(nf), TPB, 0, s, c->cur_pts, c->cur_vel, c->cur_f, c->mesh_idx, nf, d, f->fkeys[0], f->fiota);
-    size_t need2 = 0;
-    MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(nullptr, need2, f->fkeys[0], f->fkeys[1], f->fiota, f->forder, (size_t)nf, 0u,
-                                               (unsigned)f->blk_bits_plain + 6u, s));
-    if (need2 > f->sort_tmp_bytes) {
-      MPM_HIP_CHECK(c, hipMalloc(&f->sort_tmp, need2));
-      f->allocs.push_back(f->sort_tmp);
-      f->sort_tmp_bytes = need2;
-    }
-    MPM_HIP_CHECK(c, rocprim::radix_sort_pairs(f->sort_tmp, need2, f->fkeys[0], f->fkeys[1], f->fiota, f->forder, (size_t)nf,
-                                               0u, (unsigned)f->blk_bits_plain + 6u, s));
+    hipLaunchKernelGGL(k_face_keys, nblk(nf), TPB, 0, s, c->cur_pts, c->cur_vel, c->cur_f, c->mesh_idx, nf, d,
+                       f->fkeys[sort_input(f, nf, f->blk_bits_plain + 6)], f->fiota);
+    if ((rc = sort_pairs(c, f->fkeys, f->fiota, f->forder, nf, f->blk_bits_plain + 6))) return rc;
     MPM_HIP_CHECK(c, hipMemsetAsync(f->fb_cnt, 0, f->nblocks * sizeof(int), s));
     hipLaunchKernelGGL(k_face_bins, nblk(nf), TPB, 0, s, f->fkeys[1], nf, f->fb_start, f->fb_cnt);
     hipLaunchKernelGGL(k_face_sorted_idx, nblk(nf), TPB, 0, s, c->mesh_idx, f->forder, nf, f->fidx);
@@ -2667,18 +2967,19 @@ int rebin(mpmhip_ctx *c) {
       f->cap_fbins = cap_fb + 64;
     }
     (void)dummy;
-    MPM_HIP_CHECK(c, hipMemsetAsync(f->pb_flag, 0, (2 * f->nblocks + 64) * sizeof(int), s));  // pb_flag, ab_flag, rcnt
-    hipLaunchKernelGGL(k_mark_blocks, nblk(d.n_p), TPB, 0, s, skeys, d.n_p, f->blk_bits, f->pb_flag);
-    if ((rc = scan_flags_dev(c, f->pb_flag, f->pb_index, nb))) return rc;
-    hipLaunchKernelGGL(k_flag_total, 1, 1, 0, s, f->pb_flag, f->pb_index, nb, f->rcnt, (int)RC_NP, cap_P, 1);
-    MPM_HIP_CHECK(c, hipMemsetAsync(f->ranges, 0, (size_t)cap_P * 10 * sizeof(int), s));
-    hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, f->pb_flag, f->pb_index, nb, f->plist, cap_P);
+    if (attempt > 0)  // (the first time k_keys has cleared them)
+      MPM_HIP_CHECK(c, hipMemsetAsync(f->pb_flag, 0, (size_t)f->n_clear * sizeof(int), s));  // pb_flag, ab_flag, rcnt, fc_gsum
+    if (attempt > 0 || !fused_hist) hipLaunchKernelGGL(k_mark_blocks, nblk(d.n_p), TPB, 0, s, skeys, d.n_p, f->blk_bits, f->pb_flag);
+    const int ft = f->fc_tiles, fg = f->fc_groups;
+    hipLaunchKernelGGL(k_flag_count, (unsigned)ft, 256, 0, s, f->pb_flag, nb, f->fc_tcount, f->fc_gsum);
+    hipLaunchKernelGGL(k_compact_tiles, (unsigned)ft, 256, 0, s, f->pb_flag, nb, f->fc_tcount, f->fc_gsum, ft, f->pb_index, f->plist, cap_P,
+                       f->rcnt, (int)RC_NP, 1, f->ranges, cap_P * 10);
     hipLaunchKernelGGL(k_ranges, nblk(d.n_p), TPB, 0, s, skeys, d, f->blk_bits, f->pb_index, cap_P, f->ranges);
     hipLaunchKernelGGL(k_dilate, nblk((size_t)cap_P * 27), TPB, 0, s, f->plist, f->rcnt, cap_P, d.NB, f->ab_flag);
-    if ((rc = scan_flags_dev(c, f->ab_flag, f->ab_index, nb))) return rc;
-    hipLaunchKernelGGL(k_flag_total, 1, 1, 0, s, f->ab_flag, f->ab_index, nb, f->rcnt, (int)RC_NA, cap_A, 2);
-    hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, f->ab_flag, f->ab_index, nb, f->alist, cap_A);
-    hipLaunchKernelGGL(k_build_chunks, 1, 1024, 0, s, f->plist, f->ranges, cap_P, f->rcnt, f->chunks, f->chunks + cap_ch, cap_ch);
+    hipLaunchKernelGGL(k_flag_count, (unsigned)ft, 256, 0, s, f->ab_flag, nb, f->fc_tcount + ft, f->fc_gsum + fg);
+    hipLaunchKernelGGL(k_compact_tiles, (unsigned)ft, 256, 0, s, f->ab_flag, nb, f->fc_tcount + ft, f->fc_gsum + fg, ft, f->ab_index, f->alist,
+                       cap_A, f->rcnt, (int)RC_NA, 2, (int *)nullptr, 0);
+    hipLaunchKernelGGL(k_build_chunks, 1, 1024, 0, s, f->plist, f->ranges, cap_P, f->rcnt, f->chunks, f->chunks + cap_ch, cap_ch, f->g.counters);
     if (with_faces)
       hipLaunchKernelGGL(k_fbin_compact, nblk(cap_A), TPB, 0, s, f->alist, f->rcnt, cap_A, f->fb_start, f->fb_cnt, f->fbins, cap_fb);
     MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 32, f->rcnt, RC_N * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -2712,8 +3013,7 @@ int rebin(mpmhip_ctx *c) {
     fprintf(stderr, "[mpmhip] re-sort %ld: %d particle blocks, %d active blocks, %zu chunks (<=32: %d, <=64: %d, <=128: %d, <256: %d, full: %d), lead %.1f\n",
             (long)f->rebins, f->n_P, f->n_A, hc.size(), hist[0], hist[1], hist[2], hist[3], hist[4], f->lead_steps);
   }
-  MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + CNT_DRIFT, 0, sizeof(int), s));
-  MPM_HIP_CHECK(c, hipMemsetAsync(f->g.counters + CNT_PAR0, 0, 4 * sizeof(int), s));  // (ring entries up to sig_at_rebin are ignored anyway)
+  // (k_build_chunks has cleared the drift flag and the parity slots; ring entries up to sig_at_rebin are ignored anyway)
   f->h_pin[24] = 0;
   f->flag_pending = false;
   f->sig_at_rebin = f->sig_seq;  // ring entries of earlier substeps speak about the old order
@@ -2739,6 +3039,7 @@ int fast_init(mpmhip_ctx *c) {
   while ((1ull << f->blk_bits_plain) < f->nblocks) ++f->blk_bits_plain;
   int cell_bits = f->blk_bits_plain + 8 + 2 + 2 <= 32 ? 8 : 6;  // 8: predictive sort (see make_key)
   if (const char *e = getenv("MPMHIP_PREDICTIVE_SORT")) if (atoi(e) == 0) cell_bits = 6;
+  if (const char *e = getenv("MPMHIP_SORT")) f->sort_rocprim = std::string(e) == "rocprim";
   f->key_bits = f->blk_bits_plain + cell_bits + 2 + 2;
   if (f->key_bits > 32) return fail(c, MPMHIP_ERR_INVALID, "grid too large for 32-bit sort keys");
   f->blk_bits = f->blk_bits_plain | (cell_bits << 8);
@@ -2768,9 +3069,14 @@ int fast_init(mpmhip_ctx *c) {
   if ((rc = dalloc(c, &f->pack_done, (size_t)DONE_SHARDS * DONE_STRIDE))) return rc;
   // one allocation, one memset per re-sort: [particle-block flags | active-block flags | device counts]
   static_assert(RC_N <= 64, "device counts of a re-sort");
-  if ((rc = dalloc(c, &f->pb_flag, 2 * f->nblocks + 64))) return rc;
+  f->fc_tiles = (int)((f->nblocks + FC_TILE - 1) / FC_TILE);
+  f->fc_groups = (f->fc_tiles + FC_GROUP - 1) / FC_GROUP;
+  f->n_clear = (int)(2 * f->nblocks + 64 + 2 * f->fc_groups);
+  if ((rc = dalloc(c, &f->pb_flag, (size_t)f->n_clear + 2 * f->fc_tiles))) return rc;
   f->ab_flag = f->pb_flag + f->nblocks;
   f->rcnt = f->pb_flag + 2 * f->nblocks;
+  f->fc_gsum = f->rcnt + 64;
+  f->fc_tcount = f->fc_gsum + 2 * f->fc_groups;
   if ((rc = dalloc(c, &f->pb_index, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->ab_index, f->nblocks))) return rc;
   f->g.ab_flag = f->ab_flag;
@@ -3503,7 +3809,7 @@ static int rccl_rebin(mpmhip_ctx *c) {
       if ((rc = dalloc(c, &p.halo_recv, (size_t)cap * 8 * 64, false))) return rc;
       p.cap_blocks = cap;
     }
-    if (p.n_blocks) hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, p.flag, p.index, nb, p.blocks, p.cap_blocks);
+    if (p.n_blocks) hipLaunchKernelGGL(k_compact, nblk(nb), TPB, 0, s, p.flag, p.index, nb, p.blocks, p.cap_blocks, (int *)nullptr, 0, 0, (int *)nullptr, 0);
     DistPeer q;
     q.n_blocks = p.n_blocks; q.blocks = p.blocks; q.halo_send = p.halo_send; q.halo_recv = p.halo_recv;
     q.n_send_p = p.n_send_p; q.n_recv_p = p.n_recv_p; q.n_send_e = p.n_send_e; q.n_recv_e = p.n_recv_e;
@@ -3682,6 +3988,28 @@ int fast_set_debug_flags(mpmhip_ctx *c, int flags) {
                                        "-DMPMHIP_DEBUG=1, tools/build_variants.py, and select it with MPMHIP_LIB)");
   c->fast->g.dbg = flags;
   return MPMHIP_OK;
+}
+int fast_debug_sort(mpmhip_ctx *c, const uint32_t *keys_in, int n, int bits, uint32_t *keys_out, int32_t *order_out) {
+  FastState *f = c->fast;
+  if (n == 0) return MPMHIP_OK;
+  unsigned *kb[2] = {nullptr, nullptr};
+  int *vtmp = nullptr;
+  auto done = [&](int rc) {
+    for (void *p : {(void *)kb[0], (void *)kb[1], (void *)vtmp}) if (p) (void)hipFree(p);
+    return rc;
+  };
+  MPM_HIP_CHECK(c, hipMalloc(&kb[0], (size_t)n * sizeof(unsigned)));
+  if (hipMalloc(&kb[1], (size_t)n * sizeof(unsigned)) != hipSuccess || hipMalloc(&vtmp, (size_t)n * sizeof(int)) != hipSuccess)
+    return done(fail(c, MPMHIP_ERR_HIP, "debug_sort: out of memory"));
+  hipStream_t s = c->stream;
+  (void)hipMemcpyAsync(kb[sort_input(f, n, bits)], keys_in, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, s);
+  hipLaunchKernelGGL(k_iota, nblk(n), TPB, 0, s, vtmp, n);
+  int rc = sort_pairs(c, kb, vtmp, order_out, n, bits);
+  if (rc == MPMHIP_OK) {
+    (void)hipMemcpyAsync(keys_out, kb[1], (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, s);
+    if (hipStreamSynchronize(s) != hipSuccess) rc = fail(c, MPMHIP_ERR_HIP, "debug_sort: stream error");
+  }
+  return done(rc);
 }
 // Per-workgroup timeline of the p2g (kernel 0) and g2p (kernel 1) launches, MPMHIP_DEBUG builds only.  out == nullptr: start
 // recording (stamps of earlier launches are cleared); otherwise copy the stamps of the newest launch of `kernel`:
