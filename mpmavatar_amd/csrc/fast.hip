@@ -3,7 +3,7 @@
 // Data layout:
 //   * particles live in a solver-owned SoA copy (component-major fp32 arrays), ordered class-major
 //     (elements | traditional | vertices) and, inside each class, by (4x4x4-cell grid block, cell).  The order is
-//     rebuilt (rocPRIM radix sort of 30-bit keys + one gather pass) when a device-side drift flag asks for it, at the
+//     rebuilt (own radix sort of 30-bit keys, k_rs_*, + one gather pass) when a device-side drift flag asks for it, at the
 //     latest every `rebin_interval` substeps; until then a particle may sit up to one cell outside its block, which
 //     the transfer tiles absorb, and anything further out takes global-memory paths inside the same kernels.
 //   * the grid is stored block-major: block b = (x>>2,y>>2,z>>2) owns 64 nodes, channel-major inside the
@@ -552,7 +552,7 @@ __global__ void k_ranges(const SortKey *keys, Dims d, int blk_bits, const int *p
   int cls = s < d.n_e ? 0 : (s < d.n_nv ? 1 : 2);
   int c0 = cls == 0 ? 0 : (cls == 1 ? d.n_e : d.n_nv), c1 = cls == 0 ? d.n_e : (cls == 1 ? d.n_nv : d.n_p);
   int slot = pb_index[key_block(k, blk_bits)];
-  if (slot >= n_P) return;  // capacity overflow: flagged by k_flag_total, the host grows the tables and repeats
+  if (slot >= n_P) return;  // capacity overflow: flagged by k_compact_tiles, the host grows the tables and repeats
   int row = key_state(k, blk_bits) == 0 ? cls * 2 : (cls == 0 ? 6 : 8);  // ghosts: elements, vertices only
   int cb = kf_cell(blk_bits);
   if (s == c0 || (keys[s - 1] >> cb) != (k >> cb)) ranges[(row + 0) * n_P + slot] = s;
