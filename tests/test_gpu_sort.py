@@ -88,6 +88,13 @@ def test_headline_size(solver):
     _check(solver, (cls << 28) | (blk << 8) | cell, 30)
 
 
+def test_above_the_size_limit_the_library_sorts(solver):
+    """More than 2^21 pairs go to rocPRIM (its Onesweep is built for that size): same contract."""
+    rng = np.random.default_rng(21)
+    _check(solver, rng.integers(0, 1 << 30, (1 << 21) + 5, dtype=np.uint32), 30)
+    _check(solver, rng.integers(0, 1 << 30, 1 << 21, dtype=np.uint32), 30)   # the largest input of the own passes
+
+
 def _run(sc_name, n_steps, sort):
     old = os.environ.get("MPMHIP_SORT")
     if sort:
