@@ -2133,6 +2133,12 @@ template <bool FUSED, bool TWO_PASS, bool MFLAG, bool HALO = false>
 __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, const Bufs &b, const Dims &d, float dt, const GridPtrs &g,
                                          const GridParams &gp, const BCList &bcl, float4 *tile, int wg) {
   WGT(g, 1, 0);
+  // The front of a g2p workgroup is a chain of memory latencies (record -> positions + accumulators -> grid stage): few
+  // instructions, long waits.  Its wavefronts get issue priority over wavefronts that are in the VALU / LDS-bound sweeps of another
+  // workgroup on the same SIMD, so the next request of the chain goes out when its data is there: -0.5...-0.8 us on every scene
+  // (profiles/r03_experiments.md).  (The same in p2g is neutral for cloth and costs the fused traditional stress update 7 us: its
+  // SVD sits in that front.)
+  __builtin_amdgcn_s_setprio(3);
   int w = xcd_slice(wg, n_chunks);
   if (w < 0) return;
   const ChunkRec cm = recs[w];
@@ -2234,6 +2240,7 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
   }
   WGT(g, 1, 2);  // wavefront 0 has staged its nodes (accumulator loads + grid stage)
   __syncthreads();
+  __builtin_amdgcn_s_setprio(0);
   WGT(g, 1, 3);  // tile complete
   {
     // lanes without a particle in the tile margin gather from the tile corner (in range, result unused)
