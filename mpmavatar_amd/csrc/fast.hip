@@ -1234,6 +1234,7 @@ struct SplatArgs {
 struct P2GParticle {
   Stencil s;
   float mass;
+  float mass_s;  // mass * FxScale::sm (the mass channel of the fixed-point tile), else = mass
   V3 a0;    // v - dx * C' * fx
   M3 Cdx;   // dx * C'
   M3 Sdt;   // -dt * inv_dx * S   (elements: stress, traditional: vol*stress, vertices: 0)
@@ -1243,8 +1244,64 @@ struct P2GParticle {
 __device__ __forceinline__ P2GParticle p2g_zero(int ox, int oy, int oz, const Dims &d) {
   P2GParticle q;
   q.s = make_stencil(v3((float)(ox + 2) * d.dx, (float)(oy + 2) * d.dx, (float)(oz + 2) * d.dx), d.inv_dx);
-  q.mass = 0.0f; q.a0 = v3(0, 0, 0); q.Cdx = m3_zero(); q.Sdt = m3_zero(); q.vfdt = v3(0, 0, 0);
+  q.mass = 0.0f; q.mass_s = 0.0f; q.a0 = v3(0, 0, 0); q.Cdx = m3_zero(); q.Sdt = m3_zero(); q.vfdt = v3(0, 0, 0);
   return q;
+}
+
+// ---- the chunk tile in packed fixed point (template parameter FX; the default, MPMHIP_P2G_TILE=f64 selects the fp64 tile) ----
+// The tile pass is bound by LDS atomic INSTRUCTIONS: 27 nodes x 4 channels per issuing lane, a ds_add_f64 costs the CU 6.7 +
+// 0.17 x active lanes clocks and a ds_add_u64 7.5 + 0.04 x lanes (tools/ubench_lds_u64.hip; ds_add_f32 is 3 clocks PER LANE).  Two
+// 32-bit fixed-point channels share one 64-bit integer add -- (mass | p_x) and (p_y | p_z): the sum of packed words is the packed
+// word of the sums (two's complement: the signed low field borrows from the high one and the decode gives it back) -- so a node
+// takes 2 atomics instead of 4, integer ones.  The scale of each field is a power of two chosen per workgroup so that the
+// largest possible node sum of THIS chunk -- the sum over its lanes of a bound on |contribution| -- stays below 2^30: one unit
+// is 2^-23..2^-22 of the sum of the chunk's largest contributions, i.e. an add is rounded like an fp32 add into a running sum
+// of that size (what the reference's atomic_add does), and the sum itself is exact and order-independent.  Scaling by a power
+// of two commutes with fp32 rounding: the DPP pre-reduction computes exactly what it computed before, times the scale.
+struct FxScale { float sm, sp, inv_sm, inv_sp; };
+__device__ __forceinline__ float fx_pow2(float bound, float &inv) {  // largest 2^k with bound * 2^k < 2^30, and 2^-k
+  int eb = (__float_as_int(bound) >> 23) & 0xff;  // bound < 2^(eb - 126)
+  eb = min(max(eb, 40), 240);
+  inv = __int_as_float((eb - 29) << 23);
+  return __int_as_float((283 - eb) << 23);
+}
+// bound on |what lane q adds to any one node|: mass channel, momentum channels (the largest of the three components)
+__device__ __forceinline__ void fx_bounds(const P2GParticle &q, bool on, float &bm, float &bp) {
+  const float W3 = 0.421875f, DW = 0.5625f;  // max w^3 (0.75^3), max |dw| w^2
+  auto comp = [&](float a0, float cx, float cy, float cz, float s0, float s1, float s2, float vf) {
+    return W3 * q.mass * (fabsf(a0) + 2.0f * (fabsf(cx) + fabsf(cy) + fabsf(cz))) + DW * (fabsf(s0) + fabsf(s1) + fabsf(s2)) +
+           W3 * fabsf(vf);
+  };
+  const M3 &C = q.Cdx, &S = q.Sdt;
+  float bx = comp(q.a0.x, C.a00, C.a01, C.a02, S.a00, S.a01, S.a02, q.vfdt.x);
+  float by = comp(q.a0.y, C.a10, C.a11, C.a12, S.a10, S.a11, S.a12, q.vfdt.y);
+  float bz = comp(q.a0.z, C.a20, C.a21, C.a22, S.a20, S.a21, S.a22, q.vfdt.z);
+  bm = on ? W3 * q.mass : 0.0f;
+  bp = on ? fmaxf(bx, fmaxf(by, bz)) : 0.0f;
+}
+// workgroup sums of the bounds -> the chunk's scales (contains the barrier that also publishes the cleared tile); red: 8 floats
+__device__ __forceinline__ FxScale fx_scales(float bm, float bp, float *red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    bm += __shfl_xor(bm, o);
+    bp += __shfl_xor(bp, o);
+  }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = bm; red[4 + (threadIdx.x >> 6)] = bp; }
+  __syncthreads();
+  float Bm = ((red[0] + red[1]) + (red[2] + red[3])) * 1.001f, Bp = ((red[4] + red[5]) + (red[6] + red[7])) * 1.001f;
+  FxScale f;
+  f.sm = fx_pow2(Bm, f.inv_sm);
+  f.sp = fx_pow2(Bp, f.inv_sp);
+  return f;
+}
+__device__ __forceinline__ void fx_apply(P2GParticle &q, const FxScale &f) {
+  q.mass_s = q.mass * f.sm;
+  q.a0 = f.sp * q.a0; q.Cdx = f.sp * q.Cdx; q.Sdt = f.sp * q.Sdt; q.vfdt = f.sp * q.vfdt;
+}
+__device__ __forceinline__ int fx_round(float x) {  // floor(x + 0.5)
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
 }
 
 // All global loads of a particle are issued before anything waits on them: x, mass, C, v for every lane, stress / vol
@@ -1316,6 +1373,7 @@ __device__ __forceinline__ P2GParticle p2g_finish(const P2GRaw &r, const Bufs &b
   P2GParticle q;
   q.s = make_stencil(r.x, d.inv_dx);
   q.mass = r.mass;
+  q.mass_s = r.mass;
   M3 C = r.C;
   C = (1.0f - rpic) * C + (rpic / 2.0f) * (C - transpose(C));  // mpm_utils.py:530-532
   if (rpic < -0.001f) C = m3_zero();
@@ -1473,7 +1531,7 @@ __device__ __forceinline__ void p2g_escaped(const Bufs &b, const VAdj &va, int c
 
 // ---- pieces shared by the two p2g kernels -------------------------------------------------------------------
 // tile pass of one chunk: margin check (out-of-margin lanes go to the esc list), DPP pre-reduction, LDS atomics
-template <int STEPS>
+template <int STEPS, bool FX>
 __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p, P2GParticle &q, bool valid, int ox, int oy,
                                             int oz, const Dims &d, const GridPtrs &g) {
   int &esc_n = *esc_n_p;
@@ -1512,7 +1570,7 @@ __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         float wy = bspline_w(j, st.fx.y), dwy = bspline_dw(j, st.fx.y);
-        float wxy = wx * wy, wxym = wxy * q.mass;
+        float wxy = wx * wy, wxym = wxy * q.mass, wxyms = wxy * q.mass_s;
         V3 Bij = Bi + (float)j * Cy;
         V3 T = wxym * Bij + ((dwx * wy) * S0 + (wx * dwy) * S1 + wxy * q.vfdt);
         V3 dT = wxym * Cz;
@@ -1520,12 +1578,17 @@ __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           float wzk = sel3(k, st.w0.z, st.w1.z, st.w2.z), dwzk = bspline_dw(k, st.fx.z);
-          float wm = wxym * wzk;
+          float wm = wxyms * wzk;
           if (k > 0) T = T + dT;
           V3 add = wzk * T + dwzk * Q;
           float r0 = wm, r1 = add.x, r2 = add.y, r3 = add.z;
           seg_scan4<STEPS>(r0, r1, r2, r3, sm);
-          if (do_add) {
+          if (do_add && FX) {
+            unsigned long long *p = (unsigned long long *)tile + base + tile_idx(i, j, k);
+            int i0 = fx_round(r0), i1 = fx_round(r1), i2 = fx_round(r2), i3 = fx_round(r3);  // (i0 >= 0: masses)
+            atomicAdd(p, ((unsigned long long)(unsigned)i1 << 32) | (unsigned)i0);
+            atomicAdd(p + TILE_PAD, ((unsigned long long)(unsigned)(i3 + (i2 >> 31)) << 32) | (unsigned)i2);
+          } else if (do_add) {
             double *p = tile + base + tile_idx(i, j, k);
             atomicAdd(p, (double)r0);
             atomicAdd(p + TILE_PAD, (double)r1);
@@ -1540,14 +1603,24 @@ __device__ __forceinline__ void p2g_scatter(double *tile, int *esc, int *esc_n_p
 
 // flush: skip untouched nodes; every touched node lies in an active block by construction.  REZERO leaves the tile
 // cleared for the next chunk of a persistent workgroup.
-template <bool REZERO, bool TO_MOV = false>
-__device__ __forceinline__ void p2g_flush(double *tile, int ox, int oy, int oz, const Dims &d, const GridPtrs &g) {
+template <bool REZERO, bool TO_MOV, bool FX>
+__device__ __forceinline__ void p2g_flush(double *tile, int ox, int oy, int oz, const Dims &d, const GridPtrs &g, const FxScale &fs) {
   for (int t = threadIdx.x; t < TILE3; t += PT) {
     int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
-    double *qd = tile + tile_idx(ti, tj, tk);
-    float m = (float)qd[0], px = (float)qd[TILE_PAD], py = (float)qd[2 * TILE_PAD], pz = (float)qd[3 * TILE_PAD];
-    if (m == 0.0f && px == 0.0f && py == 0.0f && pz == 0.0f) continue;
-    if (REZERO) { qd[0] = 0.0; qd[TILE_PAD] = 0.0; qd[2 * TILE_PAD] = 0.0; qd[3 * TILE_PAD] = 0.0; }
+    float m, px, py, pz;
+    if (FX) {
+      unsigned long long *qd = (unsigned long long *)tile + tile_idx(ti, tj, tk);
+      unsigned long long s0 = qd[0], s1 = qd[TILE_PAD];
+      if ((s0 | s1) == 0ull) continue;
+      if (REZERO) { qd[0] = 0ull; qd[TILE_PAD] = 0ull; }
+      int im = (int)(unsigned)s0, ipx = (int)(s0 >> 32), ipy = (int)(unsigned)s1, ipz = (int)(s1 >> 32) + (ipy < 0 ? 1 : 0);
+      m = (float)im * fs.inv_sm; px = (float)ipx * fs.inv_sp; py = (float)ipy * fs.inv_sp; pz = (float)ipz * fs.inv_sp;
+    } else {
+      double *qd = tile + tile_idx(ti, tj, tk);
+      m = (float)qd[0]; px = (float)qd[TILE_PAD]; py = (float)qd[2 * TILE_PAD]; pz = (float)qd[3 * TILE_PAD];
+      if (m == 0.0f && px == 0.0f && py == 0.0f && pz == 0.0f) continue;
+      if (REZERO) { qd[0] = 0.0; qd[TILE_PAD] = 0.0; qd[2 * TILE_PAD] = 0.0; qd[3 * TILE_PAD] = 0.0; }
+    }
     if (DBG(g, 1)) continue;
     int x = ox + ti, y = oy + tj, z = oz + tk;
     if (!in_grid(x, y, z, d.G)) continue;
@@ -1771,10 +1844,10 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
 // JT = true: the mover holds MANY traditional particles (run_demo.py keeps 100k sand particles frozen for the first
 // frames); their joint splat (weight, weight * joint velocity into the mover channels, mpm_solver.py:677-704) is a
 // second pass through the same LDS tile by the chunk that owns them instead of 27 x 4 scattered global atomics each.
-template <int STEPS, bool TRAD, bool JT>
+template <int STEPS, bool TRAD, bool JT, bool FX>
 __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, const Bufs &b, const VAdj &va, const Dims &d, float rpic,
                                          float dt, const GridPtrs &g, const SplatArgs &sa, const TradParams &tp, double *tile, int *esc,
-                                         int &esc_n) {
+                                         int &esc_n, float *red) {
   WGT(g, 0, 0);
   if (blockIdx.x == 0 && threadIdx.x == 0 && g.host_sig) {
     // progress + drift flag for the host (plain stores into pinned host memory instead of a copy + event every few
@@ -1833,7 +1906,7 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
   if (DBG(g, 16)) w_nv = false;
   WGT(g, 0, 1);  // chunk record here
   P2GRaw raw = p2g_issue<TRAD>(b, va, valid, cls, s, d, w_nv, w_v);
-  for (int t = threadIdx.x; t < 4 * TILE_PAD; t += PT) tile[t] = 0.0;
+  for (int t = threadIdx.x; t < (FX ? 2 : 4) * TILE_PAD; t += PT) tile[t] = 0.0;  // (fixed point: two 64-bit words per node)
   if (threadIdx.x == 0) esc_n = 0;
   if (valid) {  // early warning for the adaptive re-sort: will this particle still fit the tile DRIFT_LOOKAHEAD substeps
                 // from now (the host reads the flag with a lag of up to 16 substeps)?  The out-of-margin paths work
@@ -1845,9 +1918,17 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
   }
   WGT(g, 0, 2);  // particle loads + first adjacency batch here, tile cleared
   P2GParticle q = p2g_finish<TRAD>(raw, b, va, valid, cls, s, d, rpic, dt, w_v, tp);
-  __syncthreads();
+  FxScale fs{1.0f, 1.0f, 1.0f, 1.0f};
+  if (FX) {
+    float bm, bp;
+    fx_bounds(q, valid, bm, bp);
+    fs = fx_scales(bm, bp, red);  // (barrier inside)
+    fx_apply(q, fs);
+  } else {
+    __syncthreads();
+  }
   WGT(g, 0, 3);  // corner forces gathered (and the fused traditional stress update done) in every wavefront
-  p2g_scatter<STEPS>(tile, esc, &esc_n, q, valid, ox, oy, oz, d, g);
+  p2g_scatter<STEPS, FX>(tile, esc, &esc_n, q, valid, ox, oy, oz, d, g);
   WGT(g, 0, 4);  // wavefront 0 through its scatter
   __syncthreads();
   WGT(g, 0, 5);  // every wavefront through its scatter
@@ -1859,7 +1940,7 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
       if (cm.map(chunk * CHUNK + esc[e], ec, es)) p2g_escaped<false>(b, va, ec, es, d, rpic, dt, g, tp);
     }
   }
-  p2g_flush<JT>(tile, ox, oy, oz, d, g);
+  p2g_flush<JT, false, FX>(tile, ox, oy, oz, d, g, fs);
   WGT(g, 0, 6);  // flush atomics of wavefront 0 acknowledged
   if (JT) {
     // held = one of the last js.n_t traditional particles in the caller's order, with the reference's range check
@@ -1880,11 +1961,19 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
         if (splat_ok(d.G, st)) {  // mpm_solver.py:692
           held = true;
           pv = load_v3(sa.js.vel_t + 3 * (size_t)jq);
-          q2.s = st; q2.mass = 1.0f; q2.a0 = pv;  // contribution = (w, w * v): the scatter's mass / momentum channels
+          q2.s = st; q2.mass = 1.0f; q2.mass_s = 1.0f; q2.a0 = pv;  // contribution = (w, w * v): the scatter's mass / momentum channels
         }
       }
-      __syncthreads();
-      p2g_scatter<STEPS>(tile, esc, &esc_n, q2, held, ox, oy, oz, d, g);
+      FxScale fs2{1.0f, 1.0f, 1.0f, 1.0f};
+      if (FX) {
+        float bm, bp;
+        fx_bounds(q2, held, bm, bp);
+        fs2 = fx_scales(bm, bp, red);  // (barrier inside)
+        fx_apply(q2, fs2);
+      } else {
+        __syncthreads();
+      }
+      p2g_scatter<STEPS, FX>(tile, esc, &esc_n, q2, held, ox, oy, oz, d, g);
       __syncthreads();
       for (int e = threadIdx.x; e < esc_n; e += PT) {
         int ec = 0, es = 0;
@@ -1892,20 +1981,21 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
         int o = sa.js.perm[es] - sa.js.off_t;
         mover_escaped(ld3(b.all, A_X, es), load_v3(sa.js.vel_t + 3 * (size_t)o), d, g);
       }
-      p2g_flush<false, true>(tile, ox, oy, oz, d, g);
+      p2g_flush<false, true, FX>(tile, ox, oy, oz, d, g, fs2);
     }
   }
   wg_done(sa.pack);
 }
 
 // The chunk records come first in the argument list: the record load is the head of every workgroup's dependency chain.
-template <int STEPS, bool TRAD, bool JT>
+template <int STEPS, bool TRAD, bool JT, bool FX>
 __global__ __launch_bounds__(PT) void k_p2g(const ChunkRec *recs, int n_chunks, Bufs b, VAdj va, Dims d, float rpic, float dt,
                                              GridPtrs g, SplatArgs sa, TradParams tp) {
   __shared__ double tile[4 * TILE_PAD];
   __shared__ int esc[CHUNK];
   __shared__ int esc_n;
-  p2g_body<STEPS, TRAD, JT>(recs, n_chunks, b, va, d, rpic, dt, g, sa, tp, tile, esc, esc_n);
+  __shared__ float red[8];
+  p2g_body<STEPS, TRAD, JT, FX>(recs, n_chunks, b, va, d, rpic, dt, g, sa, tp, tile, esc, esc_n, red);
 }
 // The cloth instantiation with six wavefronts per SIMD instead of the five its 90 VGPRs allow: 80 VGPRs + 9 spilled dwords.
 // A workgroup's life is a chain of memory latencies (record -> particles -> adjacency -> corner forces) followed by a
@@ -1917,7 +2007,8 @@ void k_p2g_w6(const ChunkRec *recs, int n_chunks, Bufs b, VAdj va, Dims d, float
   __shared__ double tile[4 * TILE_PAD];
   __shared__ int esc[CHUNK];
   __shared__ int esc_n;
-  p2g_body<3, false, false>(recs, n_chunks, b, va, d, rpic, dt, g, sa, tp, tile, esc, esc_n);
+  __shared__ float red[8];
+  p2g_body<3, false, false, true>(recs, n_chunks, b, va, d, rpic, dt, g, sa, tp, tile, esc, esc_n, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2578,6 +2669,7 @@ struct FastState {
   int splat_first_max = 1 << 30;  // more splat workgroups than this go behind the chunk workgroups (MPMHIP_SPLAT_FIRST_MAX; measured
                                   // neutral early and late -- profiles/r03_experiments.md -- so they stay in front)
   bool w6 = false;             // six-wavefront builds of the cloth kernels (k_p2g_w6, k_g2p_w6): MPMHIP_W6
+  bool p2g_fixed = true;       // p2g's chunk tile in packed fixed point (k_p2g<.., FX = true>); MPMHIP_P2G_TILE=f64: the fp64 tile
   bool g2p_mflag = false;      // g2p asks m_flag before it loads a block's accumulators (one more dependent memory level at the head
                                // of every workgroup; the default loads them with the particle positions): MPMHIP_G2P_MFLAG=1
   // adaptive collective re-sorts (mpmhip_rccl_steps with rebin_interval <= 0): the ranks' drift flags are max-reduced
@@ -3047,6 +3139,7 @@ int fast_init(mpmhip_ctx *c) {
   int cell_bits = f->blk_bits_plain + 8 + 2 + 2 <= 32 ? 8 : 6;  // 8: predictive sort (see make_key)
   if (const char *e = getenv("MPMHIP_PREDICTIVE_SORT")) if (atoi(e) == 0) cell_bits = 6;
   if (const char *e = getenv("MPMHIP_SORT")) f->sort_rocprim = std::string(e) == "rocprim";
+  if (const char *e = getenv("MPMHIP_P2G_TILE")) f->p2g_fixed = std::string(e) != "f64";
   f->key_bits = f->blk_bits_plain + cell_bits + 2 + 2;
   if (f->key_bits > 32) return fail(c, MPMHIP_ERR_INVALID, "grid too large for 32-bit sort keys");
   f->blk_bits = f->blk_bits_plain | (cell_bits << 8);
@@ -3190,10 +3283,14 @@ int fast_pull(mpmhip_ctx *c) {
 // and the in-tile joint splat of held traditional particles
 #define P2G_LAUNCH(trad, jt, ...)                                                \
   do {                                                                           \
-    if ((trad) && (jt)) hipLaunchKernelGGL((k_p2g<3, true, true>), __VA_ARGS__); \
-    else if (trad) hipLaunchKernelGGL((k_p2g<3, true, false>), __VA_ARGS__);     \
+    if (!f->p2g_fixed) {  /* MPMHIP_P2G_TILE=f64 */                                     \
+      if ((trad) && (jt)) hipLaunchKernelGGL((k_p2g<3, true, true, false>), __VA_ARGS__);  \
+      else if (trad) hipLaunchKernelGGL((k_p2g<3, true, false, false>), __VA_ARGS__);      \
+      else hipLaunchKernelGGL((k_p2g<3, false, false, false>), __VA_ARGS__);               \
+    } else if ((trad) && (jt)) hipLaunchKernelGGL((k_p2g<3, true, true, true>), __VA_ARGS__); \
+    else if (trad) hipLaunchKernelGGL((k_p2g<3, true, false, true>), __VA_ARGS__);     \
     else if (f->w6) hipLaunchKernelGGL(k_p2g_w6, __VA_ARGS__);                   \
-    else hipLaunchKernelGGL((k_p2g<3, false, false>), __VA_ARGS__);              \
+    else hipLaunchKernelGGL((k_p2g<3, false, false, true>), __VA_ARGS__);              \
   } while (0)
 
 #define G2P_LAUNCH(fused, two, ...)                                                              \

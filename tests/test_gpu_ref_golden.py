@@ -27,9 +27,22 @@ SEQS = rg.names("seq")
 
 
 def _build(z, mode, **kw):
+    """mode "fast-f64": the fast back end with p2g's chunk tile in fp64 (MPMHIP_P2G_TILE=f64, read when the solver is built) instead
+    of the packed fixed-point tile it uses by default."""
+    import os
     from mpmavatar_amd import harness
     sc = rg.scene_from_npz(z)
-    sim = harness.build_solver(sc, "cuda:0", mode=mode, **kw)
+    old = os.environ.get("MPMHIP_P2G_TILE")
+    if mode == "fast-f64":
+        os.environ["MPMHIP_P2G_TILE"] = "f64"
+    try:
+        sim = harness.build_solver(sc, "cuda:0", mode="fast" if mode == "fast-f64" else mode, **kw)
+    finally:
+        if mode == "fast-f64":
+            if old is None:
+                os.environ.pop("MPMHIP_P2G_TILE", None)
+            else:
+                os.environ["MPMHIP_P2G_TILE"] = old
     return sc, sim
 
 
@@ -37,7 +50,7 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("mode", MODES + ["fast-f64"])
 @pytest.mark.parametrize("name", TRACES)
 def test_hip_reproduces_the_traced_substep(name, mode):
     from mpmavatar_amd import harness
@@ -68,9 +81,19 @@ def test_hip_reproduces_the_traced_substep(name, mode):
         err = rg.rel(_np(getattr(md, f)), post[f])
         assert err < tol, f"{name}[{mode}]: model.{f} differs from the reference by {err:.2e}"
     m, v_in, v_out = (_np(a) for a in sim.solver.export_grid())
-    assert rg.rel(m, post["grid_m"], floor=1e-9) < tol
-    act = post["grid_m"] > 1e-13  # away from the reference's 1e-15 mass threshold (mpm_utils.py:566)
-    assert rg.rel(v_out[act], post["grid_v_out"][act]) < 2e-4
+    ref_m, ref_v = post["grid_m"], post["grid_v_out"]
+    assert rg.rel(m, ref_m, floor=1e-9) < tol
+    act = ref_m > 1e-13  # away from the reference's 1e-15 mass threshold (mpm_utils.py:566)
+    if mode == "fast":
+        # The packed fixed-point tile of p2g rounds a contribution to a unit that is fixed per chunk (2^-22 of the chunk's summed
+        # bounds): what a node carries -- mass, momentum -- is as close to the reference as ever (measured <= 4e-7 of the
+        # largest), but the QUOTIENT at a node that only received weights of 1e-3 and less has correspondingly fewer digits.
+        # Such a node hands its velocity back with the same tiny weights (the particles above hold 5e-5).  So: momentum at
+        # every node, velocity at the nodes that carry at least 1e-4 of the heaviest node's mass (measured <= 6e-5; all nodes in
+        # the fp64-tile mode below: <= 2e-5).  profiles/r03_p2g_fixed_point.md
+        assert rg.rel(m[..., None] * v_out, ref_m[..., None] * ref_v, floor=1e-12) < tol
+        act &= ref_m >= 1e-4 * ref_m.max()
+    assert rg.rel(v_out[act], ref_v[act]) < 2e-4
 
 
 def _run_to(sim, sc, cp):
