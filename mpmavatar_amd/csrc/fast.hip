@@ -1906,7 +1906,7 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
   if (DBG(g, 16)) w_nv = false;
   WGT(g, 0, 1);  // chunk record here
   P2GRaw raw = p2g_issue<TRAD>(b, va, valid, cls, s, d, w_nv, w_v);
-  for (int t = threadIdx.x; t < (FX ? 2 : 4) * TILE_PAD; t += PT) tile[t] = 0.0;  // (fixed point: two 64-bit words per node)
+  for (int t = threadIdx.x; t < ((FX && !JT) ? 2 : 4) * TILE_PAD; t += PT) tile[t] = 0.0;  // (fixed point: two 64-bit words per node; the joint pass needs all four)
   if (threadIdx.x == 0) esc_n = 0;
   if (valid) {  // early warning for the adaptive re-sort: will this particle still fit the tile DRIFT_LOOKAHEAD substeps
                 // from now (the host reads the flag with a lag of up to 16 substeps)?  The out-of-margin paths work
@@ -1964,16 +1964,11 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
           q2.s = st; q2.mass = 1.0f; q2.mass_s = 1.0f; q2.a0 = pv;  // contribution = (w, w * v): the scatter's mass / momentum channels
         }
       }
-      FxScale fs2{1.0f, 1.0f, 1.0f, 1.0f};
-      if (FX) {
-        float bm, bp;
-        fx_bounds(q2, held, bm, bp);
-        fs2 = fx_scales(bm, bp, red);  // (barrier inside)
-        fx_apply(q2, fs2);
-      } else {
-        __syncthreads();
-      }
-      p2g_scatter<STEPS, FX>(tile, esc, &esc_n, q2, held, ox, oy, oz, d, g);
+      // This pass stays on the fp64 tile: the grid stage pins EVERY node with a positive mover weight (mpm_utils.py: joint nodes
+      // take the joint velocity), and a weight below half a fixed-point unit would round to "not held" -- released sand next to
+      // the held pile then fell 3 % too fast (demo-250: x off by 2.3e-4 after 1000 substeps; with this 6e-6, tools/gpu/diag_demo.py).
+      __syncthreads();
+      p2g_scatter<STEPS, false>(tile, esc, &esc_n, q2, held, ox, oy, oz, d, g);
       __syncthreads();
       for (int e = threadIdx.x; e < esc_n; e += PT) {
         int ec = 0, es = 0;
@@ -1981,7 +1976,7 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
         int o = sa.js.perm[es] - sa.js.off_t;
         mover_escaped(ld3(b.all, A_X, es), load_v3(sa.js.vel_t + 3 * (size_t)o), d, g);
       }
-      p2g_flush<false, true, FX>(tile, ox, oy, oz, d, g, fs2);
+      p2g_flush<false, true, false>(tile, ox, oy, oz, d, g, FxScale{1.0f, 1.0f, 1.0f, 1.0f});
     }
   }
   wg_done(sa.pack);
