@@ -3276,16 +3276,19 @@ int fast_pull(mpmhip_ctx *c) {
 //   C: element finalise, drift-flag bookkeeping
 // P2G_LAUNCH(trad, jt, grid, block, shmem, stream, args...): k_p2g with / without the fused traditional stress update
 // and the in-tile joint splat of held traditional particles
+#ifndef P2G_STEPS
+#define P2G_STEPS 3  // DPP scan steps of the fixed-point instantiations (experiment switch)
+#endif
 #define P2G_LAUNCH(trad, jt, ...)                                                \
   do {                                                                           \
     if (!f->p2g_fixed) {  /* MPMHIP_P2G_TILE=f64 */                                     \
       if ((trad) && (jt)) hipLaunchKernelGGL((k_p2g<3, true, true, false>), __VA_ARGS__);  \
       else if (trad) hipLaunchKernelGGL((k_p2g<3, true, false, false>), __VA_ARGS__);      \
       else hipLaunchKernelGGL((k_p2g<3, false, false, false>), __VA_ARGS__);               \
-    } else if ((trad) && (jt)) hipLaunchKernelGGL((k_p2g<3, true, true, true>), __VA_ARGS__); \
-    else if (trad) hipLaunchKernelGGL((k_p2g<3, true, false, true>), __VA_ARGS__);     \
+    } else if ((trad) && (jt)) hipLaunchKernelGGL((k_p2g<P2G_STEPS, true, true, true>), __VA_ARGS__); \
+    else if (trad) hipLaunchKernelGGL((k_p2g<P2G_STEPS, true, false, true>), __VA_ARGS__);     \
     else if (f->w6) hipLaunchKernelGGL(k_p2g_w6, __VA_ARGS__);                   \
-    else hipLaunchKernelGGL((k_p2g<3, false, false, true>), __VA_ARGS__);              \
+    else hipLaunchKernelGGL((k_p2g<P2G_STEPS, false, false, true>), __VA_ARGS__);              \
   } while (0)
 
 #define G2P_LAUNCH(fused, two, ...)                                                              \
