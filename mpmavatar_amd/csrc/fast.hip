@@ -1280,12 +1280,18 @@ __device__ __forceinline__ void fx_bounds(const P2GParticle &q, bool on, float &
   bp = on ? fmaxf(bx, fmaxf(by, bz)) : 0.0f;
 }
 // workgroup sums of the bounds -> the chunk's scales (contains the barrier that also publishes the cleared tile); red: 8 floats
+__device__ __forceinline__ float dpp_shr_f(float v, int n);  // (defined with the DPP pre-reduction below)
+// sum over the wavefront: inclusive DPP scan inside the four 16-lane rows, then the four row totals through v_readlane (a
+// __shfl_xor butterfly is six dependent ds_bpermute round trips per value: it cost every chunk workgroup ~1 us of its ~10)
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_shr_f(v, 1); v += dpp_shr_f(v, 2); v += dpp_shr_f(v, 4); v += dpp_shr_f(v, 8);
+  int b = __float_as_int(v);
+  return (__int_as_float(__builtin_amdgcn_readlane(b, 15)) + __int_as_float(__builtin_amdgcn_readlane(b, 31))) +
+         (__int_as_float(__builtin_amdgcn_readlane(b, 47)) + __int_as_float(__builtin_amdgcn_readlane(b, 63)));
+}
 __device__ __forceinline__ FxScale fx_scales(float bm, float bp, float *red) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    bm += __shfl_xor(bm, o);
-    bp += __shfl_xor(bp, o);
-  }
+  bm = wave_sum(bm);
+  bp = wave_sum(bp);
   if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = bm; red[4 + (threadIdx.x >> 6)] = bp; }
   __syncthreads();
   float Bm = ((red[0] + red[1]) + (red[2] + red[3])) * 1.001f, Bp = ((red[4] + red[5]) + (red[6] + red[7])) * 1.001f;
