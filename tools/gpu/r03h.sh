@@ -1,15 +1,16 @@
 #!/bin/bash
-# DPP scan depth with the integer tile (ds_add_u64 barely depends on the lane count): 2 / 3 (default) / 4 steps
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r03h; rm -f gpurun_out/r03h/*.txt
-V=$GRAFT_REPO_ROOT/mpmavatar_amd/lib/variants
-for rep in 1 2; do
-for v in default st2 st4; do
-  [ $v = default ] && unset MPMHIP_LIB || export MPMHIP_LIB=$V/libmpmhip_$v.so
-  for scene in sheet-500k garment-120k-aniso demo-250; do
-    timeout 600 python bench.py --scene $scene --steps 400 --warmup 40 --no-cpu-baseline --advance 2000 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('$v $scene', round(d['value']), round(d['value_draped']), [(k['name'], round(k['ms']*1e3,1)) for k in d['kernels'][:3]])" | tee -a gpurun_out/r03h/bench.txt
-  done
-done
-done
+# round 3, batch h: S4 / S3 1000-substep parity records (oracle at a sane thread count), dist + api tests, late-state with the small-bin splat
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03h; mkdir -p $O; cd $R
+python tools/gpu/full_parity.py sheet-500k 1000 > $O/full_parity_sheet.log 2>&1; grep "^substep\|^first" $O/full_parity_sheet.log | tail -18
+python tools/gpu/full_parity.py garment-120k-aniso 1000 > $O/full_parity_garment.log 2>&1; grep "^substep\|^first" $O/full_parity_garment.log | tail -5
+cp gpurun_out/full_parity_*.json $O/ 2>/dev/null
+timeout 1200 python -m pytest tests/test_dist.py tests/test_gpu_api.py tests/test_bench_contract.py tests/test_gpu_edges.py tests/test_gpu_parity.py -q --durations=5 2>&1 | tail -12 | tee $O/pytest.txt
+python bench.py --scene sheet-500k --steps 200 --warmup 20 --no-cpu-baseline --advance 0 --pre-advance 2000 > $O/bench_late.json 2>/dev/null
+python -c "
+import json
+d=json.load(open('$O/bench_late.json'))
+print('late state:', d['value'], d['ms_per_step']*1e3, 'us;', [(k['name'], round(k['ms']*1e3,2), k.get('launches')) for k in d['kernels']])"
+python bench.py --steps 200 --warmup 40 > $O/bench.json 2> $O/bench.err; python -c "
+import json
+d=json.load(open('$O/bench.json')); print(d['value'], d.get('value_draped'), d['cpu_baseline'], d['roofline'])"
+MPMHIP_LIB=$R/mpmavatar_amd/lib/variants/libmpmhip_dbg.so python tools/gpu/wgtrace.py sheet-500k 2200 r03h_late > $O/wgtrace_sheet_late.md 2>/dev/null; sed -n 5,20p $O/wgtrace_sheet_late.md
