@@ -12,8 +12,9 @@
 // Launches per substep (single stream, no events):
 //   1. stress      per-particle map; fuses the tail of the previous substep's g2p_e (element finalise) and carries
 //                  extra workgroups that clear the grid accumulators the previous substep left loaded
-//   2. p2g         one workgroup per 256-particle chunk of a block: fp64 LDS tile (8x8x8 nodes), DPP pre-reduction,
-//                  ds_add_f64, coalesced flush; extra workgroups do the body-face and joint splats
+//   2. p2g         one workgroup per 256-particle chunk of a block: LDS tile (8x8x8 nodes) in packed fixed point, DPP
+//                  pre-reduction, two ds_add_u64 per node, coalesced flush; extra workgroups do the body-face and joint
+//                  splats (fp64 tile, ds_add_f64)
 //   3. g2p         same chunks; the tile is staged from the accumulators and every node goes through the grid stage
 //                  (normalise, gravity, damping, collide, mover, BCs) on the way -- there is no grid kernel
 // Profiling runs (one sync per reference phase) and export use the stand-alone k_grid instead.
@@ -1421,7 +1422,8 @@ __device__ __forceinline__ P2GParticle p2g_load(const Bufs &b, const VAdj &va, i
 // each 16-lane DPP row (row_shr 1,2,4,8; a segment = run of lanes with equal cell key) -- and only the last
 // lane of every segment issues the LDS atomic.  Measured on MI355X the cost of a ds_add_f64 wave instruction
 // is proportional to its active lanes (tools/ubench_lds_lanes.hip), and ds_add_f32 is ~10x slower than
-// ds_add_f64 (tools/ubench_atomics.hip), hence fp64 accumulators in LDS.
+// ds_add_f64 (tools/ubench_atomics.hip), hence fp64 accumulators in LDS for the splats -- and, cheaper still, two 32-bit
+// fixed-point channels per ds_add_u64 for the particles ("the chunk tile in packed fixed point" above).
 __device__ __forceinline__ int dpp_shr_i(int v, int old, int n) {  // lane l <- lane l-n of the same row, else old
   switch (n) {
     case 1: return __builtin_amdgcn_update_dpp(old, v, 0x111, 0xf, 0xf, false);
