@@ -321,6 +321,10 @@ int mpmhip_profile_count(const mpmhip_ctx *ctx);
 /* i-th phase: name, accumulated milliseconds, number of samples */
 int mpmhip_profile_get(const mpmhip_ctx *ctx, int32_t i, const char **name, double *total_ms,
                        int64_t *samples);
+/* on = 2 only: the i-th phase's launch timed by its OWN start / stop timestamps (the kernel duration a profiler's kernel trace
+ * reports), without what the event bracket adds around it; samples = 0 for phases that are not a single hot launch.
+ * (No reference counterpart: the reference's ScopedTimer only has the synchronised wall time, mpm_solver.py:16.) */
+int mpmhip_profile_get_kernel(const mpmhip_ctx *ctx, int32_t i, double *kernel_ms, int64_t *samples);
 int mpmhip_profile_reset(mpmhip_ctx *ctx);
 
 #ifdef __cplusplus

@@ -122,6 +122,7 @@ SIGNATURES = {
     "mpmhip_profile_enable": (C.c_int, [vp, C.c_int32]),
     "mpmhip_profile_count": (C.c_int, [vp]),
     "mpmhip_profile_get": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "mpmhip_profile_get_kernel": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mpmhip_profile_reset": (C.c_int, [vp]),
 }
 

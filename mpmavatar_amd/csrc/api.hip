@@ -84,7 +84,8 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
       return bail(MPMHIP_ERR_HIP, "hipStreamCreate failed");
     c->own_stream = true;
   }
-  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->kev0) != hipSuccess ||
+      hipEventCreate(&c->kev1) != hipSuccess)
     return bail(MPMHIP_ERR_HIP, "hipEventCreate failed");
   int rc = fast_mode(c) ? fast_init(c) : baseline_init(c);
   if (rc) return bail(rc, c->err);
@@ -110,6 +111,8 @@ void mpmhip_destroy(mpmhip_ctx *c) {
   }
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->kev0) (void)hipEventDestroy(c->kev0);
+  if (c->kev1) (void)hipEventDestroy(c->kev1);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -598,6 +601,12 @@ int mpmhip_profile_get(const mpmhip_ctx *c, int32_t i, const char **name, double
   if (name) *name = c->phases[i].name;
   if (total_ms) *total_ms = c->phases[i].total_ms;
   if (samples) *samples = c->phases[i].samples;
+  return MPMHIP_OK;
+}
+int mpmhip_profile_get_kernel(const mpmhip_ctx *c, int32_t i, double *kernel_ms, int64_t *samples) {
+  if (!c || i < 0 || i >= (int)c->phases.size()) return MPMHIP_ERR_INVALID;
+  if (kernel_ms) *kernel_ms = c->phases[i].kernel_ms;
+  if (samples) *samples = c->phases[i].kernel_samples;
   return MPMHIP_OK;
 }
 int mpmhip_profile_reset(mpmhip_ctx *c) {

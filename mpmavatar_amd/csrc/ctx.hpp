@@ -56,6 +56,8 @@ struct Phase {
   const char *name;
   double total_ms = 0.0;
   int64_t samples = 0;
+  double kernel_ms = 0.0;       // the launch's own start -> stop time (hot launches in prof_fused mode), without the bracket's cost
+  int64_t kernel_samples = 0;
 };
 
 struct FastState;  // defined in fast.hip
@@ -105,6 +107,11 @@ struct mpmhip_ctx {
   bool prof_fused = false;  // event pairs around the launches of the production (fused) loop; same kernels as unprofiled
   std::vector<mpm::Phase> phases;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // the launch's OWN start / stop timestamps (hipExtLaunchKernelGGL): what rocprofv3 --kernel-trace reports as the kernel's duration.
+  // An event bracket around a launch adds ~3 us of packet processing; in prof_fused mode the hot launches carry these two events
+  // and ScopedPhase reports both times (kernel, bracket).
+  hipEvent_t kev0 = nullptr, kev1 = nullptr;
+  bool kev_pending = false;
 
   mpm::FastState *fast = nullptr;
   bool caller_dirty = true;    // caller arrays newer than the internal state (fast mode)
@@ -139,16 +146,22 @@ struct ScopedPhase {
       c->phases.push_back(Phase{name});
       idx = (int)c->phases.size() - 1;
     }
+    c->kev_pending = false;
     (void)hipEventRecord(c->ev0, c->stream);
   }
   ~ScopedPhase() {
     if (idx < 0) return;
     (void)hipEventRecord(c->ev1, c->stream);
     (void)hipEventSynchronize(c->ev1);
-    float ms = 0.f;
+    float ms = 0.f, kms = 0.f;
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     c->phases[idx].total_ms += ms;
     c->phases[idx].samples += 1;
+    if (c->kev_pending && hipEventElapsedTime(&kms, c->kev0, c->kev1) == hipSuccess) {
+      c->phases[idx].kernel_ms += kms;
+      c->phases[idx].kernel_samples += 1;
+    }
+    c->kev_pending = false;
   }
 };
 

@@ -55,6 +55,7 @@ class MPMWARP(object):
         self.initialize(n_particles, n_elements, n_vertices, n_grid, grid_lim, mesh_vertices, mesh_faces, num_joint_t,
                         num_joint_v, num_joint_f, device=device)
         self.time_profile = {}
+        self.kernel_profile = {}   # bench.py: kernel durations of the fused loop's launches (no reference counterpart)
 
     def initialize(self, n_particles, n_elements, n_vertices, n_grid=100, grid_lim=1.0, mesh_vertices=None,
                    mesh_faces=None, num_joint_t=0, num_joint_v=0, num_joint_f=0, device="cuda:0"):
@@ -373,6 +374,9 @@ class MPMWARP(object):
             self._lib.mpmhip_profile_get(self._ctx, i, C.byref(name), C.byref(ms), C.byref(cnt))
             if cnt.value > 0:  # one entry per bracketed launch (a fused call of n substeps brackets n launches per phase)
                 self.time_profile.setdefault(name.value.decode(), []).extend([ms.value / cnt.value] * cnt.value)
+            self._lib.mpmhip_profile_get_kernel(self._ctx, i, C.byref(ms), C.byref(cnt))
+            if cnt.value > 0:  # (fused=True) the launch's own start -> stop time, without the event bracket's cost
+                self.kernel_profile.setdefault(name.value.decode(), []).extend([ms.value / cnt.value] * cnt.value)
         self._lib.mpmhip_profile_reset(self._ctx)
 
     def print_time_profile(self):
