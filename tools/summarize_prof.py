@@ -8,6 +8,13 @@ profiles/<tag>_pmc.json (per-launch HBM traffic per kernel, read by bench.py's r
 import collections, csv, glob, json, os, re, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+# counter -> bytes factors measured on known byte counts in this code's access pattern (tools/ubench_fetch.hip,
+# profiles/r04_traffic_calibration.json); without the file: the guide's x2 for reads, x1 for writes
+try:
+    _cal = json.load(open("profiles/r04_traffic_calibration.json"))
+    RF, WF = float(_cal["read_factor_soa4"]), float(_cal["write_factor_soa4"])
+except Exception:  # noqa: BLE001
+    RF, WF = 2.0, 1.0
 scenes = sys.argv[2:] or ["sheet-500k"]
 os.makedirs("profiles", exist_ok=True)
 
@@ -35,8 +42,8 @@ for scene in scenes:
     hot = [kname(r["Name"]) for r in rows[:6]]
     if agg:
         out.append("\n# PMC passes (each its own run: rocprofv3 --kernel-trace --pmc <set>), averages per launch\n")
-        out.append("FETCH_SIZE / WRITE_SIZE are KiB as reported; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x "
-                   "(MI355X_MICROARCH.md, HBM section): hbm_read_MB = 2 x FETCH_SIZE.  SQ_* cycle counters are quad-cycles summed over waves.\n")
+        out.append("FETCH_SIZE / WRITE_SIZE are KiB as reported, multiplied with the factors measured on known byte counts in this code's access "
+                   f"pattern (profiles/r04_traffic_calibration.json: reads x {RF:.3f}, writes x {WF:.3f}).  SQ_* cycle counters are quad-cycles summed over waves.\n")
         out.append("| kernel | hbm_read_MB (2x) | hbm_write_MB | L2 hit % | waves | VALU / wave | LDS / wave | VMEM rd+wr / wave | VALU busy % of wave time | wait-any % | LDS bank conflict % |")
         out.append("|---|---|---|---|---|---|---|---|---|---|---|")
         for k, v in agg.items():
@@ -46,13 +53,14 @@ for scene in scenes:
             w = max(a.get("SQ_WAVES", 0), 1)
             wc = max(a.get("SQ_WAVE_CYCLES", 0), 1)
             hit, miss = a.get("TCC_HIT_sum", 0), a.get("TCC_MISS_sum", 0)
-            out.append(f"| {k} | {2*a.get('FETCH_SIZE',0)/1024:.1f} | {a.get('WRITE_SIZE',0)/1024:.1f} | {100*hit/max(hit+miss,1):.0f} | {w:.0f} | "
+            out.append(f"| {k} | {RF*a.get('FETCH_SIZE',0)/1024:.1f} | {WF*a.get('WRITE_SIZE',0)/1024:.1f} | {100*hit/max(hit+miss,1):.0f} | {w:.0f} | "
                        f"{a.get('SQ_INSTS_VALU',0)/w:.0f} | {a.get('SQ_INSTS_LDS',0)/w:.0f} | {(a.get('SQ_INSTS_VMEM_RD',0)+a.get('SQ_INSTS_VMEM_WR',0))/w:.0f} | "
                        f"{100*a.get('SQ_ACTIVE_INST_VALU',0)/wc:.0f} | {100*a.get('SQ_WAIT_ANY',0)/wc:.0f} | {100*a.get('SQ_LDS_BANK_CONFLICT',0)/max(a.get('SQ_ACTIVE_INST_LDS',1),1):.0f} |")
         if scene == "sheet-500k":
             pmc = {k: {c: sum(x) / len(x) for c, x in v.items()} for k, v in agg.items() if "FETCH_SIZE" in v}
             json.dump({"tag": tag, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), sheet-500k fast mode",
-                       "kernels": {k: {"hbm_read_bytes": 2 * a.get("FETCH_SIZE", 0) * 1024, "hbm_write_bytes": a.get("WRITE_SIZE", 0) * 1024,
+                       "kernels": {k: {"hbm_read_bytes": RF * a.get("FETCH_SIZE", 0) * 1024, "hbm_write_bytes": WF * a.get("WRITE_SIZE", 0) * 1024,
+                                       "read_factor": RF, "write_factor": WF,
                                        "launches_sampled": len(agg[k]["FETCH_SIZE"])} for k, a in pmc.items()}},
                       open(f"profiles/{tag}_pmc.json", "w"), indent=1)
     p = f"{src}/bench_fast.json"
