@@ -279,7 +279,9 @@ def _main(out_stream):
                 "p2g": pb["p2g"] + 116 * sc.n_traditional + 28 * n_col + 16 * n_mov,                   # + trad. stress, splats
                 "g2p_v": pb["g2p_v"] + 28 * n_act + 40 * n_col + 16 * n_mov,                            # + grid stage
             }
-            fused_kernel = {"compute_stress_from_F_trial": "k_stress_elem<true>", "p2g": "k_p2g", "g2p_v": "k_g2p", "rebin": "re-sort"}
+            fused_bytes["g2p2g"] = fused_bytes["p2g"] + fused_bytes["g2p_v"]   # (traditional-only scenes: one launch does both)
+            fused_kernel = {"compute_stress_from_F_trial": "k_stress_elem<true>", "p2g": "k_p2g", "g2p_v": "k_g2p", "rebin": "re-sort",
+                            "g2p2g": "k_g2p2g"}
             sv.enable_profiling(True, fused=True)
             sv.time_profile.clear()
             sv.kernel_profile.clear()

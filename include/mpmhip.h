@@ -105,6 +105,8 @@ typedef struct {
   int32_t n_dropped;            /* fast mode: scatter contributions that fell outside the active blocks (cumulative).
                                    Must stay 0: non-zero means particles outran the re-sorts (fixed-interval mode
                                    with an interval too long for their speed) and the results are not valid */
+  int64_t g2p2g_launches;       /* fast mode, scenes of traditional particles only: substep boundaries that ran as ONE launch
+                                   (g2p of substep n + stress and p2g of substep n + 1, csrc/fast.hip k_g2p2g) */
 } mpmhip_stats;
 
 /* ---- lifetime ----------------------------------------------------------------- */

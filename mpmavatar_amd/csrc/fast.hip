@@ -2397,6 +2397,194 @@ void k_g2p_w6(const ChunkRec *recs, int n_chunks, Bufs b, Dims d, float dt, Grid
   g2p_body<true, true, MFLAG>(recs, n_chunks, b, d, dt, g, gp, bcl, tile, (int)blockIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------------
+// G2P2G (round 4): scenes of traditional particles only run ONE launch per substep.  A workgroup finishes substep n for its
+// chunk -- g2p_v (mpm_utils.py:716-786) from the accumulators p2g(n) filled, every node through the grid stage on the way -- and,
+// with the particles still in registers, starts substep n + 1: compute_stress_from_F_trial (:1047-1103) and p2g (:484-557) into
+// ANOTHER accumulator buffer.  Nothing grid-wide lies between g2p(n) and p2g(n + 1) of the same particle; what is grid-wide -- every
+// p2g(n + 1) contribution must be in before any g2p(n + 1) reads -- is the kernel boundary to the next launch.  Cloth cannot do
+// this: an element needs its three vertices' new positions and a vertex its elements' forces, both across chunks.
+// Buffers rotate by three: this launch READS R (scattered by the launch before), scatters into W and clears Z (read by the launch
+// before; nobody touches it now).  Saved per substep: a kernel boundary, the re-load of x / v / C / F_trial in p2g (they are
+// registers), the store of F_trial (only the epilogue's plain g2p writes it: a pull always sees the end of a substep) and one
+// record -> particle-loads chain per workgroup.  The host side (fast_step) keeps the g2p of the last substep PENDING and
+// flushes it with a plain k_g2p whenever anything else looks at the particles (pull, re-sort, statistics, another dt, ...).
+struct GridRead {  // the accumulator buffer g2p reads (GridPtrs g is the write side, as in k_p2g)
+  float *mv, *col, *mov;
+  int *col_flag;
+};
+template <int STEPS, bool FX>
+__device__ __forceinline__ void g2p2g_body(const ChunkRec *recs, int n_chunks, const Bufs &b, const VAdj &va, const Dims &d, float rpic,
+                                           float dt, const GridPtrs &g, const GridRead &rd, const SplatArgs &sa, const TradParams &tp,
+                                           const GridParams &gp, const BCList &bcl, double *tile, int *esc, int &esc_n, float *red) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && g.host_sig) {  // progress + flags of the substep before (see p2g_body)
+    int *prev = g.counters + CNT_PAR0 + 2 * ((g.step_id - 1) & 1);
+    unsigned v = ((unsigned)g.step_id << 2) | (prev[0] != 0 ? 2u : 0u) | (prev[1] != 0 ? 1u : 0u);
+    prev[0] = 0; prev[1] = 0;
+    __hip_atomic_store(g.host_sig + SIG_RING0 + (g.step_id & (SIG_RING_N - 1)), (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(g.host_sig + SIG_PROGRESS, g.step_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if ((int)blockIdx.x >= sa.e0 && (int)blockIdx.x < sa.e0 + sa.n_extra) {  // splats of substep n + 1 (into W)
+    int e = (int)blockIdx.x - sa.e0;
+    if (e < sa.n_fbins) col_splat_wg(tile, sa, e, d, g);
+    else if (e < sa.n_fbins + sa.n_mov_wg) mover_splat_wg(b, sa.js, e - sa.n_fbins, d, g);
+    return;
+  }
+  if ((int)blockIdx.x >= sa.z_first) {  // clearing of Z
+    zero_blocks_wg(sa.z, (int)blockIdx.x - sa.z_first);
+    return;
+  }
+  int w = xcd_slice((int)blockIdx.x - (sa.e0 == 0 ? sa.n_extra : 0), n_chunks);
+  if (w < 0) return;
+  __builtin_amdgcn_s_setprio(3);
+  const ChunkRec cm = recs[w];
+  int blk = cm.blk, chunk = cm.chunk;
+  int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
+  int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
+  int cls = 0, s = 0;
+  bool valid = cm.map(chunk * CHUNK + (int)threadIdx.x, cls, s);
+  valid = valid && cls == 1;  // (the host selects this kernel only for scenes without elements and vertices)
+  const int sx = valid ? s : d.n_e, tx = sx - d.n_e;
+  GridPtrs gr = g;  // the read side: same tables, the other accumulator buffer
+  gr.mv = rd.mv; gr.col = rd.col; gr.mov = rd.mov; gr.col_flag = rd.col_flag;
+  // ---- g2p of substep n: everything that depends on the record alone is loaded now (see g2p_body) ----
+  V3 x = ld3(b.all, A_X, sx);
+  constexpr int NPT = TILE3 / PT;
+  int nbk[NPT], nlk[NPT];
+  float am[NPT], apx[NPT], apy[NPT], apz[NPT];
+#pragma unroll
+  for (int u = 0; u < NPT; ++u) {
+    int t = (int)threadIdx.x + u * PT;
+    int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
+    int gx = ox + ti, gy = oy + tj, gz = oz + tk;
+    bool in = in_grid(gx, gy, gz, d.G);
+    nbk[u] = in ? blk_of(gx, gy, gz, d.NB) : -1;
+    nlk[u] = loc_of(gx, gy, gz);
+    const float *pm = gr.mv + ((size_t)(in ? nbk[u] : blk) * GCH_MV) * 64 + nlk[u];
+    float a0 = pm[0], a1 = pm[64], a2 = pm[128], a3 = pm[192];
+    am[u] = in ? a0 : 0.0f; apx[u] = in ? a1 : 0.0f; apy[u] = in ? a2 : 0.0f; apz[u] = in ? a3 : 0.0f;
+  }
+  unsigned long long col_mask = 0;
+  unsigned bc_mask = 0;
+  {
+    int l = threadIdx.x & 63, fl = 0;
+    if (l < 27 && gp.has_col) {
+      int nx = bx + l / 9 - 1, ny = by + (l / 3) % 3 - 1, nz = bz + l % 3 - 1;
+      if ((unsigned)nx < (unsigned)d.NB && (unsigned)ny < (unsigned)d.NB && (unsigned)nz < (unsigned)d.NB)
+        fl = gr.col_flag[(nx * d.NB + ny) * d.NB + nz];
+    }
+    if (gp.has_col) col_mask = __ballot(fl != 0);
+    for (int k = 0; k < bcl.n; ++k)
+      if (bc_may_touch(bcl.bc[k], ox, oy, oz, ox + 7, oy + 7, oz + 7, d.G, d.dx, gp.time, gp.dt)) bc_mask |= 1u << k;
+  }
+  if (threadIdx.x == 0) esc_n = 0;
+  bool escaped = false;
+  if (valid) {
+    int lx = (int)(x.x * d.inv_dx - 0.5f) - ox, ly = (int)(x.y * d.inv_dx - 0.5f) - oy, lz = (int)(x.z * d.inv_dx - 0.5f) - oz;
+    escaped = (unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u;
+  }
+  float4 *vt = reinterpret_cast<float4 *>(tile);  // velocity tile of the g2p half; the same LDS is the p2g half's tile afterwards
+#pragma unroll
+  for (int u = 0; u < NPT; ++u) {
+    int t = (int)threadIdx.x + u * PT;
+    int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
+    V3 v = v3(0, 0, 0);
+    if (nbk[u] >= 0) {
+      int nc = 0, nm = 0;
+      int nidx = ((((ox + ti) >> 2) - bx + 1) * 3 + (((oy + tj) >> 2) - by + 1)) * 3 + (((oz + tk) >> 2) - bz + 1);
+      bool uc = (col_mask >> nidx) & 1ull;
+      v = node_finish<false>(nbk[u], nlk[u], am[u], apx[u], apy[u], apz[u], d, gr, gp, bcl, nc, nm, uc, bc_mask);
+    }
+    vt[tile_idx(ti, tj, tk)] = make_float4(v.x, v.y, v.z, 0.0f);
+  }
+  __syncthreads();
+  __builtin_amdgcn_s_setprio(0);
+  const bool fit = valid && !escaped;
+  V3 nx = x, nv = v3(0, 0, 0);
+  M3 nC = m3_zero(), Ft = m3_identity();
+  if (__any(fit)) {
+    V3 xg = fit ? x : v3((float)(ox + 2) * d.dx, (float)(oy + 2) * d.dx, (float)(oz + 2) * d.dx);
+    G2PResult r = g2p_gather(vt, ox, oy, oz, xg, d);
+    nv = r.v; nC = r.C;
+    Ft = (m3_identity() + dt * r.F) * ld9(b.tr, T_F, tx);   // g2p_v :780-786
+    float a_min = (1.0f / d.inv_dx) * 2.0f, a_max = d.grid_lim - (1.0f / d.inv_dx) * 2.0f;
+    nx = x + dt * nv;
+    nx = v3(fminf(fmaxf(nx.x, a_min), a_max), fminf(fmaxf(nx.y, a_min), a_max), fminf(fmaxf(nx.z, a_min), a_max));
+    if (fit) {  // (F_trial stays in registers: see the header)
+      st9(b.all, A_C, s, nC);
+      st3(b.all, A_V, s, nv);
+      st3(b.all, A_X, s, nx);
+      int nbx = (int)(nx.x * d.inv_dx - 0.5f) - ox, nby = (int)(nx.y * d.inv_dx - 0.5f) - oy, nbz = (int)(nx.z * d.inv_dx - 0.5f) - oz;
+      if ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u) raise_drift(g.counters, g.step_id);
+    }
+  }
+  // A particle outside its tile margin (rare, and only until the re-sort its drift flag has requested) takes the global-memory
+  // paths of both halves: the plain g2p update here, with everything stored, and p2g_escaped<true> -- which loads it back and runs
+  // the stress update -- below (entry tagged with bit 16).
+  if (__any(escaped)) {
+    V3 xe = x;
+    int se = s;
+    asm volatile("" : "+v"(xe.x), "+v"(xe.y), "+v"(xe.z), "+v"(se));
+    if (escaped) {
+      G2PResult r = g2p_gather_global<true, false>(xe, d, gr, gp, bcl);
+      g2p_write(b, 1, se, xe, v3(0, 0, 0), r, ox, oy, oz, d, dt, g);
+      atomicAdd(g.counters + 0, 1);
+      esc[atomicAdd(&esc_n, 1)] = (int)threadIdx.x | (1 << 16);
+    }
+  }
+  __syncthreads();  // every wavefront is done with the velocity tile (and the escaped lanes' stores are visible in the workgroup)
+  // ---- stress + p2g of substep n + 1, from registers ----
+  for (int t = threadIdx.x; t < (FX ? 2 : 4) * TILE_PAD; t += PT) tile[t] = 0.0;
+  if (fit) {  // early warning of the adaptive re-sort (see p2g_body)
+    float la = g.lookahead * dt;
+    int fx = (int)((nx.x + la * nv.x) * d.inv_dx - 0.5f) - ox, fy = (int)((nx.y + la * nv.y) * d.inv_dx - 0.5f) - oy,
+        fz = (int)((nx.z + la * nv.z) * d.inv_dx - 0.5f) - oz;
+    if ((unsigned)fx > 5u || (unsigned)fy > 5u || (unsigned)fz > 5u) raise_drift(g.counters, g.step_id);
+  }
+  // (what the two halves share goes through an empty asm: otherwise the optimizer hoists and keeps values of the second half
+  // live across the gather of the first -- 227 VGPRs)
+  asm volatile("" : "+v"(nx.x), "+v"(nx.y), "+v"(nx.z), "+v"(nv.x), "+v"(nv.y), "+v"(nv.z), "+v"(s));
+  asm volatile("" : "+v"(nC.a00), "+v"(nC.a01), "+v"(nC.a02), "+v"(nC.a10), "+v"(nC.a11), "+v"(nC.a12), "+v"(nC.a20), "+v"(nC.a21), "+v"(nC.a22));
+  asm volatile("" : "+v"(Ft.a00), "+v"(Ft.a01), "+v"(Ft.a02), "+v"(Ft.a10), "+v"(Ft.a11), "+v"(Ft.a12), "+v"(Ft.a20), "+v"(Ft.a21), "+v"(Ft.a22));
+  const int sp = fit ? s : d.n_e, tp_ = sp - d.n_e;
+  P2GRaw raw;
+  raw.x = nx; raw.v = nv; raw.C = nC; raw.S = Ft;
+  raw.mass = b.all.at(A_MASS, sp); raw.vol = b.nv.at(N_VOL, sp); raw.mu = b.nv.at(N_MU, sp); raw.lam = b.nv.at(N_LAM, sp);
+  raw.ys = b.tr.at(T_YS, tp_);
+#pragma unroll
+  for (int u = 0; u < ADJ_BATCH; ++u) raw.ab.ent[u] = -1;
+  P2GParticle q = p2g_finish<true>(raw, b, va, fit, 1, s, d, rpic, dt, false, tp);
+  FxScale fs{1.0f, 1.0f, 1.0f, 1.0f};
+  if (FX) {
+    float bm, bp;
+    fx_bounds(q, fit, bm, bp);
+    fs = fx_scales(bm, bp, red);  // (barrier inside: also publishes the cleared tile)
+    fx_apply(q, fs);
+  } else {
+    __syncthreads();
+  }
+  p2g_scatter<STEPS, FX>(tile, esc, &esc_n, q, fit, ox, oy, oz, d, g);
+  __syncthreads();
+  if (esc_n > 0) {
+    for (int e = threadIdx.x; e < esc_n; e += PT) {
+      int ec = 0, es = 0, ent = esc[e];
+      if (!cm.map(chunk * CHUNK + (ent & 0xffff), ec, es)) continue;
+      if (ent >> 16) p2g_escaped<true>(b, va, ec, es, d, rpic, dt, g, tp);  // left the margin before this launch: nothing of it ran yet
+      else p2g_escaped<false>(b, va, ec, es, d, rpic, dt, g, tp);          // left it with this launch's move: its stress update ran above
+    }
+  }
+  p2g_flush<false, false, FX>(tile, ox, oy, oz, d, g, fs);
+}
+template <int STEPS, bool FX>
+__global__ __launch_bounds__(PT) void k_g2p2g(const ChunkRec *recs, int n_chunks, Bufs b, VAdj va, Dims d, float rpic, float dt, GridPtrs g,
+                                               GridRead rd, SplatArgs sa, TradParams tp, GridParams gp, BCList bcl) {
+  __shared__ double tile[4 * TILE_PAD];
+  __shared__ int esc[CHUNK];
+  __shared__ int esc_n;
+  __shared__ float red[8];
+  g2p2g_body<STEPS, FX>(recs, n_chunks, b, va, d, rpic, dt, g, rd, sa, tp, gp, bcl, tile, esc, esc_n, red);
+}
+
 // second half of g2p_e (mpm_utils.py:838-857): x, v = mean of the three updated vertices; d1, d2 = edges
 __global__ void k_elem_finalize(Bufs b, const int *face_slot, const SortKey *skeys, int blk_bits, int *counters, Dims d, int step_id) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2776,13 +2964,26 @@ struct FastState {
   bool fuse_grid = true, grid_dirty = false, fuse_trad = true;
   int dirty_col = 0, dirty_mov = 0;
   // accumulator double buffer: g.{mv,col,mov,m_flag,col_flag} point at buffer `par`
-  float *mv2[2] = {nullptr, nullptr}, *col2[2] = {nullptr, nullptr}, *mov2[2] = {nullptr, nullptr};
-  int *mflag2[2] = {nullptr, nullptr}, *cflag2[2] = {nullptr, nullptr};
-  int par = 0;
+  // (three for scenes that can run the fused g2p -> p2g launch, k_g2p2g: read / write / clear)
+  float *mv2[3] = {nullptr, nullptr, nullptr}, *col2[3] = {nullptr, nullptr, nullptr}, *mov2[3] = {nullptr, nullptr, nullptr};
+  int *mflag2[3] = {nullptr, nullptr, nullptr}, *cflag2[3] = {nullptr, nullptr, nullptr};
+  int par = 0, nbuf = 2;
+  // G2P2G: the g2p of the last substep has not been launched yet -- the next substep's launch does it in front of its own p2g
+  // (k_g2p2g), or flush_g2p() does with a plain k_g2p when anything else needs the particles first
+  bool g2p2g = true;           // MPMHIP_G2P2G=0: two launches per substep for traditional-only scenes as before
+  int g2p2g_max_chunks = 512;  // MPMHIP_G2P2G_MAX
+  int64_t n_g2p2g = 0;         // fused launches so far (mpmhip_stats)
+  bool g2p_pending = false;
+  GridParams pend_gp{};
+  BCList pend_bcl{};
+  float pend_dt = 0.0f;
+  int clear_later = -1, cl_col = 0, cl_mov = 0;  // buffer the last fused launch read: cleared by the next one (or by flush_g2p)
   GridParams last_gp{};
   BCList last_bcl{};  // false: ignore the drift flag (tests of the out-of-margin paths)
   std::vector<void *> allocs;
 };
+
+int flush_g2p(mpmhip_ctx *c);  // (defined with the step functions: launches the deferred g2p of a G2P2G sequence)
 
 namespace {
 
@@ -2864,9 +3065,10 @@ int scan_flags_async(mpmhip_ctx *c, const int *flag, int *index, int n, int slot
   return MPMHIP_OK;
 }
 
-// run the stand-alone element finalise if the last substep deferred it
+// run the stand-alone element finalise if the last substep deferred it (and the plain g2p, if that was deferred: G2P2G)
 int flush_elements(mpmhip_ctx *c) {
   FastState *f = c->fast;
+  flush_g2p(c);
   if (f->elem_pending && f->d.n_e)
     hipLaunchKernelGGL(k_elem_finalize, nblk(f->d.n_e), TPB, 0, c->stream, f->buf[f->cur], f->face_slot, f->keys[1],
                        f->blk_bits, f->g.counters, f->d, f->g.step_id);
@@ -3145,6 +3347,8 @@ int fast_init(mpmhip_ctx *c) {
   if (const char *e = getenv("MPMHIP_PREDICTIVE_SORT")) if (atoi(e) == 0) cell_bits = 6;
   if (const char *e = getenv("MPMHIP_SORT")) f->sort_rocprim = std::string(e) == "rocprim";
   if (const char *e = getenv("MPMHIP_P2G_TILE")) f->p2g_fixed = std::string(e) != "f64";
+  if (const char *e = getenv("MPMHIP_G2P2G")) f->g2p2g = atoi(e) != 0;
+  if (const char *e = getenv("MPMHIP_G2P2G_MAX")) f->g2p2g_max_chunks = atoi(e);
   f->key_bits = f->blk_bits_plain + cell_bits + 2 + 2;
   if (f->key_bits > 32) return fail(c, MPMHIP_ERR_INVALID, "grid too large for 32-bit sort keys");
   f->blk_bits = f->blk_bits_plain | (cell_bits << 8);
@@ -3163,7 +3367,8 @@ int fast_init(mpmhip_ctx *c) {
   if ((rc = dalloc(c, &f->adj_cnt, (size_t)d.n_v + 1))) return rc;
   if ((rc = dalloc(c, &f->order, (size_t)d.n_p))) return rc;
   if ((rc = dalloc(c, &f->iota, (size_t)d.n_p))) return rc;
-  for (int i = 0; i < 2; ++i) {
+  f->nbuf = (d.n_e == 0 && d.n_v == 0 && d.n_t > 0) ? 3 : 2;
+  for (int i = 0; i < f->nbuf; ++i) {
     if ((rc = dalloc(c, &f->mv2[i], f->nblocks * GCH_MV * 64))) return rc;
     if ((rc = dalloc(c, &f->mflag2[i], f->nblocks))) return rc;
     if ((rc = dalloc(c, &f->cflag2[i], f->nblocks))) return rc;
@@ -3247,7 +3452,7 @@ int fast_add_collider_storage(mpmhip_ctx *c, MeshCollider &mc) {
   if ((rc = dalloc(c, &f->fiota, (size_t)nf))) return rc;
   if ((rc = dalloc(c, &f->fb_start, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->fb_cnt, f->nblocks))) return rc;
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < f->nbuf; ++i)
     if ((rc = dalloc(c, &f->col2[i], f->nblocks * GCH_COL * 64))) return rc;
   select_buffer(f, f->par);
   mc.weight = f->col2[0];
@@ -3261,7 +3466,7 @@ int fast_add_mover_storage(mpmhip_ctx *c, Mover &mv) {
     return MPMHIP_OK;
   }
   int rc = MPMHIP_OK;
-  for (int i = 0; i < 2 && !rc; ++i) rc = dalloc(c, &f->mov2[i], f->nblocks * GCH_MOV * 64);
+  for (int i = 0; i < f->nbuf && !rc; ++i) rc = dalloc(c, &f->mov2[i], f->nblocks * GCH_MOV * 64);
   select_buffer(f, f->par);
   mv.weight = f->mov2[0];
   return rc;
@@ -3330,6 +3535,44 @@ int fast_pull(mpmhip_ctx *c) {
     }                                                                                           \
   } while (0)
 
+static void grid_stage_params(mpmhip_ctx *c, const StepArgs &a, GridParams &gp, BCList &bcl);
+
+// G2P2G applies to scenes of traditional particles only, in the production loop of one GPU
+static bool g2p2g_ok(const mpmhip_ctx *c) {
+  const FastState *f = c->fast;
+  const Dims &d = f->d;
+  // ... and, as the kernel stands, where one round of workgroups holds the whole scene: hipcc gives the fused kernel 212-227 VGPRs
+  // (two wavefronts per SIMD = 512 workgroup slots; either half alone needs 116-124, profiles/r04_experiments.md), which a scene
+  // of more chunks pays for with more than it saves (block-512k -8 %, garment-120k-iso -11 %; cube-8k +23 %)
+  return f->g2p2g && f->nbuf == 3 && !f->dist && !c->profiling && d.n_e == 0 && d.n_v == 0 && d.n_t > 0 && f->fuse_trad && f->fuse_grid &&
+         !f->g.halo.slot && !f->g2p_mflag && !f->w6 && !(MPMHIP_DEBUG && f->g.dbg) && f->n_chunks <= f->g2p2g_max_chunks;
+}
+// the deferred g2p of the last substep as a launch of its own (anything that reads or re-orders the particles comes here first),
+// and the clearing of the buffer the last fused launch read
+int flush_g2p(mpmhip_ctx *c) {
+  FastState *f = c->fast;
+  if (f->g2p_pending) {
+    const Dims &d = f->d;
+    hipStream_t s = c->stream;
+    Bufs &b = f->buf[f->cur];
+    if (f->n_chunks_g) {
+      ScopedPhase ph(c, "g2p_v");
+      G2P_LAUNCH(true, f->g2p_two_pass, xcd_grid(f->n_chunks_g), PT, 0, s, f->chunks_g, f->n_chunks_g, b, d, f->pend_dt, f->g, f->pend_gp, f->pend_bcl);
+    }
+    f->g2p_pending = false;
+  }
+  if (f->clear_later >= 0) {
+    const int k = f->clear_later;
+    ZeroArgs z{f->alist, f->n_A, 0, f->cl_col, f->cl_mov, f->mv2[k], f->col2[k], f->mov2[k], f->mflag2[k], f->cflag2[k]};
+    if (f->n_A) {
+      z.n_wg = (f->n_A + PT / 64 - 1) / (PT / 64);
+      hipLaunchKernelGGL(k_zero_blocks, (unsigned)z.n_wg, PT, 0, c->stream, z);
+    }
+    f->clear_later = -1;
+  }
+  return MPMHIP_OK;
+}
+
 static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   FastState *f = c->fast;
   const Dims &d = f->d;
@@ -3342,6 +3585,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   }
   const float dt = a.dt;
   // pre-p2g particle operations, mpm_solver.py:260-279 (impulses first, then velocity modifiers)
+  if (f->g2p_pending && (!g2p2g_ok(c) || !c->pre.empty() || dt != f->pend_dt)) flush_g2p(c);
   if (!c->pre.empty() && d.n_p) {
     flush_elements(c);
     float t = (float)c->time;
@@ -3431,13 +3675,28 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   }
   // accumulators left loaded by the previous (fused) substep: this substep scatters into the other buffer and clears
   // the loaded one with extra workgroups of the p2g launch
+  const bool do_g2p2g = f->g2p_pending && !jt_tile;  // (pending survives a re-sort decision above only when none happened)
+  if (f->g2p_pending && !do_g2p2g) flush_g2p(c);
+  GridRead rd{f->g.mv, f->g.col, f->g.mov, f->g.col_flag};  // (fused launch) the buffer the deferred g2p reads: the current one
+  if (do_g2p2g) {
+    // rotate: read R = current, scatter into W = the next, clear Z = what the fused launch before this one read
+    const int R = f->par, Z = f->clear_later;
+    sa.z = ZeroArgs{f->alist, f->n_A, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (Z >= 0 && f->n_A) {
+      sa.z = ZeroArgs{f->alist, f->n_A, (f->n_A + PT / 64 - 1) / (PT / 64), f->cl_col, f->cl_mov, f->mv2[Z], f->col2[Z], f->mov2[Z],
+                      f->mflag2[Z], f->cflag2[Z]};
+    }
+    f->clear_later = R; f->cl_col = f->dirty_col; f->cl_mov = f->dirty_mov;
+    f->grid_dirty = false;
+    select_buffer(f, (R + 1) % 3);
+  } else
   sa.z = take_zero(f);
-  if (sa.z.n_wg) {
+  if (sa.z.n_wg && !do_g2p2g) {
     if (c->profiling) {  // profiling runs keep one launch per reference phase: clear now
       hipLaunchKernelGGL(k_zero_blocks, (unsigned)sa.z.n_wg, PT, 0, s, sa.z);
       sa.z.n_wg = 0;
     } else {
-      select_buffer(f, f->par ^ 1);
+      select_buffer(f, (f->par + 1) % f->nbuf);
     }
   }
   sa.n_extra = (sa.n_fbins + sa.n_mov_wg + 7) & ~7;
@@ -3502,6 +3761,17 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       only.z_first = 1 << 30;
       P2G_LAUNCH(false, false, (unsigned)only.n_extra, PT, 0, s, f->chunks, 0, b, f->va(), d, c->sc.rpic_damping, dt, f->g, only, tp);
     }
+  } else if (do_g2p2g) {
+    ScopedPhase ph(c, "g2p2g");
+    const unsigned grid = xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg);
+    if (f->p2g_fixed)
+      KSTAMP_LAUNCH((k_g2p2g<P2G_STEPS, true>), grid, PT, 0, s, f->chunks, f->n_chunks, b, f->va(), d, c->sc.rpic_damping, dt, f->g, rd, sa, tp,
+                    f->pend_gp, f->pend_bcl);
+    else
+      KSTAMP_LAUNCH((k_g2p2g<3, false>), grid, PT, 0, s, f->chunks, f->n_chunks, b, f->va(), d, c->sc.rpic_damping, dt, f->g, rd, sa, tp,
+                    f->pend_gp, f->pend_bcl);
+    f->g2p_pending = false;
+    f->n_g2p2g += 1;
   } else {
     ScopedPhase ph(c, "p2g");
     if (f->n_chunks || sa.n_extra || sa.z.n_wg || sa.pack.n_wg)
@@ -3544,7 +3814,10 @@ static int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
       hipLaunchKernelGGL(k_grid<true>, xcd_grid((f->n_A + 3) / 4), TPB, 0, s, f->alist, f->n_A, d, f->g, gp, bcl);
   }
   for (auto &bc : c->bcs) bc_host_modify(bc, (float)c->time, dt);
-  {
+  if (fused && g2p2g_ok(c)) {  // G2P2G: the next substep's launch does this g2p in front of its p2g (or flush_g2p does)
+    f->g2p_pending = true;
+    f->pend_gp = gp; f->pend_bcl = bcl; f->pend_dt = dt;
+  } else {
     ScopedPhase ph(c, "g2p_v");
     if (f->n_chunks_g) {
       if (fused)
@@ -4172,7 +4445,9 @@ int fast_debug_counter(mpmhip_ctx *c, int index, int64_t *out) {
 
 int fast_stats(mpmhip_ctx *c, mpmhip_stats *out) {
   FastState *f = c->fast;
+  flush_g2p(c);  // (a pending g2p counts its out-of-margin particles too)
   out->rebins = f->rebins;
+  out->g2p2g_launches = f->n_g2p2g;
   out->n_active_blocks = f->n_A;
   int *dcnt = f->g.counters + 4;
   if (f->grid_dirty) {  // fused substeps do not count collider / mover nodes: count the last substep now
