@@ -588,7 +588,8 @@ static_assert(SIG_RING0 + SIG_RING_N <= SIG_WORDS && (SIG_RING_N & (SIG_RING_N -
 // [CNT_PAR0 + 2 * parity + {0, 1}] the same two flags per substep parity: the kernels of substep s raise slot s & 1 and the
 // p2g launch of substep s + 1 posts and clears it, so a ring entry holds exactly the flags of ONE finished substep (a plain
 // snapshot of the sticky flags raced with the workgroups of the posting launch that raise them)
-enum { CNT_FACE = 5, CNT_DRIFT = 6, CNT_PAR0 = 16, CNT_N = 32 };
+enum { CNT_FACE = 5, CNT_DRIFT = 6, CNT_PAR0 = 16, CNT_MMIN = 24, CNT_MMAX = 25, CNT_N = 32 };  // (MMIN / MMAX: smallest positive / largest
+                                                                                             // particle mass as float bits, k_mass_span)
 
 // Fused halo add (multi-GPU, peer-mapped halos): k_g2p<.., HALO = true> adds the neighbour rank's contribution to a shared
 // block while it stages its tile -- own accumulator + the value the neighbour's pack stored into this rank's arena -- instead
@@ -632,6 +633,16 @@ struct GridParams {
   int n_col_more = 0;
   float col_friction_more[3] = {0.0f, 0.0f, 0.0f};
 };
+
+// smallest positive and largest particle mass of the simulated particles (float bits; positive floats order like ints)
+__global__ void k_mass_span(const float *mass, const int *sel, int n, int *counters) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float m = (i < n && sel[i] == 0) ? mass[i] : 0.0f;
+  int lo = m > 0.0f ? __float_as_int(m) : 0x7f7fffff, hi = m > 0.0f ? __float_as_int(m) : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+  if ((threadIdx.x & 63) == 0) { atomicMin(counters + CNT_MMIN, lo); atomicMax(counters + CNT_MMAX, hi); }
+}
 
 __device__ __forceinline__ void raise_drift(int *counters, int step_id) {
   counters[CNT_DRIFT] = 1;
@@ -2862,6 +2873,8 @@ struct FastState {
   int splat_first_max = 1 << 30;  // more splat workgroups than this go behind the chunk workgroups (MPMHIP_SPLAT_FIRST_MAX; measured
                                   // neutral early and late -- profiles/r03_experiments.md -- so they stay in front)
   bool w6 = false;             // six-wavefront builds of the cloth kernels (k_p2g_w6, k_g2p_w6): MPMHIP_W6
+  bool p2g_fixed_now = true, p2g_fixed_forced = false, mass_span_pending = false;  // the tile in use (decided per import from the mass span)
+  float mass_span = 1.0f;
   bool p2g_fixed = true;       // p2g's chunk tile in packed fixed point (k_p2g<.., FX = true>); MPMHIP_P2G_TILE=f64: the fp64 tile
   bool g2p_mflag = false;      // g2p asks m_flag before it loads a block's accumulators (one more dependent memory level at the head
                                // of every workgroup; the default loads them with the particle positions): MPMHIP_G2P_MFLAG=1
@@ -3083,9 +3096,17 @@ int do_import(mpmhip_ctx *c) {
     if (d.n_p) hipLaunchKernelGGL(k_iota, nblk(d.n_p), TPB, 0, c->stream, f->perm[f->cur], d.n_p);
     f->have_order = true;
   }
-  if (d.n_p)
+  flush_g2p(c);  // (a pending g2p belongs to the state that is about to be replaced; its buffers must be left clean)
+  if (d.n_p) {
     hipLaunchKernelGGL(k_import, nblk(d.n_p), TPB, 0, c->stream, c->st, c->md, f->buf[f->cur], f->perm[f->cur], d,
                        f->dist ? 1 : 0);
+    // mass span of the scene: decides between the fixed-point and the fp64 chunk tile of p2g at the next re-sort (see rebin)
+    MPM_HIP_CHECK(c, hipMemsetD32Async((hipDeviceptr_t)(f->g.counters + CNT_MMIN), 0x7f7fffff, 1, c->stream));
+    MPM_HIP_CHECK(c, hipMemsetD32Async((hipDeviceptr_t)(f->g.counters + CNT_MMAX), 0, 1, c->stream));
+    hipLaunchKernelGGL(k_mass_span, nblk(d.n_p), TPB, 0, c->stream, (const float *)c->st.particle_mass, (const int *)c->st.particle_selection,
+                       d.n_p, f->g.counters);
+    f->mass_span_pending = true;
+  }
   if (d.n_e && d.n_v) {  // cloth topology -> ELL adjacency (original indices); K = max valence
     hipStream_t s = c->stream;
     MPM_HIP_CHECK(c, hipMemsetAsync(f->adj_cnt, 0, ((size_t)d.n_v + 1) * sizeof(int), s));
@@ -3289,7 +3310,20 @@ int rebin(mpmhip_ctx *c) {
     if (with_faces)
       hipLaunchKernelGGL(k_fbin_compact, nblk(cap_A), TPB, 0, s, f->alist, f->rcnt, cap_A, f->fb_start, f->fb_cnt, f->fbins, cap_fb);
     MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 32, f->rcnt, RC_N * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (f->mass_span_pending)
+      MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 44, f->g.counters + CNT_MMIN, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     MPM_HIP_CHECK(c, hipStreamSynchronize(s));  // the one wait of a re-sort
+    if (f->mass_span_pending) {
+      // The fixed-point chunk tile gives every chunk ONE scale, from the sum of its lanes' bounds: a particle whose mass is
+      // below ~1e-5 of its chunk mates' loses its contributions to rounding (measured, tools/gpu/mass_ratio.py: cloth beside
+      // sand 1e+6 times heavier v 1.1e-2 against 8.6e-5 with the fp64 tile; at 1e+4 both 2e-4).  Scenes whose particle masses
+      // span more than 1e+5 therefore run the fp64 tile (MPMHIP_P2G_TILE=fx overrides).
+      float lo, hi;
+      memcpy(&lo, f->h_pin + 44, 4); memcpy(&hi, f->h_pin + 45, 4);
+      f->mass_span = (hi > 0.0f && lo < 3.0e38f) ? hi / lo : 1.0f;
+      f->p2g_fixed_now = f->p2g_fixed && (f->p2g_fixed_forced || f->mass_span <= 1.0e5f);
+      f->mass_span_pending = false;
+    }
     const int *h = f->h_pin + 32;
     if (h[RC_OVER]) {  // grow what was too small and build the tables again (the sorted particles stay as they are)
       f->cap_P = std::max(f->cap_P, std::min(nb, std::max(h[RC_NP], (h[RC_NCH] - d.n_p / CHUNK)) * 2 + 1024));
@@ -3346,7 +3380,8 @@ int fast_init(mpmhip_ctx *c) {
   int cell_bits = f->blk_bits_plain + 8 + 2 + 2 <= 32 ? 8 : 6;  // 8: predictive sort (see make_key)
   if (const char *e = getenv("MPMHIP_PREDICTIVE_SORT")) if (atoi(e) == 0) cell_bits = 6;
   if (const char *e = getenv("MPMHIP_SORT")) f->sort_rocprim = std::string(e) == "rocprim";
-  if (const char *e = getenv("MPMHIP_P2G_TILE")) f->p2g_fixed = std::string(e) != "f64";
+  if (const char *e = getenv("MPMHIP_P2G_TILE")) { f->p2g_fixed = std::string(e) != "f64"; f->p2g_fixed_forced = std::string(e) == "fx"; }
+  f->p2g_fixed_now = f->p2g_fixed;
   if (const char *e = getenv("MPMHIP_G2P2G")) f->g2p2g = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_G2P2G_MAX")) f->g2p2g_max_chunks = atoi(e);
   f->key_bits = f->blk_bits_plain + cell_bits + 2 + 2;
@@ -3506,7 +3541,7 @@ int fast_pull(mpmhip_ctx *c) {
   } while (0)
 #define P2G_LAUNCH(trad, jt, ...)                                                \
   do {                                                                           \
-    if (!f->p2g_fixed) {  /* MPMHIP_P2G_TILE=f64 */                                     \
+    if (!f->p2g_fixed_now) {  /* MPMHIP_P2G_TILE=f64, or particle masses that span more than 1e5 */                                     \
       if ((trad) && (jt)) KSTAMP_LAUNCH((k_p2g<3, true, true, false>), __VA_ARGS__);  \
       else if (trad) KSTAMP_LAUNCH((k_p2g<3, true, false, false>), __VA_ARGS__);      \
       else KSTAMP_LAUNCH((k_p2g<3, false, false, false>), __VA_ARGS__);               \
@@ -3764,7 +3799,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   } else if (do_g2p2g) {
     ScopedPhase ph(c, "g2p2g");
     const unsigned grid = xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg);
-    if (f->p2g_fixed)
+    if (f->p2g_fixed_now)
       KSTAMP_LAUNCH((k_g2p2g<P2G_STEPS, true>), grid, PT, 0, s, f->chunks, f->n_chunks, b, f->va(), d, c->sc.rpic_damping, dt, f->g, rd, sa, tp,
                     f->pend_gp, f->pend_bcl);
     else

@@ -212,7 +212,7 @@ class MPMWARP(object):
     def _push_if_modified(self):
         if not self._read_snaps:
             return
-        dirty = False
+        dirty, dirty_synced = False, False
         for obj in (self._bound_state, self._bound_model):
             snap = self._read_snaps.get(id(obj))
             if not snap:
@@ -222,15 +222,22 @@ class MPMWARP(object):
                     del snap[name]
                 elif t._version != v:
                     dirty = True
+                    dirty_synced = dirty_synced or name in type(obj)._synced
         if dirty:
             if getattr(self, "_stale", False):
-                # The caller wrote in place into a tensor that has NOT seen the substeps run since it was handed out -- a view
-                # (state.particle_x[:n], .view(-1)) kept across substeps: only whole-tensor handles are refreshed after a
-                # substep (_refresh_held counts references to the tensor OBJECT, a view holds the storage).  Importing it would
-                # first write the solver's newer results over that write and lose it silently; the reference's zero-copy
-                # aliases have no such case.  Re-read the field (state.particle_x) before modifying it.
-                raise RuntimeError("in-place write into a stale view of a solver-written field (taken before the last substeps): "
-                                   "read the field again from the state (state.particle_x, ...) and modify that tensor")
+                if dirty_synced:
+                    # The caller wrote in place into a tensor that has NOT seen the substeps run since it was handed out -- a view
+                    # (state.particle_x[:n], .view(-1)) kept across substeps: only whole-tensor handles are refreshed after a
+                    # substep (_refresh_held counts references to the tensor OBJECT, a view holds the storage).  Importing it would
+                    # first write the solver's newer results over that write and lose it silently; the reference's zero-copy
+                    # aliases have no such case.  Re-read the field (state.particle_x) before modifying it.
+                    raise RuntimeError("in-place write into a stale view of a solver-written field (taken before the last substeps): "
+                                       "read the field again from the state (state.particle_x, ...) and modify that tensor")
+                # Only fields the solver never writes were edited (particle_selection, particle_vol, E, gamma, ...): nothing can be
+                # lost.  Bring the solver-written fields of the caller's tensors up to date first -- the pull does not touch the
+                # others -- so that the import below does not put old positions back.
+                self._call("mpmhip_pull_state")
+                self._stale = False
             self._call("mpmhip_push_state")
             for obj in (self._bound_state, self._bound_model):
                 if id(obj) in self._read_snaps:

@@ -373,3 +373,29 @@ def test_write_through_a_view_is_never_lost_silently():
         assert "stale view" in str(e)
         return
     assert rel(sim.state.particle_v.cpu().numpy(), want) < 1e-6
+
+
+def test_in_place_edit_of_a_field_the_solver_never_writes_after_substeps():
+    """`state.particle_selection[idx] = 1` (or particle_vol, model.E, model.gamma ...) after some substeps must simply take
+    effect -- nothing of the solver's can be lost through a field it never writes -- and must not put old positions back."""
+    sc = scenes.small_sheet()
+    sim = harness.build_solver(sc, "cuda:0", mode="fast")
+    sel = sim.state.particle_selection          # handed out before the substeps, held across them
+    gam = sim.model.gamma
+    harness.run(sim, 5, fused=True)
+    x5 = sim.state.particle_x.cpu().numpy().copy()
+    n_e = sc.n_elements
+    sel[n_e + 3] = 1                            # freeze one vertex (in place, no re-read of a solver-written field)
+    gam.mul_(0.5)
+    harness.run(sim, 5, fused=True)             # (round 3: RuntimeError "stale view")
+    x10 = sim.state.particle_x.cpu().numpy()
+    assert np.isfinite(x10).all()
+    assert np.abs(x10[n_e + 3] - x5[n_e + 3]).max() == 0.0      # the frozen vertex stayed where it was after substep 5
+    moved = np.abs(x10 - x5).max(1)
+    assert (moved > 0).sum() > 0.9 * len(moved)                 # ... and everything else went on from substep 5, not from 0
+    ref = harness.build_solver(sc, "cuda:0", mode="fast")
+    harness.run(ref, 5, fused=True)
+    ref.state.particle_selection[n_e + 3] = 1                   # the same edits through freshly read fields
+    ref.model.gamma.mul_(0.5)
+    harness.run(ref, 5, fused=True)
+    assert rel(x10, ref.state.particle_x.cpu().numpy()) < 1e-6
