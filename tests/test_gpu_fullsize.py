@@ -86,16 +86,16 @@ def _check(rows, what):
     for cp, dx, ppx, dv, ds, dvq, dsq, vmax, dxs in rows:
         assert dx < 1e-4 and ppx < 1e-4, f"{what} substep {cp}: x {dx:.2e} (per particle {ppx:.2e})"
         # v: 1e-4 of the top speed (north star), or -- where the oracle itself does not hold that against a change of its
-        # summation order -- 3 x its own distance from itself (max over the checkpoints: both are maxima over 1e5 particles)
-        bound = max(1e-4 * max(vmax, 1e-3), 3.0 * env_max)
+        # summation order -- 1.5 x its own distance from itself (round 4: was 3 x; the measured ratio is 0.5 ... 1.0) (max over the checkpoints: both are maxima over 1e5 particles)
+        bound = max(1e-4 * max(vmax, 1e-3), 1.5 * env_max)
         assert dv < bound, f"{what} substep {cp}: |dv| {dv:.2e} m/s, oracle vs itself {ds:.2e} (bound {bound:.2e})"
-        assert dvq < max(1e-4 * max(vmax, 1e-3), 3.0 * env_p999), f"{what} substep {cp}: 99.9 % of |dv| within {dvq:.2e}, oracle {dsq:.2e}"
+        assert dvq < max(1e-4 * max(vmax, 1e-3), 1.5 * env_p999), f"{what} substep {cp}: 99.9 % of |dv| within {dvq:.2e}, oracle {dsq:.2e}"
 
 
 def test_s3_one_frame_of_the_reference_cadence_400_substeps(oracle_lib):
     """One frame as the reference's drivers run it -- 400 substeps, the body advected by mesh_x + k dt mesh_v inside the library
     (train_material_params.py:616-626) -- on the full-size garment with collider, mover and swaying body, in four fused calls of
-    100, against the OpenMP oracle at every call's end.  x within 1e-4 (also per particle).  v within 3 x the oracle's distance
+    100, against the OpenMP oracle at every call's end.  x within 1e-4 (also per particle).  v within 1.5 x the oracle's distance
     from ITSELF under another summation order (measured here: the cloth QR of the HIP path is the oracle's bit for bit, what is
     left is the rounding of the transfers, and the oracle moves by as much when only the order of its atomic adds changes:
     3.6e-3 of the top speed at substep 100, profiles/r03_full_parity_garment-120k-aniso.json)."""
