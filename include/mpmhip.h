@@ -286,6 +286,20 @@ int mpmhip_bind_gaussians(int32_t device, void *stream, int32_t n_gaussians, con
                           const float *face_orien_mat, const float *face_orien_quat, const float *face_scaling, float *xyz,
                           float *rotation, float *scaling);
 
+/* The rasteriser's inputs, SURVEY.md 8(f) N4: what gaussian_renderer/__init__.py:52-103 hands to GaussianRasterizer for a mesh-bound
+ * model plus the caller's `extra` primitives (run_demo.py:578-604: sand and chair), assembled in one launch into buffers of
+ * n_gaussians + n_extra rows: means3D [*3] = get_xyz (scene/gaussian_model.py:141-151) | extra_xyz; means2D [*3] = 0 (:27);
+ * opacities [*1] = sigmoid(opacity_raw) (:158-160) | extra_opacity; scales [*3] = get_scaling (:112-122) | extra_scales;
+ * rotations [*4] WXYZ = get_rotation (:124-138) | extra_rotations -- the five torch.cat of :84-91.  Colours (shs or
+ * colors_precomp) are the caller's tensors unchanged.  With frames taken from the solver's particle_x on the device this replaces
+ * the per-frame OBJ write / re-read of train_material_params.py:819-845 for everything but the Blender AO bake. */
+int mpmhip_render_inputs(int32_t device, void *stream, int32_t n_gaussians, int32_t n_extra, const int32_t *binding,
+                         const float *xyz_local, const float *rotation_raw, const float *scaling_raw, const float *opacity_raw,
+                         const float *face_center, const float *face_orien_mat, const float *face_orien_quat,
+                         const float *face_scaling, const float *extra_xyz, const float *extra_opacity, const float *extra_scales,
+                         const float *extra_rotations, float *means3D, float *means2D, float *opacities, float *scales,
+                         float *rotations);
+
 /* MPMWARP.export_particle_cov_to_torch (warp_mpm/mpm_solver.py:543-561) = kernel compute_cov_from_F
  * (warp_mpm/mpm_utils.py:1108-1132): new_cov[6p..] = upper triangle (xx xy xz yy yz zz) of F_trial[p] * sym(particle_cov[6p..])
  * * F_trial[p]^T for p < n (= n_particles - n_vertices).  Stand-alone map on [dev] arrays in the reference's AoS layout. */

@@ -91,6 +91,7 @@ SIGNATURES = {
     "mpmhip_cov_from_F": (C.c_int, [C.c_int32, vp, vp, vp, C.c_int32, vp]),
     "mpmhip_face_frames": (C.c_int, [C.c_int32, vp, vp, vp, C.c_int32, vp, vp, vp, vp]),
     "mpmhip_bind_gaussians": (C.c_int, [C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "mpmhip_render_inputs": (C.c_int, [C.c_int32, vp, C.c_int32, C.c_int32] + [vp] * 18),
     "mpmhip_dist_enable": (C.c_int, [vp]),
     "mpmhip_dist_set_ghost_mode": (C.c_int, [vp, C.c_int32]),
     "mpmhip_dist_ghost_pack": (C.c_int, [vp]),

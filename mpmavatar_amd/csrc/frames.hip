@@ -110,6 +110,46 @@ __global__ void k_bind_gaussians(int n_g, const int32_t *binding, const float *x
     for (int k = 0; k < 3; ++k) scaling[3 * (size_t)g + k] = expf(scaling_raw[3 * (size_t)g + k]) * s;
 }
 
+// The argument lists of the rasteriser call (gaussian_renderer/__init__.py:52-103), assembled in ONE launch: rows [0, n_g) are the
+// mesh-bound Gaussians -- means3D = get_xyz, rotations = get_rotation, scales = get_scaling (as k_bind_gaussians), opacities =
+// sigmoid(_opacity) (gaussian_model.py:39,158-160) -- rows [n_g, n_g + n_x) the caller's `extra` primitives copied behind them
+// (:84-91: the five torch.cat of the render call); means2D (zeros, :27) is cleared here too.
+__global__ void k_render_inputs(int n_g, int n_x, const int32_t *binding, const float *xyz_local, const float *rot_raw,
+                                const float *scaling_raw, const float *opacity_raw, const float *center, const float *mat,
+                                const float *quat, const float *fscale, const float *x_xyz, const float *x_opacity,
+                                const float *x_scales, const float *x_rot, float *means3D, float *means2D, float *opacities,
+                                float *scales, float *rotations) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_g + n_x) return;
+  for (int k = 0; k < 3; ++k) means2D[3 * (size_t)g + k] = 0.0f;
+  if (g >= n_g) {
+    int e = g - n_g;
+    for (int k = 0; k < 3; ++k) { means3D[3 * (size_t)g + k] = x_xyz[3 * (size_t)e + k]; scales[3 * (size_t)g + k] = x_scales[3 * (size_t)e + k]; }
+    for (int k = 0; k < 4; ++k) rotations[4 * (size_t)g + k] = x_rot[4 * (size_t)e + k];
+    opacities[g] = x_opacity[e];
+    return;
+  }
+  int f = binding[g];
+  float s = fscale[f];
+  const float *m = mat + 9 * (size_t)f;
+  F3 p = ld3(xyz_local, g), c = ld3(center, f);
+  means3D[3 * (size_t)g] = (m[0] * p.x + m[1] * p.y + m[2] * p.z) * s + c.x;
+  means3D[3 * (size_t)g + 1] = (m[3] * p.x + m[4] * p.y + m[5] * p.z) * s + c.y;
+  means3D[3 * (size_t)g + 2] = (m[6] * p.x + m[7] * p.y + m[8] * p.z) * s + c.z;
+  float a[4], b[4];
+  for (int k = 0; k < 4; ++k) { a[k] = quat[4 * (size_t)f + k]; b[k] = rot_raw[4 * (size_t)g + k]; }
+  normalize4(a);
+  normalize4(b);
+  float pw = a[0], px = a[1], py = a[2], pz = a[3], qw = b[0], qx = b[1], qy = b[2], qz = b[3];
+  float *o = rotations + 4 * (size_t)g;
+  o[0] = pw * qw - px * qx - py * qy - pz * qz;
+  o[1] = pw * qx + px * qw + py * qz - pz * qy;
+  o[2] = pw * qy - px * qz + py * qw + pz * qx;
+  o[3] = pw * qz + px * qy - py * qx + pz * qw;
+  for (int k = 0; k < 3; ++k) scales[3 * (size_t)g + k] = expf(scaling_raw[3 * (size_t)g + k]) * s;
+  opacities[g] = 1.0f / (1.0f + expf(-opacity_raw[g]));  // torch.sigmoid
+}
+
 // compute_cov_from_F (/root/reference/warp_mpm/mpm_utils.py:1108-1132): cov = F_trial * sym(cov0) * F_trial^T per
 // particle, upper triangle out (xx, xy, xz, yy, yz, zz).  Products summed left to right as Warp's mat33 product does.
 __global__ void k_cov_from_F(const float *F_trial, const float *cov0, int n, float *out) {
@@ -177,6 +217,29 @@ int mpmhip_bind_gaussians(int32_t device, void *stream, int32_t n_gaussians, con
   hipLaunchKernelGGL(k_bind_gaussians, (unsigned)((n_gaussians + TPB - 1) / TPB), TPB, 0, (hipStream_t)stream, n_gaussians,
                      binding, xyz_local, rotation_raw, scaling_raw, face_center, face_orien_mat, face_orien_quat,
                      face_scaling, xyz, rotation, scaling);
+  return check(hipGetLastError());
+}
+
+int mpmhip_render_inputs(int32_t device, void *stream, int32_t n_gaussians, int32_t n_extra, const int32_t *binding,
+                         const float *xyz_local, const float *rotation_raw, const float *scaling_raw, const float *opacity_raw,
+                         const float *face_center, const float *face_orien_mat, const float *face_orien_quat,
+                         const float *face_scaling, const float *extra_xyz, const float *extra_opacity, const float *extra_scales,
+                         const float *extra_rotations, float *means3D, float *means2D, float *opacities, float *scales,
+                         float *rotations) {
+  if (n_gaussians < 0 || n_extra < 0) return MPMHIP_ERR_INVALID;
+  if (n_gaussians + n_extra > 0 && (!means3D || !means2D || !opacities || !scales || !rotations)) return MPMHIP_ERR_INVALID;
+  if (n_gaussians > 0 && (!binding || !xyz_local || !rotation_raw || !scaling_raw || !opacity_raw || !face_center || !face_orien_mat ||
+                          !face_orien_quat || !face_scaling))
+    return MPMHIP_ERR_INVALID;
+  if (n_extra > 0 && (!extra_xyz || !extra_opacity || !extra_scales || !extra_rotations)) return MPMHIP_ERR_INVALID;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0 || device < 0 || device >= n_dev) return MPMHIP_ERR_NO_DEVICE;
+  if (n_gaussians + n_extra == 0) return MPMHIP_OK;
+  if (int rc = check(hipSetDevice(device))) return rc;
+  hipLaunchKernelGGL(k_render_inputs, (unsigned)((n_gaussians + n_extra + TPB - 1) / TPB), TPB, 0, (hipStream_t)stream, n_gaussians,
+                     n_extra, binding, xyz_local, rotation_raw, scaling_raw, opacity_raw, face_center, face_orien_mat, face_orien_quat,
+                     face_scaling, extra_xyz, extra_opacity, extra_scales, extra_rotations, means3D, means2D, opacities, scales,
+                     rotations);
   return check(hipGetLastError());
 }
 

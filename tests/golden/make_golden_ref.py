@@ -474,7 +474,45 @@ FIXTURES = {
 }
 
 
+def make_alt3(name, sc, checkpoints, extra=None):
+    """Round 4: the same sequence a THIRD time, with svd3 / qr3 evaluated by the published algorithm behind
+    Warp's builtins -- McAdams et al.'s fp32 Jacobi SVD with approximate Givens quaternions and the Givens-quaternion QR
+    (warp_standin: SVD_MODE "mcadams", QR_MODE "givens") -- stored in its own small file <name>_alt3.npz as alt3_s<k>_*.
+    tests/test_ref_golden.py reports its distance from the primary run beside the other two envelopes and takes it into the
+    bound (refgolden.seq_bound)."""
+    wp.SVD_MODE, wp.QR_MODE = "mcadams", "givens"
+    payload = {}
+    sim = build_reference(sc)
+    if extra:
+        apply_extra(sim, extra)
+    t0 = time.time()
+    for cp in checkpoints:
+        run_reference(sim, cp - sim.steps_done)
+        st = full_state(sim)
+        for f in ("particle_x", "particle_v", "particle_d"):
+            payload[f"alt3_s{cp}_{f}"] = st[f]
+        print(f"   {name} (alt3: mcadams / givens): substep {cp} after {time.time() - t0:.0f} s", flush=True)
+    wp.SVD_MODE, wp.QR_MODE = "lapack", "householder"
+    payload["checkpoints"] = np.array(checkpoints)
+    save(name + "_alt3", payload)
+
+
+ALT3 = {
+    "ref_seq_cube_jelly": lambda: make_alt3("ref_seq_cube_jelly", _seq_cube("jelly"), [1, 10, 50, 100]),
+    "ref_seq_cube_sand": lambda: make_alt3("ref_seq_cube_sand", _seq_cube("sand"), [1, 10, 50, 100]),
+    "ref_seq_cube_metal": lambda: make_alt3("ref_seq_cube_metal", _seq_cube("metal"), [1, 10, 50, 100]),
+    "ref_seq_sheet": lambda: make_alt3("ref_seq_sheet", _small_sheet(), [1, 5, 20, 40, 80]),
+    "ref_seq_garment": lambda: make_alt3("ref_seq_garment", _small_garment(), [1, 5, 20, 40, 80]),
+    "ref_seq_sheet_gamma0": lambda: make_alt3("ref_seq_sheet_gamma0", _small_sheet(gamma=0.0), [1, 10, 50, 100, 200]),
+}
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--alt3":
+        for n in sys.argv[2:] or list(ALT3):
+            print(f"== {n} (alt3)", flush=True)
+            ALT3[n]()
+        sys.exit(0)
     names = sys.argv[1:] or list(FIXTURES)
     for n in names:
         print(f"== {n}", flush=True)

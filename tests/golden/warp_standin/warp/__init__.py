@@ -36,8 +36,8 @@ import numpy as np
 f32 = np.float32
 _I32 = np.int32
 
-SVD_MODE = "lapack"   # or "rot", "rot32"
-QR_MODE = "householder"  # or "gs", "gs32"
+SVD_MODE = "lapack"   # or "rot", "rot32", "mcadams" (the published fp32 algorithm behind wp.svd3)
+QR_MODE = "householder"  # or "gs", "gs32", "givens" (Givens quaternions, as behind wp.qr3)
 
 config = _pytypes.SimpleNamespace(mode="release", verify_cuda=False)
 
@@ -760,8 +760,123 @@ def _svd_rot32(A):
     return U, s, V
 
 
+# -- the PUBLISHED algorithm behind wp.svd3 / wp.qr3 (round 4) --------------------------------------------------------------
+# A. McAdams, A. Selle, R. Tamstorf, J. Teran, E. Sifakis, "Computing the Singular Value Decomposition of 3x3 matrices with
+# minimal branching and elementary floating point operations", UW-Madison TR1690 (2011): Jacobi eigenanalysis of A^T A with
+# approximate Givens quaternions (4 sweeps of 3 conjugations), singular values sorted by column norm with sign-carrying swaps,
+# then a QR of A V by three Givens quaternions (U = Q, sigma = diag(R)).  Warp's native svd3 / qr3 follow this scheme (its
+# sources are out of tree: this is the paper's algorithm restated in fp32 NumPy scalars, one rounding per operation -- not
+# Warp's code, and Q is accumulated by applying the three rotations instead of the closed form).
+_MC_GAMMA, _MC_CSTAR, _MC_SSTAR, _MC_EPS = f32(5.828427124), f32(0.923879532), f32(0.3826834323), f32(1e-6)
+
+
+def _mc_rsqrt(x):
+    return f32(1.0) / np.sqrt(f32(x))
+
+
+def _mc_approx_givens(a11, a12, a22):
+    ch, sh = f32(2.0) * (a11 - a22), a12
+    b = _MC_GAMMA * sh * sh < ch * ch
+    w = _mc_rsqrt(ch * ch + sh * sh) if (ch * ch + sh * sh) > 0 else f32(0.0)
+    return (w * ch, w * sh) if b else (_MC_CSTAR, _MC_SSTAR)
+
+
+def _mc_jacobi(S):
+    """S symmetric 3x3 (fp32) -> unit quaternion (x, y, z, w) of V with V^T S V ~ diagonal."""
+    s11, s21, s22, s31, s32, s33 = S[0, 0], S[1, 0], S[1, 1], S[2, 0], S[2, 1], S[2, 2]
+    q = [f32(0.0), f32(0.0), f32(0.0), f32(1.0)]
+    for _ in range(4):
+        for (x, y, z) in ((0, 1, 2), (1, 2, 0), (2, 0, 1)):
+            ch, sh = _mc_approx_givens(s11, s21, s22)
+            scale = ch * ch + sh * sh
+            a, b = (ch * ch - sh * sh) / scale, (f32(2.0) * sh * ch) / scale
+            t11 = a * (a * s11 + b * s21) + b * (a * s21 + b * s22)
+            t21 = a * (-b * s11 + a * s21) + b * (-b * s21 + a * s22)
+            t22 = -b * (-b * s11 + a * s21) + a * (-b * s21 + a * s22)
+            t31 = a * s31 + b * s32
+            t32 = -b * s31 + a * s32
+            t33 = s33
+            tmp = [q[0] * sh, q[1] * sh, q[2] * sh]
+            sh = sh * q[3]
+            q = [q[0] * ch, q[1] * ch, q[2] * ch, q[3] * ch]
+            q[z] = q[z] + sh
+            q[3] = q[3] - tmp[z]
+            q[x] = q[x] + tmp[y]
+            q[y] = q[y] - tmp[x]
+            s11, s21, s22, s31, s32, s33 = t22, t32, t33, t21, t31, t11   # re-arranged for the next pair
+    n = _mc_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])
+    return [c * n for c in q]
+
+
+def _mc_quat_to_mat(q):
+    x, y, z, w = q
+    two = f32(2.0)
+    return np.array([[f32(1) - two * (y * y + z * z), two * (x * y - w * z), two * (x * z + w * y)],
+                     [two * (x * y + w * z), f32(1) - two * (x * x + z * z), two * (y * z - w * x)],
+                     [two * (x * z - w * y), two * (y * z + w * x), f32(1) - two * (x * x + y * y)]], f32)
+
+
+def _mc_qr_givens_quat(a1, a2):
+    rho = np.sqrt(a1 * a1 + a2 * a2)
+    sh = a2 if rho > _MC_EPS else f32(0.0)
+    ch = np.abs(a1) + max(rho, _MC_EPS)
+    if a1 < 0:
+        sh, ch = ch, sh
+    w = _mc_rsqrt(ch * ch + sh * sh)
+    return ch * w, sh * w
+
+
+def _mc_rot(i, j, ch, sh):
+    """Rotation matrix of the Givens quaternion (ch, sh about the axis perpendicular to the (i, j) plane)."""
+    a, b = f32(1.0) - f32(2.0) * sh * sh, f32(2.0) * ch * sh
+    G = np.eye(3, dtype=f32)
+    G[i, i], G[i, j], G[j, i], G[j, j] = a, -b, b, a
+    return G
+
+
+def _mm32(A, B):
+    C = np.zeros((3, 3), f32)
+    for i in range(3):
+        for j in range(3):
+            C[i, j] = A[i, 0] * B[0, j] + A[i, 1] * B[1, j] + A[i, 2] * B[2, j]
+    return C
+
+
+def _qr_givens(A):
+    """A = Q R, Q a proper rotation built from three Givens quaternions zeroing (2,1), (3,1), (3,2) in that order."""
+    R = A.astype(f32).copy()
+    Q = np.eye(3, dtype=f32)
+    for (i, j) in ((0, 1), (0, 2), (1, 2)):
+        ch, sh = _mc_qr_givens_quat(R[i, i], R[j, i])
+        G = _mc_rot(i, j, ch, sh)
+        R = _mm32(G.T.copy(), R)
+        Q = _mm32(Q, G)
+    return Q, R
+
+
+def _svd_mcadams(A):
+    A = A.astype(f32)
+    V = _mc_quat_to_mat(_mc_jacobi(_mm32(A.T.copy(), A)))
+    B = _mm32(A, V)
+    rho = [B[0, k] * B[0, k] + B[1, k] * B[1, k] + B[2, k] * B[2, k] for k in range(3)]
+
+    def neg_swap(c, k, l):
+        if c:
+            for M in (B, V):
+                t = -M[:, k].copy()
+                M[:, k] = M[:, l]
+                M[:, l] = t
+            rho[k], rho[l] = rho[l], rho[k]
+    neg_swap(rho[0] < rho[1], 0, 1)
+    neg_swap(rho[0] < rho[2], 0, 2)
+    neg_swap(rho[1] < rho[2], 1, 2)
+    U, R = _qr_givens(B)
+    return U, np.array([R[0, 0], R[1, 1], R[2, 2]], f32), V
+
+
+
 def svd3(A, U, sigma, V):
-    u, s, v = {"rot": _svd_rot, "rot32": _svd_rot32}.get(SVD_MODE, _svd_lapack)(A.a)
+    u, s, v = {"rot": _svd_rot, "rot32": _svd_rot32, "mcadams": _svd_mcadams}.get(SVD_MODE, _svd_lapack)(A.a)
     U._assign(u.astype(f32))
     sigma._assign(s.astype(f32))
     V._assign(v.astype(f32))
@@ -799,7 +914,7 @@ def _qr_gs32(A):
 
 
 def qr3(A, Q, R):
-    q, r = {"gs": _qr_gs, "gs32": _qr_gs32}.get(QR_MODE, _qr_householder)(A.a)
+    q, r = {"gs": _qr_gs, "gs32": _qr_gs32, "givens": _qr_givens}.get(QR_MODE, _qr_householder)(A.a)
     Q._assign(q.astype(f32))
     R._assign(np.triu(r).astype(f32))
 
