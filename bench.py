@@ -156,6 +156,7 @@ def _main(out_stream):
     ap.add_argument("--weak", action="store_true", help="N > 1: time ONLY the weak-scaling workload (N stacked copies of the headline "
                     "sheet, one sheet's worth of particles per rank) instead of the strong-scaling headline")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the additional weak-scaling measurement")
+    ap.add_argument("--no-shard-floor", action="store_true", help="N > 1: skip the per-rank compute-floor measurement")
     ap.add_argument("--weak-n", type=int, default=0, help="diagnostics / tests: vertices per side of the stacked sheets of the "
                     "weak-scaling workload (default: the headline sheet's 408) -- also runs it beside scenes other than sheet-500k")
     ap.add_argument("--weak-grid", type=int, default=256)
@@ -396,6 +397,26 @@ def _main(out_stream):
                            "channels_per_node": ch, "peers_of_rank0": len(box["ss"].static) - 1,
                            "halo_exchange_us": next((k["ms"] * 1e3 for k in kernels if k["phase"] == "halo_exchange"), None),
                            "re_partitions": box["ss"].migrations}
+    if sharded and world > 1 and not args.no_shard_floor:
+        # What this N can reach at best: rank 0 runs ITS shard (owned particles + ghost copies) as an ordinary single-GPU scene, no
+        # exchange at all -- the per-rank compute floor of the slab decomposition (three latency-floored launches per substep).
+        # The first run on a real node is then self-explaining: measured value vs this bound = what the halo exchange costs.
+        try:
+            if rank == 0:
+                fsim = harness.build_solver(box["ss"].shard.scene, dev, mode="fast")
+                harness.run(fsim, max(args.warmup, 20), fused=True)
+                torch.cuda.synchronize()
+                tf = time.perf_counter()
+                harness.run(fsim, max(args.steps, 100), fused=True)
+                torch.cuda.synchronize()
+                us = 1e6 * (time.perf_counter() - tf) / max(args.steps, 100)
+                out["shard_floor"] = {"us_per_substep_rank0_alone": us, "substeps_per_s_upper_bound": 1e6 / us,
+                                      "local_particles": int(box["ss"].shard.scene.n_particles), "measured_fraction_of_bound": out["value"] * us / 1e6,
+                                      "note": "rank 0's shard as a single-GPU scene without any exchange; the sharded run cannot beat it"}
+                del fsim
+            barrier()
+        except Exception as e:  # noqa: BLE001 - the headline line must come out whatever happens here
+            out["shard_floor"] = {"error": f"{type(e).__name__}: {e}"}
     if sharded and world > 1 and not weak_only and not args.no_weak and (args.scene == "sheet-500k" or args.weak_n):
         # the regime the slab decomposition is made for: the same per-rank work at every N (one sheet's worth of particles per
         # rank: N stacked copies of the headline sheet in the same grid).  Reported beside the strong-scaling headline value.

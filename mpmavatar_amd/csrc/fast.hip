@@ -21,6 +21,7 @@
 // Reference semantics: /root/reference/warp_mpm/mpm_utils.py, mpm_solver.py:229-536 (cited per kernel).
 #include <hip/hip_ext.h>
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <string.h>
 #include <cstdlib>
@@ -4155,7 +4156,7 @@ static int rccl_link_setup(mpmhip_ctx *c) {
     memset(&mine[i], 0, sizeof(hipIpcMemHandle_t));
     if (!p.n_blocks) continue;
     if ((rc = dalloc(c, &p.link_cnt, 1))) return rc;
-    if ((rc = dalloc(c, &p.hbuf, 128))) return rc;
+    if ((rc = dalloc(c, &p.hbuf, 256))) return rc;  // [0, 96): my IPC handle + PCI bus id, [128, 224): the peer's
     p.link_cap = std::max(4 * p.n_blocks, 1024);
     size_t bytes = ((size_t)LINK_DATA0 + 2 * (size_t)p.link_cap * 8 * 64) * sizeof(float);
     if (hipExtMallocWithFlags((void **)&p.link_local, bytes, hipDeviceMallocFinegrained) != hipSuccess) { p.link_local = nullptr; bad = 1; continue; }
@@ -4165,28 +4166,63 @@ static int rccl_link_setup(mpmhip_ctx *c) {
     }
   }
   (void)hipGetLastError();
-  for (size_t i = 0; i < f->rpeers.size(); ++i)
-    if (f->rpeers[i].n_blocks) MPM_HIP_CHECK(c, hipMemcpyAsync(f->rpeers[i].hbuf, &mine[i], 64, hipMemcpyHostToDevice, s));
+  // ... and with the handle this rank's PCI bus id: the receiver asks hipDeviceCanAccessPeer before it maps the arena
+  char my_bus[32] = {0};
+  int my_dev = 0;
+  (void)hipGetDevice(&my_dev);
+  if (hipDeviceGetPCIBusId(my_bus, (int)sizeof my_bus, my_dev) != hipSuccess) my_bus[0] = 0;
+  (void)hipGetLastError();
+  std::vector<std::array<char, 96>> msg_out(f->rpeers.size()), msg_in(f->rpeers.size());
+  for (size_t i = 0; i < f->rpeers.size(); ++i) {
+    memcpy(msg_out[i].data(), &mine[i], 64);
+    memcpy(msg_out[i].data() + 64, my_bus, 32);
+    if (f->rpeers[i].n_blocks) MPM_HIP_CHECK(c, hipMemcpyAsync(f->rpeers[i].hbuf, msg_out[i].data(), 96, hipMemcpyHostToDevice, s));
+  }
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handle size");
   MPM_NCCL_CHECK(c, r, r.GroupStart());
   for (auto &p : f->rpeers) {
     if (!p.n_blocks) continue;
-    MPM_NCCL_CHECK(c, r, r.Send(p.hbuf, 64, ncclUint8, p.rank, r.comm, s));
-    MPM_NCCL_CHECK(c, r, r.Recv(p.hbuf + 64, 64, ncclUint8, p.rank, r.comm, s));
+    MPM_NCCL_CHECK(c, r, r.Send(p.hbuf, 96, ncclUint8, p.rank, r.comm, s));
+    MPM_NCCL_CHECK(c, r, r.Recv(p.hbuf + 128, 96, ncclUint8, p.rank, r.comm, s));
   }
   MPM_NCCL_CHECK(c, r, r.GroupEnd());
   for (size_t i = 0; i < f->rpeers.size(); ++i)
-    if (f->rpeers[i].n_blocks) MPM_HIP_CHECK(c, hipMemcpyAsync(&theirs[i], f->rpeers[i].hbuf + 64, 64, hipMemcpyDeviceToHost, s));
+    if (f->rpeers[i].n_blocks) MPM_HIP_CHECK(c, hipMemcpyAsync(msg_in[i].data(), f->rpeers[i].hbuf + 128, 96, hipMemcpyDeviceToHost, s));
   MPM_HIP_CHECK(c, hipStreamSynchronize(s));
+  const bool verbose = getenv("MPMHIP_VERBOSE") != nullptr;
   for (size_t i = 0; i < f->rpeers.size(); ++i) {
     RcclPeer &p = f->rpeers[i];
     if (!p.n_blocks) continue;
     static const hipIpcMemHandle_t none{};
-    if (!memcmp(&theirs[i], &none, 64) ||
-        hipIpcOpenMemHandle((void **)&p.link_remote, theirs[i], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+    memcpy(&theirs[i], msg_in[i].data(), 64);
+    char peer_bus[33] = {0};
+    memcpy(peer_bus, msg_in[i].data() + 64, 32);
+    // Can this GPU reach the peer's memory at all?  Asked BEFORE the arena is mapped (round 4): a pair without peer access (another
+    // PCIe root without xGMI, an IOMMU setting) is refused here with a reason, instead of failing inside hipIpcOpenMemHandle or --
+    // worse -- passing it and faulting in the first substep.  The same GPU (ranks sharing a device in tests) needs no peer access; a
+    // peer device this process cannot see (masked by HIP_VISIBLE_DEVICES) cannot be asked, and the mapping is attempted.
+    int peer_dev = -1, can = 1;
+    const char *why = "same device";
+    if (peer_bus[0] && hipDeviceGetByPCIBusId(&peer_dev, peer_bus) == hipSuccess) {
+      if (peer_dev != my_dev) {
+        if (hipDeviceCanAccessPeer(&can, my_dev, peer_dev) != hipSuccess) can = 0;
+        why = can ? "hipDeviceCanAccessPeer: yes" : "hipDeviceCanAccessPeer: NO";
+      }
+    } else {
+      why = "peer device not visible to this process: not asked";
+    }
+    (void)hipGetLastError();
+    bool mapped = false;
+    if (can && memcmp(&theirs[i], &none, 64) &&
+        hipIpcOpenMemHandle((void **)&p.link_remote, theirs[i], hipIpcMemLazyEnablePeerAccess) == hipSuccess)
+      mapped = true;
+    if (!mapped) {
       p.link_remote = nullptr;
       bad = 1;
     }
+    if (verbose || !mapped)
+      fprintf(stderr, "[mpmhip] rank %d (%s) <- rank %d (%s): %s; halo arena %s\n", r.rank, my_bus[0] ? my_bus : "?", p.rank,
+              peer_bus[0] ? peer_bus : "?", why, mapped ? "mapped (HIP IPC)" : "NOT mapped: every rank falls back to ncclSend / ncclRecv");
   }
   (void)hipGetLastError();
   const char *fault = getenv("MPMHIP_LINK_FAULT");  // tests: this rank pretends its links failed

@@ -59,21 +59,59 @@ class Shard:
     cuts: np.ndarray = None           # the world-1 slab boundaries (x) of this partition
 
 
-def _owners(sc: Scene, world: int):
+CUT_BINS = 1 << 14   # histogram resolution of the device-side quantile cut: grid_lim / 16384 (1/64 cell at 256^3)
+
+
+def cuts_from_histogram(hist, world: int, grid_lim: float) -> np.ndarray:
+    """The world-1 slab boundaries from a histogram of the owned particles' x (CUT_BINS bins over [0, grid_lim), summed over the
+    ranks): the upper edge of the first bin at which the cumulative count reaches k/world of the particles.  Deterministic and
+    identical on every rank (integer counts); within one bin width of np.quantile."""
+    h = np.asarray(hist, np.int64)
+    cum = np.cumsum(h)
+    total = int(cum[-1]) if cum.size else 0
+    if world <= 1 or total == 0:
+        return np.zeros(0)
+    targets = (np.arange(1, world) * total + world - 1) // world
+    idx = np.searchsorted(cum, targets, side="left")
+    return (idx + 1).astype(np.float64) * (float(grid_lim) / h.size)
+
+
+def device_cuts(ss: "ShardedSim") -> np.ndarray:
+    """Collective: new slab boundaries at the particles' CURRENT positions without bringing a position to the host: every rank
+    histograms the x of the particles it owns on its GPU (torch.histc), the histograms are summed over the ranks (one all-reduce of
+    64 KiB) and every rank reads the same cuts off the same cumulative counts.  (Round 3: np.quantile over the all-gathered
+    positions of the whole scene.)"""
+    import torch
+    import torch.distributed as dist
+    sh = ss.shard
+    x = ss.sim.state.particle_x.detach()[:, 0]
+    ne_l = sh.own_e.size + sh.ghost_e.size
+    xs = x[ne_l:ne_l + sh.own_t.size + sh.own_v.size].float()
+    lim = float(ss.global_scene.grid_lim)
+    h = torch.histc(xs, bins=CUT_BINS, min=0.0, max=lim) if xs.numel() else torch.zeros(CUT_BINS, device=x.device)
+    h = h.to(torch.int64)
+    h = h.cpu() if ss.backend == "gloo" else h
+    dist.all_reduce(h)
+    return cuts_from_histogram(h.cpu().numpy(), sh.world, lim)
+
+
+def _owners(sc: Scene, world: int, cuts=None):
     n_e, n_t = sc.n_elements, sc.n_traditional
     xt, xv = sc.x[n_e:n_e + n_t, 0], sc.x[n_e + n_t:, 0]
     px = np.concatenate([xv, xt]).astype(np.float64)
-    cuts = np.quantile(px, np.arange(1, world) / world) if world > 1 and px.size else np.zeros(0)
+    if cuts is None:
+        cuts = np.quantile(px, np.arange(1, world) / world) if world > 1 and px.size else np.zeros(0)
     owner_v = np.searchsorted(cuts, xv, side="right").astype(np.int32)
     owner_t = np.searchsorted(cuts, xt, side="right").astype(np.int32)
     owner_e = owner_v[sc.faces[:, 0]] if n_e else np.zeros(0, np.int32)
     return owner_e, owner_t, owner_v, np.asarray(cuts, np.float64)
 
 
-def partition(sc: Scene, world: int) -> List[Shard]:
-    """Deterministic: every rank computes the full partition from the same Scene, no communication."""
+def partition(sc: Scene, world: int, cuts=None) -> List[Shard]:
+    """Deterministic: every rank computes the full partition from the same Scene, no communication.  cuts: slab boundaries to use
+    (re-partition: device_cuts()); None = the world-quantiles of the vertices' and traditional particles' x."""
     n_e, n_t, n_v = sc.n_elements, sc.n_traditional, sc.n_vertices
-    owner_e, owner_t, owner_v, cuts = _owners(sc, world)
+    owner_e, owner_t, owner_v, cuts = _owners(sc, world, cuts)
     faces = sc.faces.astype(np.int64)
     shards = []
     for r in range(world):
@@ -153,13 +191,14 @@ class ShardedSim:
     migrations: int = 0
 
 
-def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int = 0, _carry: dict = None) -> ShardedSim:
-    """Collective.  ``_carry`` (re-partition only): per-particle state in GLOBAL order to continue from, see repartition()."""
+def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int = 0, _carry: dict = None, _cuts=None) -> ShardedSim:
+    """Collective.  ``_carry`` / ``_cuts`` (re-partition only): per-particle state in GLOBAL order to continue from and the slab
+    boundaries to cut at, see repartition()."""
     import os
     import torch
     import torch.distributed as dist
     from . import harness
-    shard = partition(sc, world)[rank]
+    shard = partition(sc, world, _cuts)[rank]
     sim = harness.build_solver(shard.scene, device, mode="fast")
     sv = sim.solver
     if _carry is not None:
@@ -316,7 +355,11 @@ def repartition(ss: "ShardedSim") -> "ShardedSim":
     (state, solver time and substep count carried over).  The ShardedSim is updated IN PLACE (and returned): a caller that
     keeps its reference without rebinding continues on the new shard.  The old solver context -- with its RCCL communicator
     and peer-mapped arenas -- is destroyed before the new shard is built, so the two never coexist."""
+    import sys
+    import torch
+    import torch.distributed as dist
     sc = ss.global_scene
+    cuts = device_cuts(ss)                      # (before the state leaves the device: histogram of the owned particles' x)
     carry = gather_global_state(ss)
     carry["time"] = ss.sim.solver.time
     new_sc = replace(sc, x=carry["particle_x"], v=carry["particle_v"], d=carry["particle_d"])
@@ -330,7 +373,22 @@ def repartition(ss: "ShardedSim") -> "ShardedSim":
         ss.__dict__.pop(name, None)
     old.solver.close()                                          # ... and the context itself (communicator, IPC arenas)
     del old
-    new = build_sharded(new_sc, dev, rank, world, rebin_interval=rebin_interval, _carry=carry)
+    # The rebuild can fail on ONE rank (out of memory, a peer link that does not come up): that rank must not be left with
+    # sim = None while the others wait in the next collective.  Every rank reports, the minimum decides, all raise.
+    new, err = None, None
+    try:
+        new = build_sharded(new_sc, dev, rank, world, rebin_interval=rebin_interval, _carry=carry, _cuts=cuts)
+    except Exception as e:  # noqa: BLE001 - reported collectively below
+        err = e
+    ok = torch.tensor([0 if new is None else 1], dtype=torch.int32, device="cpu" if ss.backend == "gloo" else dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) != 1:
+        if new is not None:
+            new.sim.solver.close()
+        msg = f"re-partition at substep {keep['steps_done']} failed on " + ("this rank: " + repr(err) if err is not None else "another rank")
+        print(f"[mpmavatar_amd.dist] rank {rank}: {msg}", file=sys.stderr, flush=True)
+        raise RuntimeError("mpmavatar_amd.dist.repartition: " + msg + " (every rank raises; the sharded simulation is gone -- "
+                           "rebuild it from a checkpoint of gather_global_state)") from err
     ss.__dict__.update(new.__dict__)
     for k, v in keep.items():
         setattr(ss, k, v)
@@ -493,6 +551,9 @@ def _held_local(ss: ShardedSim, step: int) -> int:
 
 
 def run(ss: ShardedSim, n_steps: int):
+    # NOTE: the migration check (maybe_repartition) runs at the START of a call only, every `migrate_check_every` (512) substeps of
+    # accumulated progress: run(ss, n) with a large n never re-partitions mid-call -- callers that expect particles to cross slabs
+    # advance in frames (the reference's drivers call per frame of 400 substeps anyway).
     """Advance n substeps on every rank (collective).  Returns ``ss`` (a re-partition updates it in place)."""
     import torch
     ss = maybe_repartition(ss)

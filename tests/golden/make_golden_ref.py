@@ -477,7 +477,7 @@ FIXTURES = {
 def make_alt3(name, sc, checkpoints, extra=None):
     """Round 4: the same sequence a THIRD time, with svd3 / qr3 evaluated by the published algorithm behind
     Warp's builtins -- McAdams et al.'s fp32 Jacobi SVD with approximate Givens quaternions and the Givens-quaternion QR
-    (warp_standin: SVD_MODE "mcadams", QR_MODE "givens") -- stored in its own small file <name>_alt3.npz as alt3_s<k>_*.
+    (warp_standin: SVD_MODE "mcadams", QR_MODE "givens") -- stored in its own small file alt3_<name>.npz as alt3_s<k>_*.
     tests/test_ref_golden.py reports its distance from the primary run beside the other two envelopes and takes it into the
     bound (refgolden.seq_bound)."""
     wp.SVD_MODE, wp.QR_MODE = "mcadams", "givens"
@@ -494,7 +494,7 @@ def make_alt3(name, sc, checkpoints, extra=None):
         print(f"   {name} (alt3: mcadams / givens): substep {cp} after {time.time() - t0:.0f} s", flush=True)
     wp.SVD_MODE, wp.QR_MODE = "lapack", "householder"
     payload["checkpoints"] = np.array(checkpoints)
-    save(name + "_alt3", payload)
+    save("alt3_" + name, payload)
 
 
 ALT3 = {

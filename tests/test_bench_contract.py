@@ -87,6 +87,10 @@ def test_bench_gpus_n_without_a_launcher():
     assert "error" not in w, w
     assert w["value"] > 0 and w["n_particles"] == 2 * w["particles_per_rank"] and w["unit"] == "substeps/s"
     assert o["config"]["exchange"] == o["exchange"]["transport"]
+    # ... and the per-rank compute floor beside the measured value (round 4): rank 0's shard alone, no exchange
+    sf = o["shard_floor"]
+    assert "error" not in sf, sf
+    assert sf["substeps_per_s_upper_bound"] > 0 and sf["local_particles"] > 0 and 0 < sf["measured_fraction_of_bound"] < 1.5
     # the in-library loop (what a multi-GPU node runs), its RCCL entry points bound to the shared-memory stand-in
     sys.path.insert(0, os.path.join(ROOT, "tests", "mock_rccl"))
     from build import build as build_mock

@@ -93,3 +93,25 @@ def test_weak_scaling_workload_gives_every_rank_one_sheets_worth():
         for s in shards:                                                        # ... made of a strip of every layer
             layers = np.unique(s.own_v // nv1)
             assert layers.size == world, (world, layers)
+
+
+def test_device_side_quantile_cuts_match_np_quantile_to_a_bin():
+    """Round 4: the slab boundaries of a re-partition come from a histogram of the owned particles' x summed over the ranks
+    (dist.device_cuts) instead of np.quantile over all-gathered positions: identical on every rank, within one bin of the quantile,
+    and partition(cuts=...) splits the particles as evenly."""
+    from mpmavatar_amd import dist as md
+    sc = scenes.small_sheet()
+    n_e, n_t = sc.n_elements, sc.n_traditional
+    px = np.concatenate([sc.x[n_e + n_t:, 0], sc.x[n_e:n_e + n_t, 0]])
+    for world in (2, 3, 4):
+        # per-"rank" histograms of disjoint subsets, summed: what the all-reduce delivers
+        parts = np.array_split(np.random.default_rng(world).permutation(px), world)
+        h = sum(np.histogram(p, bins=md.CUT_BINS, range=(0.0, sc.grid_lim))[0] for p in parts)
+        cuts = md.cuts_from_histogram(h, world, sc.grid_lim)
+        q = np.quantile(px.astype(np.float64), np.arange(1, world) / world)
+        assert cuts.shape == q.shape and np.abs(cuts - q).max() <= 1.5 * sc.grid_lim / md.CUT_BINS + np.diff(np.unique(px)).max()
+        shards = md.partition(sc, world, cuts)
+        sizes = [s.own_v.size + s.own_t.size for s in shards]
+        assert sum(sizes) == px.size and max(sizes) - min(sizes) <= 0.1 * px.size / world + 48   # (lattice columns are 24 vertices)
+        assert all(np.array_equal(s.cuts, cuts) for s in shards)
+    assert md.cuts_from_histogram(np.zeros(md.CUT_BINS, np.int64), 4, 2.0).size == 0

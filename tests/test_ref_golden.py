@@ -220,3 +220,37 @@ def test_fixture_inventory():
     assert need <= seen, need - seen
     mats = {json.loads(str(rg.load(n)["scene_meta"]))["params"]["material"] for n in TRACES}
     assert {"jelly", "metal", "sand", "foam", "snow", "plasticine", "cloth"} <= mats
+
+
+def test_third_convention_mcadams_svd_givens_qr():
+    """VERDICT r3 item 4c.  tests/golden/alt3_ref_seq_*.npz: the reference's own source run a third time with svd3 / qr3 evaluated by
+    the PUBLISHED algorithm behind Warp's builtins (McAdams et al. 2011: fp32 Jacobi eigenanalysis with approximate Givens
+    quaternions, sorted singular values, Givens-quaternion QR; tests/golden/warp_standin SVD_MODE "mcadams" / QR_MODE "givens").
+    What it says about the envelopes (distances of the reference from ITSELF, max over the checkpoints, velocities):
+      * traditional materials (svd3): the third convention stays CLOSER to the fp64-accurate run than the second did -- jelly 5e-7
+        (alt 3e-6), metal 2e-5 (4e-4), sand 3e-5 (7e-4): the bounds of the plastic cases do not change;
+      * friction cloth (qr3): FARTHER -- sheet 2.9e-3 (alt 1.2e-3), garment 2.6e-3 (7.2e-4): if Warp's qr3 rounds like the published
+        Givens-quaternion scheme, the reference's own sensitivity envelope for gamma > 0 is 2.4-3.6x WIDER than the one the tests
+        use.  The tests keep the tighter envelope (alt / alt2): the oracle and the HIP path pass it;
+      * positions agree to 3e-6 everywhere, and cloth without the R22 discontinuity (gamma = 0) stays at 1.2e-5 over 200 substeps."""
+    import glob
+    import os
+    rows = {}
+    for path in sorted(glob.glob(os.path.join(rg.GOLDEN, "alt3_ref_seq_*.npz"))):
+        name = os.path.basename(path)[5:-4]
+        z, a = rg.load(name), np.load(path)
+        cps = [int(c) for c in a["checkpoints"]]
+        e3 = max(rg.rel(a[f"alt3_s{c}_particle_v"], z[f"s{c}_particle_v"]) for c in cps)
+        e1 = max(rg.rel(z[f"alt_s{c}_particle_v"], z[f"s{c}_particle_v"]) for c in cps)
+        ex = max(rg.rel(a[f"alt3_s{c}_particle_x"], z[f"s{c}_particle_x"]) for c in cps)
+        rows[name] = (e3, e1, ex)
+        print(f"{name}: v envelope alt3 (mcadams / givens) {e3:.2e}, alt (fp32 Jacobi / Gram-Schmidt) {e1:.2e}; x {ex:.2e}")
+        assert ex < 1e-5, (name, ex)
+    assert {"ref_seq_cube_jelly", "ref_seq_cube_sand", "ref_seq_cube_metal", "ref_seq_sheet", "ref_seq_garment"} <= set(rows)
+    for name in ("ref_seq_cube_jelly", "ref_seq_cube_sand", "ref_seq_cube_metal"):
+        assert rows[name][0] <= rows[name][1], (name, rows[name])          # svd3: bounds unchanged
+    assert rows["ref_seq_cube_jelly"][0] < 1e-4                              # the strict case stays strict
+    for name in ("ref_seq_sheet", "ref_seq_garment"):
+        assert 1.5 * rows[name][1] < rows[name][0] < 6 * rows[name][1], (name, rows[name])   # qr3: 2.4-3.6x wider, not used to loosen
+    if "ref_seq_sheet_gamma0" in rows:
+        assert rows["ref_seq_sheet_gamma0"][0] < 1e-4                   # (measured 1.2e-5 over 200 substeps: inside the north-star bound)
