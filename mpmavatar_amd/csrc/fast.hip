@@ -822,9 +822,8 @@ __global__ __launch_bounds__(RS_TPB) void k_keys(Bufs b, Dims d, int kf, float l
 // director matrix less per substep.  The host runs the stand-alone k_elem_finalize instead whenever something needs
 // finished elements earlier (re-sort, read-back, pre-p2g operations, joint-face splats, multi-GPU ghosts).
 template <bool FINALIZE>
-__global__ void k_stress_elem(Bufs b, F3 *ef, Dims d, float friction_coeff, const int *face_slot,
-                              const SortKey *skeys, int blk_bits, int *counters, int step_id) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void stress_elem_body(int e, const Bufs &b, F3 *ef, const Dims &d, float friction_coeff, const int *face_slot,
+                                                 const SortKey *skeys, int blk_bits, int *counters, int step_id) {
   if (e >= d.n_e) return;
   if (b.sel[e] == 1) {  // not simulated (selection == 2 marks a ghost copy: stress yes, transfers no)
     for (int c = 0; c < 3; ++c) ef[c * d.n_e + e] = F3{0.0f, 0.0f, 0.0f};
@@ -866,6 +865,11 @@ __global__ void k_stress_elem(Bufs b, F3 *ef, Dims d, float friction_coeff, cons
   ef[e] = F3{f1.x, f1.y, f1.z};
   ef[d.n_e + e] = F3{f2.x, f2.y, f2.z};
   ef[2 * d.n_e + e] = F3{f3.x, f3.y, f3.z};
+}
+template <bool FINALIZE>
+__global__ void k_stress_elem(Bufs b, F3 *ef, Dims d, float friction_coeff, const int *face_slot,
+                              const SortKey *skeys, int blk_bits, int *counters, int step_id) {
+  stress_elem_body<FINALIZE>(blockIdx.x * blockDim.x + threadIdx.x, b, ef, d, friction_coeff, face_slot, skeys, blk_bits, counters, step_id);
 }
 
 __global__ void k_stress_trad(Bufs b, Dims d, mpmhip_model_scalars sc, float dt) {
@@ -1234,6 +1238,7 @@ struct SplatArgs {
   const int *fidx;         // [n_f][3] vertex ids in bin order
   const FaceBin *fbins;
   int n_fbins;             // workgroups [0, n_fbins): one face bin each
+  int splat_passes;        // 3: both passes of the body-face splat here; 2: only the normal pass (pass 0 rode in the stress launch)
   JointSplatArgs js;       // workgroups [n_fbins, n_fbins + n_mov_wg): joints
   int n_mov_wg;
   int n_extra;             // n_fbins + n_mov_wg rounded up to a multiple of 8 (keeps the XCD mapping of the chunks)
@@ -1722,6 +1727,13 @@ __device__ __forceinline__ void col_splat_flush(const double *tile, int ox, int 
 }
 
 constexpr int SPLAT_SMALL = 32;  // faces per bin up to which the splat workgroup maps lanes to (face, node) pairs
+// PASSES: bit 0 = the weight / velocity pass (w, w v_face: collider channels 0-3, sets col_flag), bit 1 = the normal pass (w n:
+// channels 4-6).  3 = both in one workgroup, as rounds 1-3 did.  Round 4: in cloth scenes the two passes ride in DIFFERENT
+// launches -- pass 0 in front of the stress kernel, pass 1 in the p2g launch -- because a two-pass splat workgroup lives 10-17 us and
+// set the length of the p2g launch in scenes that fit one round of workgroups (garment-120k: p2g 18 us for 10 us chunk
+// workgroups), while the stress launch before it has room (9 us of streaming work, no LDS, one round).  Nothing reads the collider
+// channels before g2p; the buffer they go into was cleared by the p2g launch of the substep before.
+template <int PASSES>
 __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, int bin, const Dims &d, const GridPtrs &g) {
   const FaceBin fb = sa.fbins[bin];
   int blk = fb.blk;
@@ -1771,9 +1783,11 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
       if (ok && in_tile) {
         wk[it] = w;
         basek[it] = tile_idx(lx + ni, ly + nj, lz + nk);
-        double *p = tile + basek[it];
-        atomicAdd(p, (double)w);
-        atomicAdd(p + TILE_PAD, (double)(w * a.x)); atomicAdd(p + 2 * TILE_PAD, (double)(w * a.y)); atomicAdd(p + 3 * TILE_PAD, (double)(w * a.z));
+        if (PASSES & 1) {
+          double *p = tile + basek[it];
+          atomicAdd(p, (double)w);
+          atomicAdd(p + TILE_PAD, (double)(w * a.x)); atomicAdd(p + 2 * TILE_PAD, (double)(w * a.y)); atomicAdd(p + 3 * TILE_PAD, (double)(w * a.z));
+        }
       } else if (ok) {  // drifted out of the tile margin since the faces were binned: this lane's node through global atomics
         raise_drift(g.counters, g.step_id);
         raise_face(g.counters, g.step_id);
@@ -1781,18 +1795,25 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
         int nb = blk_of(x, y, z, d.NB);
         if (g.ab_flag[nb]) {
           float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
-          __hip_atomic_store(&g.col_flag[nb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          atomicAdd(p, w);
-          atomicAdd(p + 64, w * a.x); atomicAdd(p + 128, w * a.y); atomicAdd(p + 192, w * a.z);
-          atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
+          if (PASSES & 1) {
+            __hip_atomic_store(&g.col_flag[nb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(p, w);
+            atomicAdd(p + 64, w * a.x); atomicAdd(p + 128, w * a.y); atomicAdd(p + 192, w * a.z);
+          }
+          if (PASSES & 2) { atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z); }
         }
       }
     }
-    __syncthreads();
-    col_splat_flush<0>(tile, ox, oy, oz, bx, by, bz, act_mask, d, g);
-    __syncthreads();
-    for (int t = l; t < 3 * TILE_PAD; t += PT) tile[t] = 0.0;
-    __syncthreads();
+    if (PASSES & 1) {
+      __syncthreads();
+      col_splat_flush<0>(tile, ox, oy, oz, bx, by, bz, act_mask, d, g);
+    }
+    if (!(PASSES & 2)) return;
+    if (PASSES & 1) {
+      __syncthreads();
+      for (int t = l; t < 3 * TILE_PAD; t += PT) tile[t] = 0.0;
+      __syncthreads();
+    }
 #pragma unroll
     for (int it = 0; it < SPLAT_SMALL / 8; ++it)
       if (wk[it] != 0.0f) {
@@ -1831,7 +1852,7 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
     bool do_add = tile_ok && (dist & 7) == 0;
     if (DBG(g, 4096)) { sm.m1 = sm.m2 = sm.m4 = sm.m8 = 0.0f; do_add = tile_ok; }
     __syncthreads();
-    if (any) col_splat_scatter<0>(tile, s, on, a, sm, do_add, base);
+    if (any && (PASSES & 1)) col_splat_scatter<0>(tile, s, on, a, sm, do_add, base);
     if (ok && !in_tile) {  // drifted out of the tile margin since the faces were binned
       raise_drift(g.counters, g.step_id);
       raise_face(g.counters, g.step_id);  // ... which is what makes the next re-sort bin the faces again (rebin)
@@ -1843,23 +1864,43 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
         int nb = blk_of(x, y, z, d.NB);
         if (g.ab_flag[nb]) {
           float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
-          __hip_atomic_store(&g.col_flag[nb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          atomicAdd(p, w);
-          atomicAdd(p + 64, w * a.x); atomicAdd(p + 128, w * a.y); atomicAdd(p + 192, w * a.z);
-          atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
+          if (PASSES & 1) {
+            __hip_atomic_store(&g.col_flag[nb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(p, w);
+            atomicAdd(p + 64, w * a.x); atomicAdd(p + 128, w * a.y); atomicAdd(p + 192, w * a.z);
+          }
+          if (PASSES & 2) { atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z); }
         }
       }
     }
-    __syncthreads();
-    col_splat_flush<0>(tile, ox, oy, oz, bx, by, bz, act_mask, d, g);
-    __syncthreads();
-    for (int t = l; t < 3 * TILE_PAD; t += PT) tile[t] = 0.0;
-    __syncthreads();
-    if (any) col_splat_scatter<1>(tile, s, on, fn, sm, do_add, base);
-    __syncthreads();
-    col_splat_flush<1>(tile, ox, oy, oz, bx, by, bz, act_mask, d, g);
+    if (PASSES & 1) {
+      __syncthreads();
+      col_splat_flush<0>(tile, ox, oy, oz, bx, by, bz, act_mask, d, g);
+    }
+    if (PASSES == 3) {
+      __syncthreads();
+      for (int t = l; t < 3 * TILE_PAD; t += PT) tile[t] = 0.0;
+    }
+    if (PASSES & 2) {
+      __syncthreads();
+      if (any) col_splat_scatter<1>(tile, s, on, fn, sm, do_add, base);
+      __syncthreads();
+      col_splat_flush<1>(tile, ox, oy, oz, bx, by, bz, act_mask, d, g);
+    }
     __syncthreads();
   }
+}
+// The cloth scenes' stress launch with the collider splat's first pass in front (see col_splat_wg): workgroups [0, n_splat) splat,
+// the rest are k_stress_elem<true>.
+__global__ __launch_bounds__(TPB) void k_stress_elem_splat(Bufs b, F3 *ef, Dims d, float friction_coeff, const int *face_slot,
+                                                           const SortKey *skeys, int blk_bits, int n_splat, GridPtrs g, SplatArgs sa) {
+  __shared__ double tile[4 * TILE_PAD];
+  if ((int)blockIdx.x < n_splat) {
+    col_splat_wg<1>(tile, sa, (int)blockIdx.x, d, g);
+    return;
+  }
+  stress_elem_body<true>(((int)blockIdx.x - n_splat) * (int)blockDim.x + (int)threadIdx.x, b, ef, d, friction_coeff, face_slot, skeys,
+                         blk_bits, g.counters, g.step_id);
 }
 
 // JT = true: the mover holds MANY traditional particles (run_demo.py keeps 100k sand particles frozen for the first
@@ -1890,7 +1931,11 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
   if ((int)blockIdx.x >= sa.e0 && (int)blockIdx.x < sa.e0 + sa.n_extra) {
     int e = (int)blockIdx.x - sa.e0;
     if (DBG(g, 256)) return;
-    if (e < sa.n_fbins) { if (!DBG(g, 8192)) col_splat_wg(tile, sa, e, d, g); }   // (8192 / 16384: ablation switches)
+    if (e < sa.n_fbins) {   // (8192 / 16384: ablation switches)
+      if (DBG(g, 8192)) {}
+      else if (sa.splat_passes == 2) col_splat_wg<2>(tile, sa, e, d, g);   // (pass 0 rode in the stress launch)
+      else col_splat_wg<3>(tile, sa, e, d, g);
+    }
     else if (e < sa.n_fbins + sa.n_mov_wg) { if (!DBG(g, 16384)) mover_splat_wg(b, sa.js, e - sa.n_fbins, d, g); }
     WGT(g, 0, 6);
     wg_done(sa.pack);
@@ -2438,7 +2483,7 @@ __device__ __forceinline__ void g2p2g_body(const ChunkRec *recs, int n_chunks, c
   }
   if ((int)blockIdx.x >= sa.e0 && (int)blockIdx.x < sa.e0 + sa.n_extra) {  // splats of substep n + 1 (into W)
     int e = (int)blockIdx.x - sa.e0;
-    if (e < sa.n_fbins) col_splat_wg(tile, sa, e, d, g);
+    if (e < sa.n_fbins) col_splat_wg<3>(tile, sa, e, d, g);
     else if (e < sa.n_fbins + sa.n_mov_wg) mover_splat_wg(b, sa.js, e - sa.n_fbins, d, g);
     return;
   }
@@ -2986,6 +3031,8 @@ struct FastState {
   // (k_g2p2g), or flush_g2p() does with a plain k_g2p when anything else needs the particles first
   bool g2p2g = true;           // MPMHIP_G2P2G=0: two launches per substep for traditional-only scenes as before
   int g2p2g_max_chunks = 512;  // MPMHIP_G2P2G_MAX
+  int split_splat_max_chunks = 1024;  // MPMHIP_SPLIT_SPLAT_MAX
+  bool split_splat = true;     // body-face splat: pass 0 in the stress launch, pass 1 in the p2g launch (MPMHIP_SPLIT_SPLAT=0: both in p2g)
   int64_t n_g2p2g = 0;         // fused launches so far (mpmhip_stats)
   bool g2p_pending = false;
   GridParams pend_gp{};
@@ -3384,6 +3431,8 @@ int fast_init(mpmhip_ctx *c) {
   if (const char *e = getenv("MPMHIP_P2G_TILE")) { f->p2g_fixed = std::string(e) != "f64"; f->p2g_fixed_forced = std::string(e) == "fx"; }
   f->p2g_fixed_now = f->p2g_fixed;
   if (const char *e = getenv("MPMHIP_G2P2G")) f->g2p2g = atoi(e) != 0;
+  if (const char *e = getenv("MPMHIP_SPLIT_SPLAT")) f->split_splat = atoi(e) != 0;
+  if (const char *e = getenv("MPMHIP_SPLIT_SPLAT_MAX")) f->split_splat_max_chunks = atoi(e);
   if (const char *e = getenv("MPMHIP_G2P2G_MAX")) f->g2p2g_max_chunks = atoi(e);
   f->key_bits = f->blk_bits_plain + cell_bits + 2 + 2;
   if (f->key_bits > 32) return fail(c, MPMHIP_ERR_INVALID, "grid too large for 32-bit sort keys");
@@ -3735,6 +3784,13 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       select_buffer(f, (f->par + 1) % f->nbuf);
     }
   }
+  // cloth scenes of the production loop: the splat's first pass rides in front of the stress launch (col_splat_wg)
+  // ... where the p2g launch is at most one round of workgroups, i.e. as long as a workgroup's life is the launch's length
+  // (garment-120k-aniso: stress 9.7 -> 12.0 us, p2g 20.0 -> 16.4 us, 24.7 k -> 25.6 k substeps/s; with several rounds of chunk
+  // workgroups the splat hides among them and the split only lengthens the stress launch: sheet-500k -1 %, profiles/r04_experiments.md)
+  const bool split_splat = f->split_splat && has_col && sa.n_fbins > 0 && d.n_e > 0 && f->elem_pending && !c->profiling && !f->dist &&
+                           f->n_chunks <= f->split_splat_max_chunks && !(MPMHIP_DEBUG && f->g.dbg);
+  sa.splat_passes = split_splat ? 2 : 3;
   sa.n_extra = (sa.n_fbins + sa.n_mov_wg + 7) & ~7;
   sa.z_first = sa.n_extra + (int)xcd_grid(f->n_chunks);
   sa.e0 = (sa.n_extra > f->splat_first_max && !c->profiling) ? (int)xcd_grid(f->n_chunks) : 0;
@@ -3764,7 +3820,10 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   if (d.n_e || (d.n_t && !trad_fused)) {  // (no empty event bracket when the stress update rides in p2g)
     ScopedPhase ph(c, "compute_stress_from_F_trial");
     if (d.n_e) {
-      if (f->elem_pending)
+      if (split_splat)
+        KSTAMP_LAUNCH(k_stress_elem_splat, nblk(d.n_e) + (unsigned)sa.n_fbins, TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff, f->face_slot,
+                      f->keys[1], f->blk_bits, sa.n_fbins, f->g, sa);
+      else if (f->elem_pending)
         KSTAMP_LAUNCH(k_stress_elem<true>, nblk(d.n_e), TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff, f->face_slot,
                            f->keys[1], f->blk_bits, f->g.counters, f->g.step_id);
       else
