@@ -60,7 +60,15 @@ typedef struct {
   void *stream;           /* own_stream == 0: hipStream_t to launch on (NULL = the HIP null stream), e.g.
                              torch.cuda.current_stream().cuda_stream so that solver work is ordered with the
                              caller's tensor ops the way Warp's stream is with torch's */
+  int32_t p2g_tile;       /* fast mode, the one setting that changes NUMERICS: accumulator of p2g's chunk tile.
+                             MPMHIP_P2G_TILE_AUTO (0): packed fixed point, or fp64 when the particle masses of the scene span more
+                             than 1e5 (decided at every import of the state); MPMHIP_P2G_TILE_FIXED (1); MPMHIP_P2G_TILE_F64 (2).
+                             (The environment variable MPMHIP_P2G_TILE=fx|f64 overrides it for experiments.) */
+  int32_t reserved_;      /* must be 0 */
 } mpmhip_config;
+#define MPMHIP_P2G_TILE_AUTO 0
+#define MPMHIP_P2G_TILE_FIXED 1
+#define MPMHIP_P2G_TILE_F64 2
 
 /* MPMStateStruct fields the substep touches, mpm_data_structure.py:13-49.  All [dev]. */
 typedef struct {

@@ -31,7 +31,8 @@ class Config(C.Structure):
     _fields_ = [("n_particles", C.c_int32), ("n_elements", C.c_int32), ("n_vertices", C.c_int32),
                 ("n_grid", C.c_int32), ("grid_lim", C.c_float), ("num_joint_t", C.c_int32),
                 ("num_joint_v", C.c_int32), ("num_joint_f", C.c_int32), ("device", C.c_int32), ("mode", C.c_int32),
-                ("rebin_interval", C.c_int32), ("own_stream", C.c_int32), ("stream", vp)]
+                ("rebin_interval", C.c_int32), ("own_stream", C.c_int32), ("stream", vp), ("p2g_tile", C.c_int32),
+                ("reserved_", C.c_int32)]
 
 
 class StatePtrs(C.Structure):

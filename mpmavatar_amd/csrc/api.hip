@@ -55,6 +55,10 @@ int mpmhip_create(const mpmhip_config *cfg, mpmhip_ctx **out) {
     g_create_error = "mpmhip_create: unknown mode";
     return MPMHIP_ERR_INVALID;
   }
+  if (cfg->p2g_tile < MPMHIP_P2G_TILE_AUTO || cfg->p2g_tile > MPMHIP_P2G_TILE_F64 || cfg->reserved_ != 0) {
+    g_create_error = "mpmhip_create: p2g_tile must be MPMHIP_P2G_TILE_AUTO / _FIXED / _F64 (and reserved_ 0)";
+    return MPMHIP_ERR_INVALID;
+  }
   int ndev = mpmhip_device_count();
   if (ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
     g_create_error = "mpmhip_create: no HIP device " + std::to_string(cfg->device) + " (visible devices: " +

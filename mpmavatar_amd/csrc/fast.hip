@@ -2058,20 +2058,6 @@ __global__ __launch_bounds__(PT) void k_p2g(const ChunkRec *recs, int n_chunks, 
   __shared__ float red[8];
   p2g_body<STEPS, TRAD, JT, FX>(recs, n_chunks, b, va, d, rpic, dt, g, sa, tp, tile, esc, esc_n, red);
 }
-// The cloth instantiation with six wavefronts per SIMD instead of the five its 90 VGPRs allow: 80 VGPRs + 9 spilled dwords.
-// A workgroup's life is a chain of memory latencies (record -> particles -> adjacency -> corner forces) followed by a
-// VALU-bound scatter; with 5 workgroups per CU the headline scene's 2,700 chunks need a third round of the 1,280 slots
-// (profiles/r03_wg_timeline.md), with 6 they fit two rounds of 1,536.  (The instantiation with the fused traditional stress
-// update would spill 216 bytes per lane and keeps its natural budget.)
-__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6)))
-void k_p2g_w6(const ChunkRec *recs, int n_chunks, Bufs b, VAdj va, Dims d, float rpic, float dt, GridPtrs g, SplatArgs sa, TradParams tp) {
-  __shared__ double tile[4 * TILE_PAD];
-  __shared__ int esc[CHUNK];
-  __shared__ int esc_n;
-  __shared__ float red[8];
-  p2g_body<3, false, false, true>(recs, n_chunks, b, va, d, rpic, dt, g, sa, tp, tile, esc, esc_n, red);
-}
-
 // ------------------------------------------------------------------------------------------------
 // g2p (g2p_v / g2p_e, mpm_utils.py:716-857) with the v_out tile staged in LDS.
 // Factored gather: for every (i,j) column first reduce over k
@@ -2446,14 +2432,6 @@ __global__ __launch_bounds__(PT) void k_g2p_halo(const ChunkRec *recs, int n_chu
   __shared__ float4 tile[TILE_PAD];
   g2p_body<true, TWO_PASS, false, true>(recs, n_chunks, b, d, dt, g, gp, bcl, tile, (int)blockIdx.x);
 }
-// six wavefronts per SIMD for the fused two-pass form (94 VGPRs -> 80 + 12 spilled dwords), see k_p2g_w6
-template <bool MFLAG>
-__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6)))
-void k_g2p_w6(const ChunkRec *recs, int n_chunks, Bufs b, Dims d, float dt, GridPtrs g, GridParams gp, BCList bcl) {
-  __shared__ float4 tile[TILE_PAD];
-  g2p_body<true, true, MFLAG>(recs, n_chunks, b, d, dt, g, gp, bcl, tile, (int)blockIdx.x);
-}
-
 // ------------------------------------------------------------------------------------------------
 // G2P2G (round 4): scenes of traditional particles only run ONE launch per substep.  A workgroup finishes substep n for its
 // chunk -- g2p_v (mpm_utils.py:716-786) from the accumulators p2g(n) filled, every node through the grid stage on the way -- and,
@@ -2918,7 +2896,6 @@ struct FastState {
   bool g2p_two_pass = false;   // k_g2p<., true, .>: see there (default: scenes without traditional particles)
   int splat_first_max = 1 << 30;  // more splat workgroups than this go behind the chunk workgroups (MPMHIP_SPLAT_FIRST_MAX; measured
                                   // neutral early and late -- profiles/r03_experiments.md -- so they stay in front)
-  bool w6 = false;             // six-wavefront builds of the cloth kernels (k_p2g_w6, k_g2p_w6): MPMHIP_W6
   bool p2g_fixed_now = true, p2g_fixed_forced = false, mass_span_pending = false;  // the tile in use (decided per import from the mass span)
   float mass_span = 1.0f;
   bool p2g_fixed = true;       // p2g's chunk tile in packed fixed point (k_p2g<.., FX = true>); MPMHIP_P2G_TILE=f64: the fp64 tile
@@ -3428,6 +3405,8 @@ int fast_init(mpmhip_ctx *c) {
   int cell_bits = f->blk_bits_plain + 8 + 2 + 2 <= 32 ? 8 : 6;  // 8: predictive sort (see make_key)
   if (const char *e = getenv("MPMHIP_PREDICTIVE_SORT")) if (atoi(e) == 0) cell_bits = 6;
   if (const char *e = getenv("MPMHIP_SORT")) f->sort_rocprim = std::string(e) == "rocprim";
+  f->p2g_fixed = cfg.p2g_tile != MPMHIP_P2G_TILE_F64;
+  f->p2g_fixed_forced = cfg.p2g_tile == MPMHIP_P2G_TILE_FIXED;
   if (const char *e = getenv("MPMHIP_P2G_TILE")) { f->p2g_fixed = std::string(e) != "f64"; f->p2g_fixed_forced = std::string(e) == "fx"; }
   f->p2g_fixed_now = f->p2g_fixed;
   if (const char *e = getenv("MPMHIP_G2P2G")) f->g2p2g = atoi(e) != 0;
@@ -3481,7 +3460,6 @@ int fast_init(mpmhip_ctx *c) {
   if (const char *e = getenv("MPMHIP_G2P_TWO_PASS")) f->g2p_two_pass = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_FUSE_TRAD")) f->fuse_trad = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_DIST_FUSED_HALO")) f->fused_want = atoi(e) != 0;
-  if (const char *e = getenv("MPMHIP_W6")) f->w6 = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_SPLAT_FIRST_MAX")) f->splat_first_max = atoi(e);
   f->g.stagger = 0; f->g.stagger_groups = 2; f->g.stagger_first = 0;
   if (const char *e = getenv("MPMHIP_P2G_STAGGER")) {  // "units[,groups[,first]]": units of 1024 cycles per group step
@@ -3597,7 +3575,6 @@ int fast_pull(mpmhip_ctx *c) {
       else KSTAMP_LAUNCH((k_p2g<3, false, false, false>), __VA_ARGS__);               \
     } else if ((trad) && (jt)) KSTAMP_LAUNCH((k_p2g<P2G_STEPS, true, true, true>), __VA_ARGS__); \
     else if (trad) KSTAMP_LAUNCH((k_p2g<P2G_STEPS, true, false, true>), __VA_ARGS__);     \
-    else if (f->w6) KSTAMP_LAUNCH(k_p2g_w6, __VA_ARGS__);                   \
     else KSTAMP_LAUNCH((k_p2g<P2G_STEPS, false, false, true>), __VA_ARGS__);              \
   } while (0)
 
@@ -3610,12 +3587,10 @@ int fast_pull(mpmhip_ctx *c) {
       if (two) KSTAMP_LAUNCH((k_g2p_halo<true>), __VA_ARGS__);                             \
       else KSTAMP_LAUNCH((k_g2p_halo<false>), __VA_ARGS__);                                \
     } else if (f->g2p_mflag) {                                                                  \
-      if ((two) && f->w6) KSTAMP_LAUNCH((k_g2p_w6<true>), __VA_ARGS__);                    \
-      else if (two) KSTAMP_LAUNCH((k_g2p<true, true, true>), __VA_ARGS__);                 \
+      if (two) KSTAMP_LAUNCH((k_g2p<true, true, true>), __VA_ARGS__);                 \
       else KSTAMP_LAUNCH((k_g2p<true, false, true>), __VA_ARGS__);                         \
     } else {                                                                                    \
-      if ((two) && f->w6) KSTAMP_LAUNCH((k_g2p_w6<false>), __VA_ARGS__);                   \
-      else if (two) KSTAMP_LAUNCH((k_g2p<true, true, false>), __VA_ARGS__);                \
+      if (two) KSTAMP_LAUNCH((k_g2p<true, true, false>), __VA_ARGS__);                \
       else KSTAMP_LAUNCH((k_g2p<true, false, false>), __VA_ARGS__);                        \
     }                                                                                           \
   } while (0)
@@ -3630,7 +3605,7 @@ static bool g2p2g_ok(const mpmhip_ctx *c) {
   // (two wavefronts per SIMD = 512 workgroup slots; either half alone needs 116-124, profiles/r04_experiments.md), which a scene
   // of more chunks pays for with more than it saves (block-512k -8 %, garment-120k-iso -11 %; cube-8k +23 %)
   return f->g2p2g && f->nbuf == 3 && !f->dist && !c->profiling && d.n_e == 0 && d.n_v == 0 && d.n_t > 0 && f->fuse_trad && f->fuse_grid &&
-         !f->g.halo.slot && !f->g2p_mflag && !f->w6 && !(MPMHIP_DEBUG && f->g.dbg) && f->n_chunks <= f->g2p2g_max_chunks;
+         !f->g.halo.slot && !f->g2p_mflag && !(MPMHIP_DEBUG && f->g.dbg) && f->n_chunks <= f->g2p2g_max_chunks;
 }
 // the deferred g2p of the last substep as a launch of its own (anything that reads or re-orders the particles comes here first),
 // and the clearing of the buffer the last fused launch read

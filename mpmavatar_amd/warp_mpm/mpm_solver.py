@@ -47,8 +47,10 @@ class MPMWARP(object):
     # mpm_solver.py:14-51
     def __init__(self, n_particles, n_elements, n_vertices, n_grid=100, grid_lim=1.0, mesh_vertices=None,
                  mesh_faces=None, num_joint_t=0, num_joint_v=0, num_joint_f=0, device="cuda:0", mode=None,
-                 rebin_interval=0):
+                 rebin_interval=0, p2g_tile="auto"):
+        # p2g_tile (no reference counterpart): "auto" | "fixed" | "f64", mpmhip_config.p2g_tile -- the one numerics-changing setting
         self._lib = L.load()
+        self._p2g_tile = {"auto": 0, "fixed": 1, "fx": 1, "f64": 2}[p2g_tile] if isinstance(p2g_tile, str) else int(p2g_tile)
         self._ctx = None
         self._mode = _mode_from_env() if mode is None else {"fast": L.MODE_FAST, "baseline": L.MODE_BASELINE}.get(mode, mode)
         self._rebin_interval = rebin_interval
@@ -75,7 +77,7 @@ class MPMWARP(object):
         if torch.cuda.is_available():
             stream = torch.cuda.current_stream(self.device).cuda_stream
         cfg = L.Config(n_particles, n_elements, n_vertices, n_grid, float(grid_lim), num_joint_t, num_joint_v,
-                       num_joint_f, dev_index, self._mode, self._rebin_interval, 0, stream)
+                       num_joint_f, dev_index, self._mode, self._rebin_interval, 0, stream, self._p2g_tile, 0)
         ctx = L.vp()
         rc = self._lib.mpmhip_create(C.byref(cfg), C.byref(ctx))
         L.check(self._lib, None, rc)
