@@ -3558,42 +3558,88 @@ int fast_pull(mpmhip_ctx *c) {
 #define P2G_STEPS 3  // DPP scan steps of the fixed-point instantiations (experiment switch)
 #endif
 // the hot launches: in prof_fused mode they carry the context's kernel-stamp events (ctx.hpp kev0 / kev1); otherwise a plain launch
-#define KSTAMP_LAUNCH(k, gr, bl, sh, st, ...)                                                                           \
-  do {                                                                                                                  \
-    if (c->prof_fused) {                                                                                                \
-      hipExtLaunchKernelGGL(k, dim3(gr), dim3(bl), sh, st, c->kev0, c->kev1, 0, __VA_ARGS__);                           \
-      c->kev_pending = true;                                                                                            \
-    } else {                                                                                                            \
-      hipLaunchKernelGGL(k, gr, bl, sh, st, __VA_ARGS__);                                                               \
-    }                                                                                                                   \
-  } while (0)
-#define P2G_LAUNCH(trad, jt, ...)                                                \
-  do {                                                                           \
-    if (!f->p2g_fixed_now) {  /* MPMHIP_P2G_TILE=f64, or particle masses that span more than 1e5 */                                     \
-      if ((trad) && (jt)) KSTAMP_LAUNCH((k_p2g<3, true, true, false>), __VA_ARGS__);  \
-      else if (trad) KSTAMP_LAUNCH((k_p2g<3, true, false, false>), __VA_ARGS__);      \
-      else KSTAMP_LAUNCH((k_p2g<3, false, false, false>), __VA_ARGS__);               \
-    } else if ((trad) && (jt)) KSTAMP_LAUNCH((k_p2g<P2G_STEPS, true, true, true>), __VA_ARGS__); \
-    else if (trad) KSTAMP_LAUNCH((k_p2g<P2G_STEPS, true, false, true>), __VA_ARGS__);     \
-    else KSTAMP_LAUNCH((k_p2g<P2G_STEPS, false, false, true>), __VA_ARGS__);              \
-  } while (0)
-
-#define G2P_LAUNCH(fused, two, ...)                                                              \
-  do {                                                                                          \
-    if (!(fused)) {                                                                             \
-      if (two) KSTAMP_LAUNCH((k_g2p<false, true, true>), __VA_ARGS__);                     \
-      else KSTAMP_LAUNCH((k_g2p<false, false, true>), __VA_ARGS__);                        \
-    } else if (f->g.halo.slot) {                                                                \
-      if (two) KSTAMP_LAUNCH((k_g2p_halo<true>), __VA_ARGS__);                             \
-      else KSTAMP_LAUNCH((k_g2p_halo<false>), __VA_ARGS__);                                \
-    } else if (f->g2p_mflag) {                                                                  \
-      if (two) KSTAMP_LAUNCH((k_g2p<true, true, true>), __VA_ARGS__);                 \
-      else KSTAMP_LAUNCH((k_g2p<true, false, true>), __VA_ARGS__);                         \
-    } else {                                                                                    \
-      if (two) KSTAMP_LAUNCH((k_g2p<true, true, false>), __VA_ARGS__);                \
-      else KSTAMP_LAUNCH((k_g2p<true, false, false>), __VA_ARGS__);                        \
-    }                                                                                           \
-  } while (0)
+template <class K, class... A>
+inline void kstamp_launch(mpmhip_ctx *c, K kernel, unsigned grid, unsigned block, A &&...args) {
+  if (c->prof_fused) {
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, c->stream, c->kev0, c->kev1, 0, args...);
+    c->kev_pending = true;
+  } else {
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, c->stream, args...);
+  }
+}
+// ---- launchers of the substep's kernels (the only places that name their template instantiations) -------------------------
+// k_p2g with / without the fused traditional stress update (trad) and the in-tile joint splat of held traditional particles (jt),
+// on the chunk list's first n_chunks records (0: only the extra workgroups sa describes)
+void launch_p2g(mpmhip_ctx *c, bool trad, bool jt, unsigned grid, int n_chunks, float dt, const SplatArgs &sa, const TradParams &tp) {
+  FastState *f = c->fast;
+  const Dims &d = f->d;
+  const Bufs &b = f->buf[f->cur];
+  const float rpic = c->sc.rpic_damping;
+#define P2G_ARGS grid, PT, f->chunks, n_chunks, b, f->va(), d, rpic, dt, f->g, sa, tp
+  if (!f->p2g_fixed_now) {  // mpmhip_config.p2g_tile = F64, or particle masses that span more than 1e5
+    if (trad && jt) kstamp_launch(c, k_p2g<3, true, true, false>, P2G_ARGS);
+    else if (trad) kstamp_launch(c, k_p2g<3, true, false, false>, P2G_ARGS);
+    else kstamp_launch(c, k_p2g<3, false, false, false>, P2G_ARGS);
+  } else if (trad && jt) kstamp_launch(c, k_p2g<P2G_STEPS, true, true, true>, P2G_ARGS);
+  else if (trad) kstamp_launch(c, k_p2g<P2G_STEPS, true, false, true>, P2G_ARGS);
+  else kstamp_launch(c, k_p2g<P2G_STEPS, false, false, true>, P2G_ARGS);
+#undef P2G_ARGS
+}
+// compute_stress_from_F_trial of the elements: mode 0 = from the stored directors (first substep after an import), 1 = with the
+// element finalize of the substep before fused in, 2 = the same with the collider splat's first pass in front (sa.n_fbins workgroups)
+void launch_stress_elem(mpmhip_ctx *c, int mode, const SplatArgs &sa) {
+  FastState *f = c->fast;
+  const Dims &d = f->d;
+  const Bufs &b = f->buf[f->cur];
+  hipStream_t s = c->stream;
+  if (mode == 2)
+    kstamp_launch(c, k_stress_elem_splat, nblk(d.n_e) + (unsigned)sa.n_fbins, TPB, b, f->eforce, d, c->sc.friction_coeff, f->face_slot,
+                  f->keys[1], f->blk_bits, sa.n_fbins, f->g, sa);
+  else if (mode == 1)
+    kstamp_launch(c, k_stress_elem<true>, nblk(d.n_e), TPB, b, f->eforce, d, c->sc.friction_coeff, f->face_slot, f->keys[1], f->blk_bits,
+                  f->g.counters, f->g.step_id);
+  else
+    hipLaunchKernelGGL(k_stress_elem<false>, nblk(d.n_e), TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff, f->face_slot, f->keys[1],
+                       f->blk_bits, f->g.counters, f->g.step_id);
+}
+void launch_stress_trad(mpmhip_ctx *c, float dt) {
+  FastState *f = c->fast;
+  hipLaunchKernelGGL(k_stress_trad, nblk(f->d.n_t), TPB, 0, c->stream, f->buf[f->cur], f->d, c->sc, dt);
+}
+// k_g2p on the g2p chunk list: fused = with the grid stage (no grid kernel in the substep), two = the two-sweep gather of cloth scenes
+void launch_g2p(mpmhip_ctx *c, bool fused, bool two, float dt, const GridParams &gp, const BCList &bcl) {
+  FastState *f = c->fast;
+  const Dims &d = f->d;
+  const Bufs &b = f->buf[f->cur];
+#define G2P_ARGS xcd_grid(f->n_chunks_g), PT, f->chunks_g, f->n_chunks_g, b, d, dt, f->g, gp, bcl
+  if (!fused) {
+    if (two) kstamp_launch(c, k_g2p<false, true, true>, G2P_ARGS);
+    else kstamp_launch(c, k_g2p<false, false, true>, G2P_ARGS);
+  } else if (f->g.halo.slot) {
+    if (two) kstamp_launch(c, k_g2p_halo<true>, G2P_ARGS);
+    else kstamp_launch(c, k_g2p_halo<false>, G2P_ARGS);
+  } else if (f->g2p_mflag) {
+    if (two) kstamp_launch(c, k_g2p<true, true, true>, G2P_ARGS);
+    else kstamp_launch(c, k_g2p<true, false, true>, G2P_ARGS);
+  } else {
+    if (two) kstamp_launch(c, k_g2p<true, true, false>, G2P_ARGS);
+    else kstamp_launch(c, k_g2p<true, false, false>, G2P_ARGS);
+  }
+#undef G2P_ARGS
+}
+// k_g2p2g: g2p of the substep before (gp, bcl, read side rd) + stress and p2g of this one, see the kernel
+void launch_g2p2g(mpmhip_ctx *c, unsigned grid, float dt, const GridRead &rd, const SplatArgs &sa, const TradParams &tp, const GridParams &gp,
+                  const BCList &bcl) {
+  FastState *f = c->fast;
+  const Dims &d = f->d;
+  const Bufs &b = f->buf[f->cur];
+  if (f->p2g_fixed_now)
+    kstamp_launch(c, k_g2p2g<P2G_STEPS, true>, grid, PT, f->chunks, f->n_chunks, b, f->va(), d, c->sc.rpic_damping, dt, f->g, rd, sa, tp,
+                  gp, bcl);
+  else
+    kstamp_launch(c, k_g2p2g<3, false>, grid, PT, f->chunks, f->n_chunks, b, f->va(), d, c->sc.rpic_damping, dt, f->g, rd, sa, tp, gp,
+                  bcl);
+}
 
 static void grid_stage_params(mpmhip_ctx *c, const StepArgs &a, GridParams &gp, BCList &bcl);
 
@@ -3612,12 +3658,9 @@ static bool g2p2g_ok(const mpmhip_ctx *c) {
 int flush_g2p(mpmhip_ctx *c) {
   FastState *f = c->fast;
   if (f->g2p_pending) {
-    const Dims &d = f->d;
-    hipStream_t s = c->stream;
-    Bufs &b = f->buf[f->cur];
     if (f->n_chunks_g) {
       ScopedPhase ph(c, "g2p_v");
-      G2P_LAUNCH(true, f->g2p_two_pass, xcd_grid(f->n_chunks_g), PT, 0, s, f->chunks_g, f->n_chunks_g, b, d, f->pend_dt, f->g, f->pend_gp, f->pend_bcl);
+      launch_g2p(c, true, f->g2p_two_pass, f->pend_dt, f->pend_gp, f->pend_bcl);
     }
     f->g2p_pending = false;
   }
@@ -3705,7 +3748,6 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   }
   f->last_dt = dt;
   f->true_since_rebin += 1;
-  Bufs &b = f->buf[f->cur];
   // The body-face and joint splats ride along in the p2g launch as extra workgroups (SplatArgs).  With profiling on
   // (one sync per phase, like the reference's ScopedTimer) they get a launch of their own under the reference's
   // phase names: the same kernel with no particle chunks.
@@ -3795,25 +3837,16 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   if (d.n_e || (d.n_t && !trad_fused)) {  // (no empty event bracket when the stress update rides in p2g)
     ScopedPhase ph(c, "compute_stress_from_F_trial");
     if (d.n_e) {
-      if (split_splat)
-        KSTAMP_LAUNCH(k_stress_elem_splat, nblk(d.n_e) + (unsigned)sa.n_fbins, TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff, f->face_slot,
-                      f->keys[1], f->blk_bits, sa.n_fbins, f->g, sa);
-      else if (f->elem_pending)
-        KSTAMP_LAUNCH(k_stress_elem<true>, nblk(d.n_e), TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff, f->face_slot,
-                           f->keys[1], f->blk_bits, f->g.counters, f->g.step_id);
-      else
-        hipLaunchKernelGGL(k_stress_elem<false>, nblk(d.n_e), TPB, 0, s, b, f->eforce, d, c->sc.friction_coeff, f->face_slot,
-                           f->keys[1], f->blk_bits, f->g.counters, f->g.step_id);
+      launch_stress_elem(c, split_splat ? 2 : (f->elem_pending ? 1 : 0), sa);
       f->elem_pending = false;
     }
-    if (d.n_t && !trad_fused) hipLaunchKernelGGL(k_stress_trad, nblk(d.n_t), TPB, 0, s, b, d, c->sc, dt);
+    if (d.n_t && !trad_fused) launch_stress_trad(c, dt);
   }
   if (c->profiling && sa.n_extra) {
     {
       ScopedPhase ph(c, "p2g");
       if (f->n_chunks)
-        P2G_LAUNCH(false, false, xcd_grid(f->n_chunks), PT, 0, s, f->chunks, f->n_chunks, b, f->va(), d,
-                   c->sc.rpic_damping, dt, f->g, none, tp);
+        launch_p2g(c, false, false, xcd_grid(f->n_chunks), f->n_chunks, dt, none, tp);
     }
     if (sa.n_fbins) {
       ScopedPhase ph(c, "apply_Mesh_Collision_on_grid");
@@ -3821,7 +3854,7 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       only.n_mov_wg = 0;
       only.n_extra = (only.n_fbins + 7) & ~7;
       only.z_first = 1 << 30;
-      P2G_LAUNCH(false, false, (unsigned)only.n_extra, PT, 0, s, f->chunks, 0, b, f->va(), d, c->sc.rpic_damping, dt, f->g, only, tp);
+      launch_p2g(c, false, false, (unsigned)only.n_extra, 0, dt, only, tp);
     }
     if (sa.n_mov_wg) {
       ScopedPhase ph(c, "apply_Particle_Moving_on_grid");
@@ -3829,24 +3862,18 @@ static int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       only.n_fbins = 0;
       only.n_extra = (only.n_mov_wg + 7) & ~7;
       only.z_first = 1 << 30;
-      P2G_LAUNCH(false, false, (unsigned)only.n_extra, PT, 0, s, f->chunks, 0, b, f->va(), d, c->sc.rpic_damping, dt, f->g, only, tp);
+      launch_p2g(c, false, false, (unsigned)only.n_extra, 0, dt, only, tp);
     }
   } else if (do_g2p2g) {
     ScopedPhase ph(c, "g2p2g");
     const unsigned grid = xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg);
-    if (f->p2g_fixed_now)
-      KSTAMP_LAUNCH((k_g2p2g<P2G_STEPS, true>), grid, PT, 0, s, f->chunks, f->n_chunks, b, f->va(), d, c->sc.rpic_damping, dt, f->g, rd, sa, tp,
-                    f->pend_gp, f->pend_bcl);
-    else
-      KSTAMP_LAUNCH((k_g2p2g<3, false>), grid, PT, 0, s, f->chunks, f->n_chunks, b, f->va(), d, c->sc.rpic_damping, dt, f->g, rd, sa, tp,
-                    f->pend_gp, f->pend_bcl);
+    launch_g2p2g(c, grid, dt, rd, sa, tp, f->pend_gp, f->pend_bcl);
     f->g2p_pending = false;
     f->n_g2p2g += 1;
   } else {
     ScopedPhase ph(c, "p2g");
     if (f->n_chunks || sa.n_extra || sa.z.n_wg || sa.pack.n_wg)
-      P2G_LAUNCH(trad_fused, jt_tile, xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg + sa.pack.n_wg), PT, 0, s, f->chunks,
-                 f->n_chunks, b, f->va(), d, c->sc.rpic_damping, dt, f->g, sa, tp);
+      launch_p2g(c, trad_fused, jt_tile, xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg + sa.pack.n_wg), f->n_chunks, dt, sa, tp);
   }
   return MPMHIP_OK;
 }
@@ -3871,7 +3898,6 @@ static int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
   int rc;
   (void)rc; (void)d; (void)s;
   const float dt = a.dt;
-  Bufs &b = f->buf[f->cur];
   GridParams gp;
   BCList bcl;
   grid_stage_params(c, a, gp, bcl);
@@ -3890,10 +3916,7 @@ static int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
   } else {
     ScopedPhase ph(c, "g2p_v");
     if (f->n_chunks_g) {
-      if (fused)
-        G2P_LAUNCH(true, f->g2p_two_pass, xcd_grid(f->n_chunks_g), PT, 0, s, f->chunks_g, f->n_chunks_g, b, d, dt, f->g, gp, bcl);
-      else
-        G2P_LAUNCH(false, f->g2p_two_pass, xcd_grid(f->n_chunks_g), PT, 0, s, f->chunks_g, f->n_chunks_g, b, d, dt, f->g, gp, bcl);
+      launch_g2p(c, fused, f->g2p_two_pass, dt, gp, bcl);
     }
   }
   if (fused) {
