@@ -16,8 +16,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libmpmhip.so")
-SOURCES = ["api.hip", "common.hip", "baseline.hip", "fast.hip", "frames.hip"]
-HEADERS = ["ctx.hpp", "mpm_math.hpp", "bc.hpp", os.path.join("..", "..", "include", "mpmhip.h")]
+FAST_SOURCES = ["fast.hip", "resort.hip", "p2g.hip", "g2p.hip", "dist.hip"]   # the fast back end (one translation unit until round 4)
+SOURCES = ["api.hip", "common.hip", "baseline.hip"] + FAST_SOURCES + ["frames.hip"]
+HEADERS = ["ctx.hpp", "mpm_math.hpp", "bc.hpp", "fast_device.hpp", "p2g_device.hpp", "g2p_device.hpp", "fast_state.hpp", os.path.join("..", "..", "include", "mpmhip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast-honor-pragmas",
          "-Wall", "-Wno-unused-function"]
@@ -60,7 +61,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 def build_variant(name: str, flags, every: bool = False) -> str:
     """Another build of the same sources with extra compiler flags, in lib/variants/libmpmhip_<name>.so (selected at run time with
-    MPMHIP_LIB=<path>; the default library is untouched).  every = False compiles only fast.hip with the flags.  Used for the
+    MPMHIP_LIB=<path>; the default library is untouched).  every = False compiles only the fast back end (FAST_SOURCES) with the flags.  Used for the
     contraction-free witness build (tests/test_gpu_ref_golden.py) and for kernel A/B experiments (tools/build_variants.py)."""
     build()
     vdir = os.path.join(LIBDIR, "variants")
@@ -68,7 +69,7 @@ def build_variant(name: str, flags, every: bool = False) -> str:
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     for src in SOURCES:
-        if src != "fast.hip" and not every:
+        if src not in FAST_SOURCES and not every:
             objs.append(os.path.join(OBJDIR, src.replace(".hip", ".o")))
             continue
         obj = os.path.join(vdir, f"{src[:-4]}_{name}.o")

@@ -96,12 +96,12 @@ def test_product_never_imports_the_oracle():
 
 def test_rccl_stand_in_exports_what_the_library_binds():
     """tests/mock_rccl (test infrastructure for the multi-rank GPU tests) must offer every RCCL entry point that
-    csrc/fast.hip resolves with dlsym -- a new binding without a stand-in would make those tests fall back silently."""
+    csrc/dist.hip resolves with dlsym -- a new binding without a stand-in would make those tests fall back silently."""
     import re
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = open(os.path.join(root, "mpmavatar_amd", "csrc", "fast.hip")).read()
+    src = "".join(open(os.path.join(root, "mpmavatar_amd", "csrc", f)).read() for f in ("dist.hip", "fast_state.hpp", "fast.hip"))
     bound = set(re.findall(r'sym\("(nccl\w+)"\)', src))
     assert len(bound) == 10, bound
     sys.path.insert(0, os.path.join(root, "tests", "mock_rccl"))
