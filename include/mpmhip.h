@@ -114,7 +114,7 @@ typedef struct {
                                    Must stay 0: non-zero means particles outran the re-sorts (fixed-interval mode
                                    with an interval too long for their speed) and the results are not valid */
   int64_t g2p2g_launches;       /* fast mode, scenes of traditional particles only: substep boundaries that ran as ONE launch
-                                   (g2p of substep n + stress and p2g of substep n + 1, csrc/fast.hip k_g2p2g) */
+                                   (g2p of substep n + stress and p2g of substep n + 1, csrc/g2p.hip k_g2p2g) */
 } mpmhip_stats;
 
 /* ---- lifetime ----------------------------------------------------------------- */
@@ -318,7 +318,7 @@ int mpmhip_cov_from_F(int32_t device, void *stream, const float *particle_F_tria
 /* dense reference-layout copies of grid_m [G^3], grid_v_in [G^3*3], grid_v_out [G^3*3] as they
  * stand after the last substep's grid stage ([dev] outputs, any may be NULL).  Synchronous. */
 int mpmhip_export_grid(mpmhip_ctx *ctx, float *grid_m, float *grid_v_in, float *grid_v_out);
-/* performance experiments only (kernel ablations, MPMHIP_DBG bit mask of csrc/fast.hip; most bits make the results wrong).
+/* performance experiments only (kernel ablations, MPMHIP_DBG bit mask of csrc/fast_device.hpp; most bits make the results wrong).
  * The kernel switches exist only in -DMPMHIP_DEBUG=1 builds; the production build accepts bit 64 (host-side) alone. */
 int mpmhip_set_debug_flags(mpmhip_ctx *ctx, int32_t flags);
 int mpmhip_debug_counter(mpmhip_ctx *ctx, int32_t index, int64_t *out); /* device-side experiment counters, synchronous */
@@ -329,7 +329,7 @@ int mpmhip_debug_counter(mpmhip_ctx *ctx, int32_t index, int64_t *out); /* devic
 int mpmhip_debug_wgtrace(mpmhip_ctx *ctx, int32_t kernel, uint64_t *out, int32_t max_wg);
 /* the sort of the re-sort on its own (tests/test_gpu_sort.py): stable sort of n 32-bit keys by their low `bits` bits
  * ([dev] keys_in; bits above `bits` must be zero) -> [dev] keys_out (sorted), order_out (source index of each sorted key).
- * Uses the path the context's re-sorts use (csrc/fast.hip k_rs_*; rocPRIM with MPMHIP_SORT=rocprim or n > 2^21).
+ * Uses the path the context's re-sorts use (csrc/resort.hip k_rs_*; rocPRIM with MPMHIP_SORT=rocprim or n > 2^21).
  * Synchronous; fast mode only. */
 int mpmhip_debug_sort(mpmhip_ctx *ctx, const uint32_t *keys_in, int32_t n, int32_t bits, uint32_t *keys_out, int32_t *order_out);
 /* counts for the algorithmic-bytes formula; synchronous, runs small count kernels */

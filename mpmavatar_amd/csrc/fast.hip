@@ -333,7 +333,7 @@ static bool g2p2g_ok(const mpmhip_ctx *c) {
   // (two wavefronts per SIMD = 512 workgroup slots; either half alone needs 116-124, profiles/r04_experiments.md), which a scene
   // of more chunks pays for with more than it saves (block-512k -8 %, garment-120k-iso -11 %; cube-8k +23 %)
   return f->g2p2g && f->nbuf == 3 && !f->dist && !c->profiling && d.n_e == 0 && d.n_v == 0 && d.n_t > 0 && f->fuse_trad && f->fuse_grid &&
-         !f->g.halo.slot && !f->g2p_mflag && !(MPMHIP_DEBUG && f->g.dbg) && f->n_chunks <= f->g2p2g_max_chunks;
+         !f->g.halo.slot && !f->g2p_mflag && !(MPMHIP_DEBUG && f->g.dbg) && f->n_chunks > 0 && f->n_chunks <= f->g2p2g_max_chunks;
 }
 // the deferred g2p of the last substep as a launch of its own (anything that reads or re-orders the particles comes here first),
 // and the clearing of the buffer the last fused launch read

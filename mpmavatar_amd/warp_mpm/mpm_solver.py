@@ -399,9 +399,15 @@ class MPMWARP(object):
         Ft, cov0 = mpm_state.particle_F_trial, mpm_state.particle_cov   # reading F_trial writes the solver's results back first
         if cov0 is None or cov0.numel() < 6 * n:
             raise RuntimeError("export_particle_cov_to_torch: particle_cov holds fewer than 6 * n_no_vertices values")
+        # the caller ASSIGNS particle_cov (state.particle_cov = ...): whatever it is, the kernel gets contiguous fp32 on F_trial's device
+        if cov0.dtype != torch.float32 or cov0.device != Ft.device or not cov0.is_contiguous():
+            cov0 = cov0.to(device=Ft.device, dtype=torch.float32).contiguous()
+        if torch.device(device).type == "cuda" and torch.device(device) != Ft.device and torch.device(device).index is not None:
+            raise RuntimeError(f"export_particle_cov_to_torch: the state lives on {Ft.device}, not on {device}")
         new_cov = torch.zeros(n * 6, dtype=torch.float32, device=Ft.device)
         if n:
             dev = Ft.device
+            self.synchronize()   # F_trial was written back on the context's stream; the launch below goes on torch's current stream
             rc = self._lib.mpmhip_cov_from_F(dev.index or 0, torch.cuda.current_stream(dev).cuda_stream, Ft.data_ptr(),
                                              cov0.data_ptr(), n, new_cov.data_ptr())
             if rc != 0:

@@ -132,7 +132,7 @@ def test_in_library_rccl_transport_single_rank():
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene,steps", [("garment", 40), ("sheet", 60), ("demo", 30)])
 def test_in_library_rccl_transport_two_ranks(scene, steps):
-    """The RCCL send/recv group between REAL peers (fast.hip: fast_rccl_steps): needs two GPUs, skipped on a one-GPU box
+    """The RCCL send/recv group between REAL peers (dist.hip: fast_rccl_steps): needs two GPUs, skipped on a one-GPU box
     (RCCL refuses two ranks on one device) -- the first multi-GPU machine that sees this repository runs it."""
     import torch
     if torch.cuda.device_count() < 2:
@@ -167,7 +167,7 @@ def test_in_library_loop_with_several_ranks(world, scene, steps, rebin, ghost_g2
     context's trajectory.
     halo = "peer": the halos go through peer-mapped buffers (HIP IPC between the processes, flags in the receiver's
     fine-grained memory, handshake at set-up) and the substep has NO halo kernels: the pack rides in the p2g launch, g2p adds
-    the neighbour's share while it stages its tile (PackArgs / HaloIn in csrc/fast.hip); "peer-unfused": the same buffers with
+    the neighbour's share while it stages its tile (PackArgs / HaloIn in csrc/fast_device.hpp); "peer-unfused": the same buffers with
     the separate pack / add kernels (MPMHIP_DIST_FUSED_HALO=0); "rccl": through the send/recv groups."""
     import re
     out = _launch(world, "gpu", scene, steps, extra_env=_mock_rccl_env(MPMHIP_TEST_REBIN=rebin, MPMHIP_DIST_GHOST_G2P=ghost_g2p,

@@ -1,4 +1,4 @@
-"""G2P2G (csrc/fast.hip k_g2p2g): scenes of traditional particles run one launch per substep -- g2p of substep n and stress + p2g of
+"""G2P2G (csrc/g2p.hip k_g2p2g): scenes of traditional particles run one launch per substep -- g2p of substep n and stress + p2g of
 substep n + 1 in the same workgroup, the g2p of the last substep pending until something else needs the particles.
 
 Checked here: the fused sequence against the two-launch sequence (MPMHIP_G2P2G=0) and against the CPU oracle, with reads of the

@@ -5,7 +5,7 @@ cloth sheet with a sand block lying on it (the same 4^3 blocks, hence the same c
 internal force alike -- scaled so that (sand mass) / (cloth vertex mass) is 1e+6 ... 1e-6.  Measured (tools/gpu/mass_ratio.py, 60
 substeps, velocity of the LIGHT class against the oracle): ratio 1e+4 / 1e-4 fixed point 2.3e-4 / 9.6e-4 = fp64 tile 1.7e-4 / 9.4e-4;
 ratio 1e+6 / 1e-6 fixed point 1.1e-2 / 2.5e-3 against 8.6e-5 / 1.6e-4 -- so a scene whose masses span more than 1e+5 is given the
-fp64 tile at import (csrc/fast.hip rebin(): mass span), and this test pins both sides of that switch."""
+fp64 tile at import (csrc/resort.hip rebin(): mass span), and this test pins both sides of that switch."""
 import os
 
 import numpy as np

@@ -1,4 +1,4 @@
-"""The sort of the re-sort (csrc/fast.hip k_rs_hist / k_rs_scan / k_rs_scatter) on its own and inside the loop.
+"""The sort of the re-sort (csrc/resort.hip k_rs_hist / k_rs_scan / k_rs_scatter) on its own and inside the loop.
 
 A re-sort orders the particles by class | state | block | cell with a STABLE sort of (key, index) pairs; the radix passes
 written for it must produce the permutation a stable reference sort produces, for every size around the tile and slice

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Kernel A/B experiments: build libmpmhip.so variants that differ in -D switches of csrc/fast.hip.
+"""Kernel A/B experiments: build libmpmhip.so variants that differ in -D switches of the fast back end (csrc/fast.hip, resort.hip, p2g.hip, g2p.hip, dist.hip and their headers).
 
     python tools/build_variants.py name1:-DFOO=1,-DBAR=2 name2:-DFOO=0 ...
 

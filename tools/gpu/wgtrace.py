@@ -4,7 +4,7 @@
 
     MPMHIP_LIB=mpmavatar_amd/lib/variants/libmpmhip_dbg.so python tools/gpu/wgtrace.py <scene> [pre_advance] [tag]
 
-The -DMPMHIP_DEBUG=1 build stamps the 100 MHz constant clock at fixed points of every workgroup (WGT() in csrc/fast.hip; a stamp
+The -DMPMHIP_DEBUG=1 build stamps the 100 MHz constant clock at fixed points of every workgroup (WGT() in csrc/fast_device.hpp; a stamp
 waits for all outstanding memory operations of wavefront 0 first, so it perturbs the kernel a little: compare the span with the
 rocprofv3 average).  Prints, per kernel: span, workgroups by kind, phase durations (median / p90), how many workgroups run
 concurrently over time, and the start-time structure ("rounds").  Saves the raw stamps to gpurun_out/wgtrace_<tag>_<scene>.npz."""
