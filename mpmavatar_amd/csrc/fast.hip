@@ -245,11 +245,17 @@ int fast_init(mpmhip_ctx *c) {
   if (const char *e = getenv("MPMHIP_FUSE_TRAD")) f->fuse_trad = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_DIST_FUSED_HALO")) f->fused_want = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_SPLAT_FIRST_MAX")) f->splat_first_max = atoi(e);
-  f->g.stagger = 0; f->g.stagger_groups = 2; f->g.stagger_first = 0;
-  if (const char *e = getenv("MPMHIP_P2G_STAGGER")) {  // "units[,groups[,first]]": units of 1024 cycles per group step
+  // p2g's first round staggered by wave slot -- 2 x 1024 cycles per step, 5 groups, the first 1,280 workgroups -- where the launch is
+  // more than two rounds of workgroups (decided per launch in step_phase_a): the headline scene +1.1 % at t = 0 and draped (round 4,
+  // three alternating runs: 16.06-16.08 k -> 16.21-16.29 k; round 3 had measured the same and left it off because a launch of less
+  // than one round loses up to 20 %).  MPMHIP_P2G_STAGGER="units[,groups[,first]]" forces a setting for every launch, "0" none.
+  f->g.stagger = 0; f->g.stagger_groups = 5; f->g.stagger_first = 1280;
+  f->stagger_auto = 2;
+  if (const char *e = getenv("MPMHIP_P2G_STAGGER")) {
     int u = 0, gr = 2, first = 1280;
     sscanf(e, "%d,%d,%d", &u, &gr, &first);
     f->g.stagger = std::max(0, u); f->g.stagger_groups = std::max(1, gr); f->g.stagger_first = std::max(0, first);
+    f->stagger_auto = -1;  // forced
   }
   if (const char *e = getenv("MPMHIP_G2P_MFLAG")) f->g2p_mflag = atoi(e) != 0;
   MPM_HIP_CHECK(c, hipHostMalloc((void **)&f->h_pin, 64 * sizeof(int), hipHostMallocDefault));
@@ -516,6 +522,7 @@ int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     sa.pack.target = f->pack_target;
   }
   f->g.step_id = (int)++f->sig_seq;
+  if (f->stagger_auto >= 0) f->g.stagger = (f->n_chunks >= 2 * 1280 && !c->profiling) ? f->stagger_auto : 0;
   if (d.n_e || (d.n_t && !trad_fused)) {  // (no empty event bracket when the stress update rides in p2g)
     ScopedPhase ph(c, "compute_stress_from_F_trial");
     if (d.n_e) {

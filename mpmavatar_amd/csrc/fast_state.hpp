@@ -211,6 +211,7 @@ struct FastState {
   // (k_g2p2g), or flush_g2p() does with a plain k_g2p when anything else needs the particles first
   bool g2p2g = true;           // MPMHIP_G2P2G=0: two launches per substep for traditional-only scenes as before
   int g2p2g_max_chunks = 512;  // MPMHIP_G2P2G_MAX
+  int stagger_auto = 2;        // p2g first-round stagger units for chunk lists of at least two rounds; -1: forced by MPMHIP_P2G_STAGGER
   int split_splat_max_chunks = 1024;  // MPMHIP_SPLIT_SPLAT_MAX
   bool split_splat = true;     // body-face splat: pass 0 in the stress launch, pass 1 in the p2g launch (MPMHIP_SPLIT_SPLAT=0: both in p2g)
   int64_t n_g2p2g = 0;         // fused launches so far (mpmhip_stats)
