@@ -414,9 +414,10 @@ def _main(out_stream):
                                       "local_particles": int(box["ss"].shard.scene.n_particles), "measured_fraction_of_bound": out["value"] * us / 1e6,
                                       "note": "rank 0's shard as a single-GPU scene without any exchange; the sharded run cannot beat it"}
                 del fsim
-            barrier()
         except Exception as e:  # noqa: BLE001 - the headline line must come out whatever happens here
             out["shard_floor"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            barrier()               # (every rank, whatever happened on rank 0: the others wait here)
     if sharded and world > 1 and not weak_only and not args.no_weak and (args.scene == "sheet-500k" or args.weak_n):
         # the regime the slab decomposition is made for: the same per-rank work at every N (one sheet's worth of particles per
         # rank: N stacked copies of the headline sheet in the same grid).  Reported beside the strong-scaling headline value.
