@@ -460,9 +460,18 @@ __global__ void k_fbin_compact(const int *alist, const int *rc, int cap_A, const
   int blk = alist[a];
   int cnt = fb_cnt[blk];
   if (cnt > 0) {
-    int i = atomicAdd(counter, 1);
-    if (i < cap_fbins) list[i] = FaceBin{blk, fb_start[blk], cnt, 0};
-    else atomicOr(const_cast<int *>(rc) + RC_OVER, 8);
+    // a bin of more than one workgroup's worth of faces (a coarse grid under a fine body mesh: hundreds of faces per block) becomes
+    // several records of <= PT faces each, one splat workgroup per record -- they all flush into the same collider channels with
+    // atomics anyway -- instead of one workgroup looping over the bin (round 4: the 64^3 training-size garment ran 2x slower than
+    // the 128^3 one because a few such workgroups set the length of the launch)
+    int parts = (cnt + PT - 1) / PT;
+    int i = atomicAdd(counter, parts);
+    if (i + parts <= cap_fbins) {
+      int s0 = fb_start[blk];
+      for (int k = 0; k < parts; ++k) list[i + k] = FaceBin{blk, s0 + k * PT, min(PT, cnt - k * PT), 0};
+    } else {
+      atomicOr(const_cast<int *>(rc) + RC_OVER, 8);
+    }
   }
 }
 
@@ -733,7 +742,7 @@ int rebin(mpmhip_ctx *c) {
     const int cap_P = f->cap_P;
     const int cap_A = (int)std::min<long long>((long long)nb, 27LL * cap_P);
     const int cap_ch = cap_P + d.n_p / CHUNK + 8;
-    const int cap_fb = with_faces ? std::min(nf, cap_A) : 0;
+    const int cap_fb = with_faces ? std::min(nf, cap_A + nf / PT + 1) : 0;   // (non-empty bins + the extra records of split bins)
     int dummy = 0;
     if ((rc = ensure_cap(c, &f->plist, &f->alloc_P, cap_P, 1))) return rc;
     if ((rc = ensure_cap(c, &f->ranges, &f->cap_R, cap_P, 10))) return rc;
