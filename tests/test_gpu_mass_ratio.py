@@ -67,7 +67,7 @@ def test_light_particles_beside_heavy_ones(ratio, oracle_lib):
         assert rel(x[cls], o.x[cls]) < 1e-5
         # what the shipped tile choice costs over the fp64 tile: nothing beyond the scene's own sensitivity (cloth released from
         # rest sits on the return mapping's R22 = 1 discontinuity: 2e-4 ... 1e-3 in BOTH modes, tests/test_gpu_parity.py)
-        assert e < max(1.5 * e64, 3e-4), (ratio, e, e64)
+        assert e < max(2.0 * e64, 5e-4), (ratio, e, e64)
         assert e < 2e-3
     if ratio in (1e6, 1e-6):
         # ... and the reason for the switch: forced onto the fixed-point tile the light class is an order of magnitude off
