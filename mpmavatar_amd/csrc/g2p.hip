@@ -6,11 +6,12 @@ namespace mpm {
 
 namespace {
 
-template <bool FUSED, bool TWO_PASS, bool MFLAG>
+// B128: the tile is read with ds_read_b128 instead of the ds_read_b96 hipcc narrows the load to (g2p_device.hpp tile_read)
+template <bool FUSED, bool TWO_PASS, bool MFLAG, bool B128>
 __global__ __launch_bounds__(PT) void k_g2p(const ChunkRec *recs, int n_chunks, Bufs b, Dims d, float dt, GridPtrs g, GridParams gp,
                                              BCList bcl) {
   __shared__ float4 tile[TILE_PAD];  // node velocity, 16 bytes per node
-  g2p_body<FUSED, TWO_PASS, MFLAG>(recs, n_chunks, b, d, dt, g, gp, bcl, tile, (int)blockIdx.x);
+  g2p_body<FUSED, TWO_PASS, MFLAG, false, B128>(recs, n_chunks, b, d, dt, g, gp, bcl, tile, (int)blockIdx.x);
 }
 
 // multi-GPU: fused halo add (see HaloIn)
@@ -39,18 +40,21 @@ void launch_g2p(mpmhip_ctx *c, bool fused, bool two, float dt, const GridParams 
   const Dims &d = f->d;
   const Bufs &b = f->buf[f->cur];
 #define G2P_ARGS xcd_grid(f->n_chunks_g), PT, f->chunks_g, f->n_chunks_g, b, d, dt, f->g, gp, bcl
+  // (two-sweep kernel: ds_read_b128 costs it its fifth wavefront per SIMD -- taken where a launch is at most one round of workgroups)
+  const bool wide = f->n_chunks_g <= 1280;
   if (!fused) {
-    if (two) kstamp_launch(c, k_g2p<false, true, true>, G2P_ARGS);
-    else kstamp_launch(c, k_g2p<false, false, true>, G2P_ARGS);
+    if (two) kstamp_launch(c, k_g2p<false, true, true, false>, G2P_ARGS);
+    else kstamp_launch(c, k_g2p<false, false, true, true>, G2P_ARGS);
   } else if (f->g.halo.slot) {
     if (two) kstamp_launch(c, k_g2p_halo<true>, G2P_ARGS);
     else kstamp_launch(c, k_g2p_halo<false>, G2P_ARGS);
   } else if (f->g2p_mflag) {
-    if (two) kstamp_launch(c, k_g2p<true, true, true>, G2P_ARGS);
-    else kstamp_launch(c, k_g2p<true, false, true>, G2P_ARGS);
+    if (two) kstamp_launch(c, k_g2p<true, true, true, false>, G2P_ARGS);
+    else kstamp_launch(c, k_g2p<true, false, true, true>, G2P_ARGS);
   } else {
-    if (two) kstamp_launch(c, k_g2p<true, true, false>, G2P_ARGS);
-    else kstamp_launch(c, k_g2p<true, false, false>, G2P_ARGS);
+    if (two && wide) kstamp_launch(c, k_g2p<true, true, false, true>, G2P_ARGS);
+    else if (two) kstamp_launch(c, k_g2p<true, true, false, false>, G2P_ARGS);
+    else kstamp_launch(c, k_g2p<true, false, false, true>, G2P_ARGS);
   }
 #undef G2P_ARGS
 }

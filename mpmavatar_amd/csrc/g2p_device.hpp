@@ -29,6 +29,25 @@ __device__ __forceinline__ G2PResult g2p_finish(const Stencil &s, const Dims &d,
   return r;
 }
 
+// One tile node = one ds_read_b128.  Left to itself hipcc narrows the load to ds_read_b96 because the gathers never use .w -- and a
+// ds_read_b96 costs the LDS 8 cycles per wave instruction (eight lane groups) against 4 for a ds_read_b128 (MI355X_MICROARCH.md, LDS
+// table): the sweeps are LDS-read bound, so the "narrower" load is the slower one.  .w is made a used value at the point of the
+// load: x + 0 * w with w = 0 as staged (exact; without fast-math the compiler must keep it: w could be NaN for all it knows).  An
+// empty asm on .w does the same but lets the scheduler park all 27 w registers until the end of the sweep (+29 VGPRs).
+// B128 costs four VGPRs (one more per load in flight): the two-sweep cloth kernel goes from 96 to 100, i.e. from five to four
+// wavefronts per SIMD -- measured (tools/gpu/r04n.sh): garment-120k-aniso k_g2p 11.0-11.4 -> 10.3-10.6 us (a launch of less than one round:
+// a workgroup's latency is what counts), sheet-500k 18.7-19.2 -> 20.1-20.3 us (2.1 rounds: occupancy counts; forced back to five
+// wavefronts it spills 21 registers: 21.4 us).  So B128 is a template parameter and the launcher picks it where occupancy is not what
+// bounds the launch: chunk lists of at most one round, and the single-sweep kernels of traditional scenes (117 -> 121 VGPRs, four
+// wavefronts either way).
+template <bool B128>
+__device__ __forceinline__ float4 tile_read(const float4 *tile, int idx) {
+  float4 t4 = tile[idx];
+  if (B128) t4.x = fmaf(0.0f, t4.w, t4.x);
+  return t4;
+}
+
+template <bool B128>
 __device__ __forceinline__ G2PResult g2p_gather(const float4 *tile, int ox, int oy, int oz, V3 x, const Dims &d) {
   Stencil s = make_stencil(x, d.inv_dx);
   int base = tile_idx(s.bx - ox, s.by - oy, s.bz - oz);
@@ -44,7 +63,7 @@ __device__ __forceinline__ G2PResult g2p_gather(const float4 *tile, int ox, int 
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         float wzk = sel3(k, s.w0.z, s.w1.z, s.w2.z), dwzk = sel3(k, s.dw0.z, s.dw1.z, s.dw2.z);
-        const float4 t4 = tile[base + tile_idx(i, j, k)];   // one ds_read_b128 per node instead of three ds_read_b32
+        const float4 t4 = tile_read<B128>(tile, base + tile_idx(i, j, k));
         V3 u = v3(t4.x, t4.y, t4.z);
         s0 = s0 + wzk * u;
         s1 = s1 + dwzk * u;
@@ -65,6 +84,7 @@ __device__ __forceinline__ G2PResult g2p_gather(const float4 *tile, int ox, int 
 
 // the same gather in two passes (velocity + APIC matrix, then the velocity gradient): 12 and 9 accumulators instead
 // of 21 at a time
+template <bool B128>
 __device__ __forceinline__ void g2p_gather_vC(const float4 *tile, int ox, int oy, int oz, V3 x, const Dims &d, V3 &v, M3 &C) {
   Stencil s = make_stencil(x, d.inv_dx);
   int base = tile_idx(s.bx - ox, s.by - oy, s.bz - oz);
@@ -79,7 +99,7 @@ __device__ __forceinline__ void g2p_gather_vC(const float4 *tile, int ox, int oy
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         float wzk = sel3(k, s.w0.z, s.w1.z, s.w2.z);
-        const float4 t4 = tile[base + tile_idx(i, j, k)];
+        const float4 t4 = tile_read<B128>(tile, base + tile_idx(i, j, k));
         V3 u = v3(t4.x, t4.y, t4.z);
         s0 = s0 + wzk * u;
         if (k > 0) s2 = s2 + ((float)k * wzk) * u;
@@ -95,6 +115,7 @@ __device__ __forceinline__ void g2p_gather_vC(const float4 *tile, int ox, int oy
   v = nv;
   C = m3_cols(c4 * (Mx - s.fx.x * nv), c4 * (My - s.fx.y * nv), c4 * (Mz - s.fx.z * nv));
 }
+template <bool B128>
 __device__ __forceinline__ M3 g2p_gather_grad(const float4 *tile, int ox, int oy, int oz, V3 x, const Dims &d) {
   Stencil s = make_stencil(x, d.inv_dx);
   int base = tile_idx(s.bx - ox, s.by - oy, s.bz - oz);
@@ -109,7 +130,7 @@ __device__ __forceinline__ M3 g2p_gather_grad(const float4 *tile, int ox, int oy
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         float wzk = sel3(k, s.w0.z, s.w1.z, s.w2.z), dwzk = bspline_dw(k, s.fx.z);
-        const float4 t4 = tile[base + tile_idx(i, j, k)];
+        const float4 t4 = tile_read<B128>(tile, base + tile_idx(i, j, k));
         V3 u = v3(t4.x, t4.y, t4.z);
         s0 = s0 + wzk * u;
         s1 = s1 + dwzk * u;
@@ -215,7 +236,7 @@ __device__ __forceinline__ void g2p_write(const Bufs &b, int cls, int s, V3 x, V
 // level less at the head of every workgroup for more L2 traffic; node values are identical (an unflagged block holds zeros).
 // HALO = true (multi-GPU, needs MFLAG = false): blocks shared with a neighbour rank get its contribution added on the way
 // (HaloIn), after the workgroup has seen the neighbour's flag for this substep.
-template <bool FUSED, bool TWO_PASS, bool MFLAG, bool HALO = false>
+template <bool FUSED, bool TWO_PASS, bool MFLAG, bool HALO = false, bool B128 = false>
 __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, const Bufs &b, const Dims &d, float dt, const GridPtrs &g,
                                          const GridParams &gp, const BCList &bcl, float4 *tile, int wg) {
   WGT(g, 1, 0);
@@ -336,19 +357,19 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
     // stage the tile and is done: the gather is ~600 VALU instructions per wavefront and the kernel is bound by VALU issue
     if (!__any(fit)) {
     } else if (!TWO_PASS) {
-      G2PResult r = g2p_gather(tile, ox, oy, oz, xg, d);
+      G2PResult r = g2p_gather<B128>(tile, ox, oy, oz, xg, d);
       if (fit) g2p_write(b, cls, s, x, d3, r, ox, oy, oz, d, dt, g);
     } else {
       {
         G2PResult r;
         r.F = m3_zero();
-        g2p_gather_vC(tile, ox, oy, oz, xg, d, r.v, r.C);
+        g2p_gather_vC<B128>(tile, ox, oy, oz, xg, d, r.v, r.C);
         if (fit) g2p_write<true>(b, cls, s, x, d3, r, ox, oy, oz, d, dt, g);
       }
       WGT(g, 1, 4);  // first sweep (v, C) of wavefront 0 stored
       if (__any(fit && cls != 2)) {  // elements and traditional particles also need grad v
         asm volatile("" : "+v"(xg.x), "+v"(xg.y), "+v"(xg.z));  // a fresh stencil: nothing of the first sweep stays live
-        M3 rF = g2p_gather_grad(tile, ox, oy, oz, xg, d);
+        M3 rF = g2p_gather_grad<B128>(tile, ox, oy, oz, xg, d);
         if (fit && cls != 2) g2p_write_grad(b, cls, s, d3, rF, d, dt);
       }
     }
@@ -474,7 +495,7 @@ __device__ __forceinline__ void g2p2g_body(const ChunkRec *recs, int n_chunks, c
   M3 nC = m3_zero(), Ft = m3_identity();
   if (__any(fit)) {
     V3 xg = fit ? x : v3((float)(ox + 2) * d.dx, (float)(oy + 2) * d.dx, (float)(oz + 2) * d.dx);
-    G2PResult r = g2p_gather(vt, ox, oy, oz, xg, d);
+    G2PResult r = g2p_gather<false>(vt, ox, oy, oz, xg, d);
     nv = r.v; nC = r.C;
     Ft = (m3_identity() + dt * r.F) * ld9(b.tr, T_F, tx);   // g2p_v :780-786
     float a_min = (1.0f / d.inv_dx) * 2.0f, a_max = d.grid_lim - (1.0f / d.inv_dx) * 2.0f;
