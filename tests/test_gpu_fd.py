@@ -62,3 +62,36 @@ def test_fd_variants_sharded_over_ranks(world):
     r = subprocess.run(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert f"fd sharded over {world} ranks" in r.stdout
+
+
+def test_fd_simulation_against_the_oracle(oracle_lib):
+    """VERDICT r3 weak point 10: the tests above compare the HIP path with itself.  Here one finite-difference variant -- reset to the
+    first frame, density D, Young's modulus 100 E, rest pose scaled by H, three frames of 30 substeps with the body advected inside the
+    fused call (train_material_params.py:584-641) -- is repeated by the CPU oracle with the same inputs, and the per-frame cloth
+    vertices (what the loss is computed from) and the loss itself are compared."""
+    from mpmavatar_amd import garment
+    from oracle.scene_adapter import oracle_from_scene
+    m = _problem(False)
+    sc = m.sc
+    D, E, H = 1.05, 0.9, 1.005
+    fd.capture(m, 1.0, 1.0, 1.0)                      # targets from the HIP path at the 'true' parameters
+    rec = []
+    loss_hip = m.simulate(m.sims[0], D, E, H, record=rec)
+    o = oracle_from_scene(sc)
+    scaled = sc.x[sc.n_elements + sc.n_traditional:].astype(np.float32) * np.array([[1.0, H, 1.0]], np.float32)
+    o.R_inv[:] = garment.compute_rest_dir_inv_from_vf(scaled, sc.faces)
+    o.density[:] = D
+    o.mass[:] = o.density * o.vol
+    o.E[:] = E * 100.0
+    o.prepare_mu_lam()
+    shift, scale = m.shift.cpu().numpy(), m.scale
+    loss_or, worst = 0.0, 0.0
+    for f, got in zip(m.frames, rec):
+        o.p2g2p_n(m.substep_size, m.substeps, mesh_x=f.mesh_x, mesh_v=f.mesh_v, joint_verts_v=f.joint_verts_v, joint_faces_v=f.joint_faces_v)
+        cloth = (o.x[sc.n_elements:] - shift) / scale
+        worst = max(worst, float(np.abs(got - cloth).max() / np.abs(cloth).max()))
+        loss_or += float(((cloth - f.target) ** 2).mean())
+    loss_or /= len(m.frames)
+    assert worst < 1e-5, worst                        # positions after 30 / 60 / 90 substeps
+    assert loss_hip > 0 and abs(loss_hip - loss_or) < 2e-3 * loss_or, (loss_hip, loss_or)
+    m.close()
