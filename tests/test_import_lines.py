@@ -50,3 +50,12 @@ def test_facade_from_the_package():
     code = "from warp_mpm import wp; import torch; t = torch.ones(2); assert wp.to_torch(t) is t; print('ok')"
     r = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_package_import_asks_for_one_hardware_queue_per_stream():
+    """Importing the package sets GPU_MAX_HW_QUEUES for the four-context FD step unless the user chose a value (mpmavatar_amd/__init__.py)."""
+    import subprocess, sys
+    code = "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import mpmavatar_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip() == "8"
+    code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '2'; import mpmavatar_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip() == "2"
