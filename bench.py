@@ -162,6 +162,9 @@ def _main(out_stream):
     ap.add_argument("--weak-grid", type=int, default=256)
     ap.add_argument("--force-dist", action="store_true", help="diagnostics: run the sharded driver even with one rank "
                     "(launch under torch.distributed.run --nproc-per-node 1)")
+    ap.add_argument("--watchdog", type=int, default=1500, help="N > 1: seconds after which a rank that is still running dumps its "
+                    "Python stacks to stderr and exits (a rank that died leaves the others in a collective for RCCL's 10 minutes per "
+                    "call otherwise); 0 = off")
     args = ap.parse_args()
 
     import torch
@@ -193,6 +196,9 @@ def _main(out_stream):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if world > 1 and args.watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)   # (stderr; the JSON line is the only thing on stdout)
     if os.environ.get("MPMHIP_DIST_BACKEND") == "gloo":
         local_rank = local_rank % torch.cuda.device_count()  # ranks may share a GPU in the gloo test mode
     torch.cuda.set_device(local_rank)
@@ -207,7 +213,9 @@ def _main(out_stream):
         from mpmavatar_amd import dist as mdist
         backend = os.environ.get("MPMHIP_DIST_BACKEND", "nccl")  # "gloo": host-staged exchange (2 ranks on 1 GPU tests)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(dev))
+            import datetime
+            dist.init_process_group("nccl", device_id=torch.device(dev),
+                                    timeout=datetime.timedelta(seconds=min(args.watchdog, 600) if args.watchdog > 0 else 600))
         else:
             dist.init_process_group(backend)
         sim = mdist.build_sharded(sc, dev, rank, world, rebin_interval=args.rebin_interval)
