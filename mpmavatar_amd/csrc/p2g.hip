@@ -47,7 +47,7 @@ __global__ __launch_bounds__(TPB) void k_stress_elem_splat(Bufs b, F3 *ef, Dims 
 template <int STEPS, bool TRAD, bool JT, bool FX>
 __global__ __launch_bounds__(PT) void k_p2g(const ChunkRec *recs, int n_chunks, Bufs b, VAdj va, Dims d, float rpic, float dt,
                                              GridPtrs g, SplatArgs sa, TradParams tp) {
-  __shared__ double tile[4 * TILE_PAD];
+  __shared__ double tile[P2G_TILE_DOUBLES];  // (the one-pass small-bin splat needs 7 * 536 doubles, everything else 4 * TILE_PAD)
   __shared__ int esc[CHUNK];
   __shared__ int esc_n;
   __shared__ float red[8];

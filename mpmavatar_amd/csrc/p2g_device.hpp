@@ -567,6 +567,12 @@ __device__ __forceinline__ void col_splat_flush(const double *tile, int ox, int 
   }
 }
 
+// One-pass form of the small-bin splat (PASSES == 3): all seven collider channels (weight, weight * velocity, weight * normal) in
+// one tile of 8 x 8 x 8 nodes at strides (67, 8, 1) -- 2 * (67 i + 8 j + k) mod 64 puts 25 of a face's 27 nodes into different bank
+// pairs -- so that a bin costs one clearing, one scatter and one flush instead of two of each with five barriers in between.  The
+// workgroup tile is 7 * 536 doubles = 30 KB instead of 24.6 KB: still five workgroups per CU (VGPR-bound at five).
+constexpr int SPLAT7_SI = 67, SPLAT7_SJ = 8, SPLAT7_S = 536;  // 7*67 + 7*8 + 7 = 532 < 536
+constexpr int P2G_TILE_DOUBLES = 7 * SPLAT7_S > 4 * TILE_PAD ? 7 * SPLAT7_S : 4 * TILE_PAD;
 constexpr int SPLAT_SMALL = 32;  // faces per bin up to which the splat workgroup maps lanes to (face, node) pairs
 // PASSES: bit 0 = the weight / velocity pass (w, w v_face: collider channels 0-3, sets col_flag), bit 1 = the normal pass (w n:
 // channels 4-6).  3 = both in one workgroup, as rounds 1-3 did.  Round 4: in cloth scenes the two passes ride in DIFFERENT
@@ -599,6 +605,97 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
     // second (normal) pass through the four-channel tile.
     const int fi = l >> 5, n = l & 31;
     const int ni = n / 9, nj = (n / 3) % 3, nk = n % 3;
+    if (PASSES == 3) {  // one pass through a seven-channel tile (see SPLAT7_S)
+      for (int t = l; t < 7 * SPLAT7_S; t += PT) tile[t] = 0.0;
+      __syncthreads();
+      WGT(g, 0, 2);  // (debug build: bin record, block flags, tile cleared)
+      // Two steps' loads in flight at a time, then their LDS atomics; the global atomics of the out-of-margin lanes wait until all
+      // steps are through.  With those inside the load loop (they may alias the vertex arrays) the compiler kept the four steps in
+      // order and a bin paid index -> vertex latency four times: 5.3 us of the workgroup's 11 (profiles/r04_experiments.md 15); all
+      // four steps' loads at once are 84 registers of raw vertex data and cost the whole kernel a wavefront per SIMD.
+      auto face_eval = [&](int it, float &w, V3 &a, V3 &fn, Stencil &s) -> bool {
+        const int q = it * 8 + fi;
+        const bool have = q < fb.cnt && n < 27;
+        const int jq = q < fb.cnt ? fb.start + q : fb.start;
+        int i0 = sa.fidx[3 * jq], i1 = sa.fidx[3 * jq + 1], i2 = sa.fidx[3 * jq + 2];
+        V3 p0 = mesh_point(sa.pts, sa.vel, sa.adv, i0), p1 = mesh_point(sa.pts, sa.vel, sa.adv, i1), p2 = mesh_point(sa.pts, sa.vel, sa.adv, i2);
+        V3 u0 = load_v3(sa.vel + 3 * i0), u1 = load_v3(sa.vel + 3 * i1), u2 = load_v3(sa.vel + 3 * i2);
+        V3 fp = v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
+        a = v3((u0.x + u1.x + u2.x) / 3.0f, (u0.y + u1.y + u2.y) / 3.0f, (u0.z + u1.z + u2.z) / 3.0f);
+        fn = normalize(cross(p1 - p0, p2 - p0));  // wp.mesh_eval_face_normal
+        s = make_stencil(fp, d.inv_dx);
+        w = sel3(ni, s.w0.x, s.w1.x, s.w2.x) * sel3(nj, s.w0.y, s.w1.y, s.w2.y) * sel3(nk, s.w0.z, s.w1.z, s.w2.z);
+        return have && splat_ok(d.G, s);  // mpm_solver.py:858
+      };
+      unsigned esc_mask = 0;  // steps whose face left the tile margin since the faces were binned
+#pragma unroll
+      for (int h = 0; h < SPLAT_SMALL / 8; h += 2) {
+        float w[2];
+        V3 a[2], fn[2];
+        int off[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          Stencil s;
+          const bool ok = face_eval(h + u, w[u], a[u], fn[u], s);
+          const int lx = s.bx - ox, ly = s.by - oy, lz = s.bz - oz;
+          const bool in_tile = !((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u);
+          off[u] = (ok && in_tile) ? (lx + ni) * SPLAT7_SI + (ly + nj) * SPLAT7_SJ + (lz + nk) : -1;
+          if (ok && !in_tile) esc_mask |= 1u << (h + u);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (off[u] >= 0) {
+            double *p = tile + off[u];
+            atomicAdd(p, (double)w[u]);
+            atomicAdd(p + SPLAT7_S, (double)(w[u] * a[u].x)); atomicAdd(p + 2 * SPLAT7_S, (double)(w[u] * a[u].y));
+            atomicAdd(p + 3 * SPLAT7_S, (double)(w[u] * a[u].z));
+            atomicAdd(p + 4 * SPLAT7_S, (double)(w[u] * fn[u].x)); atomicAdd(p + 5 * SPLAT7_S, (double)(w[u] * fn[u].y));
+            atomicAdd(p + 6 * SPLAT7_S, (double)(w[u] * fn[u].z));
+          }
+        asm volatile("" : "+v"(esc_mask)::"memory");  // (the next pair's loads stay behind this pair's)
+      }
+      if (esc_mask) {  // rare: this lane's node through global atomics; the flag makes the next re-sort bin the faces again
+        raise_drift(g.counters, g.step_id);
+        raise_face(g.counters, g.step_id);
+#pragma unroll 1
+        for (int it = 0; it < SPLAT_SMALL / 8; ++it) {
+          if (!((esc_mask >> it) & 1u)) continue;
+          float w;
+          V3 a, fn;
+          Stencil s;
+          (void)face_eval(it, w, a, fn, s);
+          int x = s.bx + ni, y = s.by + nj, z = s.bz + nk;
+          int nb = blk_of(x, y, z, d.NB);
+          if (g.ab_flag[nb]) {
+            float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
+            __hip_atomic_store(&g.col_flag[nb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(p, w);
+            atomicAdd(p + 64, w * a.x); atomicAdd(p + 128, w * a.y); atomicAdd(p + 192, w * a.z);
+            atomicAdd(p + 256, w * fn.x); atomicAdd(p + 320, w * fn.y); atomicAdd(p + 384, w * fn.z);
+          }
+        }
+      }
+      WGT(g, 0, 3);  // faces loaded, LDS atomics of wavefront 0 out
+      __syncthreads();
+      WGT(g, 0, 4);
+      for (int t = l; t < TILE3; t += PT) {  // (same rules as col_splat_flush<0> and <1>: a node without weight got nothing at all)
+        int ti = t >> 6, tj = (t >> 3) & 7, tk = t & 7;
+        const double *q = tile + (ti * SPLAT7_SI + tj * SPLAT7_SJ + tk);
+        float c0 = (float)q[0];
+        if (c0 == 0.0f) continue;
+        int x = ox + ti, y = oy + tj, z = oz + tk;
+        if (!in_grid(x, y, z, d.G)) continue;
+        int nb = blk_of(x, y, z, d.NB);
+        int nidx = (((x >> 2) - bx + 1) * 3 + ((y >> 2) - by + 1)) * 3 + ((z >> 2) - bz + 1);
+        if (!((act_mask >> nidx) & 1ull)) continue;  // inactive block: never read by g2p, never re-zeroed
+        float *p = g.col + ((size_t)nb * GCH_COL) * 64 + loc_of(x, y, z);
+        atomicAdd(p, c0);
+        atomicAdd(p + 64, (float)q[SPLAT7_S]); atomicAdd(p + 128, (float)q[2 * SPLAT7_S]); atomicAdd(p + 192, (float)q[3 * SPLAT7_S]);
+        atomicAdd(p + 256, (float)q[4 * SPLAT7_S]); atomicAdd(p + 320, (float)q[5 * SPLAT7_S]); atomicAdd(p + 384, (float)q[6 * SPLAT7_S]);
+        __hip_atomic_store(&g.col_flag[nb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
     float wk[SPLAT_SMALL / 8];
     V3 fnk[SPLAT_SMALL / 8];
     int basek[SPLAT_SMALL / 8];

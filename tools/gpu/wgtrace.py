@@ -51,6 +51,13 @@ def analyse(name, buf, labels):
         d = (t[other, 6] - t[other, 0]) / 100.0
         print(f"   {other.sum()} extra workgroups (splat / clearing): duration median {np.median(d):.2f} us, p90 {np.quantile(d, .9):.2f}, max {d.max():.2f}; "
               f"start median {np.median(us(t[other, 0])):.1f} us, last end {us(t[other, 6].max()):.1f} us")
+    sp = other & (t[:, 2] > 0) & (t[:, 3] > 0) & (t[:, 4] > 0)   # one-pass small-bin splat workgroups (stamps 2, 3, 4)
+    if name == "p2g" and sp.any():
+        ts = t[sp]
+        seg = lambda a, b: (ts[:, b] - ts[:, a]) / 100.0
+        print(f"   {sp.sum()} one-pass splat workgroups: life median {np.median(seg(0, 6)):.2f} us (p90 {np.quantile(seg(0, 6), .9):.2f}); start -> record + tile cleared "
+              f"{np.median(seg(0, 2)):.2f}, -> faces loaded + LDS atomics {np.median(seg(2, 3)):.2f}, -> barrier {np.median(seg(3, 4)):.2f}, -> flushed {np.median(seg(4, 6)):.2f}; "
+              f"start median {np.median(us(ts[:, 0])):.1f} us")
     idx = np.where(full)[0]
     tt = t[idx]
     dur = (tt[:, 6] - tt[:, 0]) / 100.0
