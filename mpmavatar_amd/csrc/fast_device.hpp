@@ -422,46 +422,68 @@ template <bool FINALIZE>
 __device__ __forceinline__ void stress_elem_body(int e, const Bufs &b, F3 *ef, const Dims &d, float friction_coeff, const int *face_slot,
                                                  const SortKey *skeys, int blk_bits, int *counters, int step_id) {
   if (e >= d.n_e) return;
-  if (b.sel[e] == 1) {  // not simulated (selection == 2 marks a ghost copy: stress yes, transfers no)
-    for (int c = 0; c < 3; ++c) ef[c * d.n_e + e] = F3{0.0f, 0.0f, 0.0f};
-    return;
-  }
+  // Every load that depends on e alone goes out FIRST, in one burst, and every store comes after the last load: the pointers are not
+  // restrict-qualified, so a store (or the drift flag) between two loads pins the later one behind it, and the straightforward order
+  // -- selection -> vertex slots -> vertices -> store x, v -> sort key -> director -> gamma, kappa -> store d3 -> R^-1, vol, mu, lam
+  // -> store stress -- was a chain of SEVEN dependent memory levels per wavefront (ISA: one s_waitcnt vmcnt(0) after each), which is
+  // what a launch of one round of workgroups lasts.  Now: e-indexed data -> vertices -> stores.
+  const int sel = b.sel[e];
+  int s1 = 0, s2 = 0, s3 = 0;
+  SortKey sk = 0;
   M3 dm;
   if (FINALIZE) {
-    int v1 = d.n_nv + face_slot[e], v2 = d.n_nv + face_slot[d.n_e + e], v3i = d.n_nv + face_slot[2 * d.n_e + e];
-    V3 x1 = ld3(b.all, A_X, v1), x2 = ld3(b.all, A_X, v2), x3 = ld3(b.all, A_X, v3i);
-    V3 u1 = ld3(b.all, A_V, v1), u2 = ld3(b.all, A_V, v2), u3 = ld3(b.all, A_V, v3i);
-    st3(b.all, A_V, e, v3((u1.x + u2.x + u3.x) / 3.0f, (u1.y + u2.y + u3.y) / 3.0f, (u1.z + u2.z + u3.z) / 3.0f));
-    V3 xe = v3((x1.x + x2.x + x3.x) / 3.0f, (x1.y + x2.y + x3.y) / 3.0f, (x1.z + x2.z + x3.z) / 3.0f);
-    st3(b.all, A_X, e, xe);
-    {  // drift check against the block this element was sorted into
-      int blk = key_block(skeys[e], blk_bits);
-      int oz = 4 * (blk % d.NB) - 1, oy = 4 * ((blk / d.NB) % d.NB) - 1, ox = 4 * (blk / (d.NB * d.NB)) - 1;
-      // (no look-ahead here: an element follows its three vertices, whose g2p raises the flag early, see g2p_write)
-      int nbx = (int)(xe.x * d.inv_dx - 0.5f) - ox, nby = (int)(xe.y * d.inv_dx - 0.5f) - oy, nbz = (int)(xe.z * d.inv_dx - 0.5f) - oz;
-      if (b.sel[e] == 0 && ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u)) raise_drift(counters, step_id);
-    }
-    V3 d3o = v3(b.el.at(E_D + 2, e), b.el.at(E_D + 5, e), b.el.at(E_D + 8, e));
-    V3 d1 = x2 - x1, d2 = x3 - x1;
-    dm = m3_cols(d1, d2, d3o);
-    // d1, d2 are not stored here: nothing reads them before the next finalize (every consumer of finished elements --
-    // re-sort, read-back, ghosts -- runs k_elem_finalize first, which recomputes them from the vertices)
+    s1 = face_slot[e]; s2 = face_slot[d.n_e + e]; s3 = face_slot[2 * d.n_e + e];
+    sk = skeys[e];
+    dm = m3_zero();
+    dm.a02 = b.el.at(E_D + 2, e); dm.a12 = b.el.at(E_D + 5, e); dm.a22 = b.el.at(E_D + 8, e);
   } else {
     dm = ld9(b.el, E_D, e);
   }
-  QR3 q = qr_cloth(dm);
   float gamma = b.el.at(E_GAMMA, e), kappa = b.el.at(E_KAPPA, e);
+  V3 rinv = ld3(b.el, E_RINV, e);
+  float vol = b.nv.at(N_VOL, e), mu = b.nv.at(N_MU, e), lam = b.nv.at(N_LAM, e);
+  // (an empty asm that "uses" the loaded values HERE: without it LLVM sinks the loads into the blocks behind the branches below, next
+  // to their first use, and the chain is back)
+  asm volatile("" : "+v"(s1), "+v"(s2), "+v"(s3), "+v"(sk), "+v"(dm.a02), "+v"(dm.a12), "+v"(dm.a22));
+  asm volatile("" : "+v"(gamma), "+v"(kappa), "+v"(rinv.x), "+v"(rinv.y), "+v"(rinv.z), "+v"(vol), "+v"(mu), "+v"(lam));
+  if (sel == 1) {  // not simulated (selection == 2 marks a ghost copy: stress yes, transfers no)
+    for (int c = 0; c < 3; ++c) ef[c * d.n_e + e] = F3{0.0f, 0.0f, 0.0f};
+    return;
+  }
+  V3 xe = v3(0, 0, 0), ve = v3(0, 0, 0);
+  if (FINALIZE) {
+    int v1 = d.n_nv + s1, v2 = d.n_nv + s2, v3i = d.n_nv + s3;
+    V3 x1 = ld3(b.all, A_X, v1), x2 = ld3(b.all, A_X, v2), x3 = ld3(b.all, A_X, v3i);
+    V3 u1 = ld3(b.all, A_V, v1), u2 = ld3(b.all, A_V, v2), u3 = ld3(b.all, A_V, v3i);
+    ve = v3((u1.x + u2.x + u3.x) / 3.0f, (u1.y + u2.y + u3.y) / 3.0f, (u1.z + u2.z + u3.z) / 3.0f);
+    xe = v3((x1.x + x2.x + x3.x) / 3.0f, (x1.y + x2.y + x3.y) / 3.0f, (x1.z + x2.z + x3.z) / 3.0f);
+    V3 d1 = x2 - x1, d2 = x3 - x1;
+    dm = m3_cols(d1, d2, v3(dm.a02, dm.a12, dm.a22));
+    // d1, d2 are not stored here: nothing reads them before the next finalize (every consumer of finished elements --
+    // re-sort, read-back, ghosts -- runs k_elem_finalize first, which recomputes them from the vertices)
+  }
+  QR3 q = qr_cloth(dm);
   float r02, r12, r22;
   V3 d3 = anisotropy_return_mapping(q, gamma, kappa, friction_coeff, r02, r12, r22);
-  b.el.at(E_D + 2, e) = d3.x; b.el.at(E_D + 5, e) = d3.y; b.el.at(E_D + 8, e) = d3.z;
   M3 stress;
   V3 f1, f2, f3;
-  kirchhoff_anisotropy(q, r02, r12, r22, d3, ld3(b.el, E_RINV, e), b.nv.at(N_VOL, e), b.nv.at(N_MU, e),
-                       b.nv.at(N_LAM, e), gamma, kappa, stress, f1, f2, f3);
+  kirchhoff_anisotropy(q, r02, r12, r22, d3, rinv, vol, mu, lam, gamma, kappa, stress, f1, f2, f3);
+  if (FINALIZE) {
+    st3(b.all, A_V, e, ve);
+    st3(b.all, A_X, e, xe);
+  }
+  b.el.at(E_D + 2, e) = d3.x; b.el.at(E_D + 5, e) = d3.y; b.el.at(E_D + 8, e) = d3.z;
   st9(b.nv, N_STRESS, e, stress);
   ef[e] = F3{f1.x, f1.y, f1.z};
   ef[d.n_e + e] = F3{f2.x, f2.y, f2.z};
   ef[2 * d.n_e + e] = F3{f3.x, f3.y, f3.z};
+  if (FINALIZE) {  // drift check against the block this element was sorted into
+    int blk = key_block(sk, blk_bits);
+    int oz = 4 * (blk % d.NB) - 1, oy = 4 * ((blk / d.NB) % d.NB) - 1, ox = 4 * (blk / (d.NB * d.NB)) - 1;
+    // (no look-ahead here: an element follows its three vertices, whose g2p raises the flag early, see g2p_write)
+    int nbx = (int)(xe.x * d.inv_dx - 0.5f) - ox, nby = (int)(xe.y * d.inv_dx - 0.5f) - oy, nbz = (int)(xe.z * d.inv_dx - 0.5f) - oz;
+    if (sel == 0 && ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u)) raise_drift(counters, step_id);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
