@@ -440,6 +440,10 @@ __device__ __forceinline__ void g2p2g_body(const ChunkRec *recs, int n_chunks, c
   gr.mv = rd.mv; gr.col = rd.col; gr.mov = rd.mov; gr.col_flag = rd.col_flag;
   // ---- g2p of substep n: everything that depends on the record alone is loaded now (see g2p_body) ----
   V3 x = ld3(b.all, A_X, sx);
+  // ... including what only the p2g half needs (mass, volume, Lame parameters, yield stress): loaded behind the g2p half's stores and the
+  // barrier they were one more exposed memory level in the middle of a launch that is one workgroup's dependency chain long
+  float pm_mass = b.all.at(A_MASS, sx), pm_vol = b.nv.at(N_VOL, sx), pm_mu = b.nv.at(N_MU, sx), pm_lam = b.nv.at(N_LAM, sx);
+  float pm_ys = b.tr.at(T_YS, tx);
   constexpr int NPT = TILE3 / PT;
   int nbk[NPT], nlk[NPT];
   float am[NPT], apx[NPT], apy[NPT], apz[NPT];
@@ -488,6 +492,7 @@ __device__ __forceinline__ void g2p2g_body(const ChunkRec *recs, int n_chunks, c
     }
     vt[tile_idx(ti, tj, tk)] = make_float4(v.x, v.y, v.z, 0.0f);
   }
+  asm volatile("" : "+v"(pm_mass), "+v"(pm_vol), "+v"(pm_mu), "+v"(pm_lam), "+v"(pm_ys));  // (here at the latest: they were issued before the accumulators)
   __syncthreads();
   __builtin_amdgcn_s_setprio(0);
   const bool fit = valid && !escaped;
@@ -537,11 +542,9 @@ __device__ __forceinline__ void g2p2g_body(const ChunkRec *recs, int n_chunks, c
   asm volatile("" : "+v"(nx.x), "+v"(nx.y), "+v"(nx.z), "+v"(nv.x), "+v"(nv.y), "+v"(nv.z), "+v"(s));
   asm volatile("" : "+v"(nC.a00), "+v"(nC.a01), "+v"(nC.a02), "+v"(nC.a10), "+v"(nC.a11), "+v"(nC.a12), "+v"(nC.a20), "+v"(nC.a21), "+v"(nC.a22));
   asm volatile("" : "+v"(Ft.a00), "+v"(Ft.a01), "+v"(Ft.a02), "+v"(Ft.a10), "+v"(Ft.a11), "+v"(Ft.a12), "+v"(Ft.a20), "+v"(Ft.a21), "+v"(Ft.a22));
-  const int sp = fit ? s : d.n_e, tp_ = sp - d.n_e;
   P2GRaw raw;
   raw.x = nx; raw.v = nv; raw.C = nC; raw.S = Ft;
-  raw.mass = b.all.at(A_MASS, sp); raw.vol = b.nv.at(N_VOL, sp); raw.mu = b.nv.at(N_MU, sp); raw.lam = b.nv.at(N_LAM, sp);
-  raw.ys = b.tr.at(T_YS, tp_);
+  raw.mass = pm_mass; raw.vol = pm_vol; raw.mu = pm_mu; raw.lam = pm_lam; raw.ys = pm_ys;  // (of slot s for every valid lane: only fit lanes use them)
 #pragma unroll
   for (int u = 0; u < ADJ_BATCH; ++u) raw.ab.ent[u] = -1;
   P2GParticle q = p2g_finish<true>(raw, b, va, fit, 1, s, d, rpic, dt, false, tp);
