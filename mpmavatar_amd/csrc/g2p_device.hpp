@@ -249,6 +249,9 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
   int w = xcd_slice(wg, n_chunks);
   if (w < 0) return;
   const ChunkRec cm = recs[w];
+  // (the whole record with the first request: LLVM sinks the load of a field into the branch of map() that uses it, and e0 -- the
+  // common case -- arrived one dependent memory level after the rest; the empty asm uses the three range starts here)
+  asm volatile("" ::"s"(cm.e0), "s"(cm.t0), "s"(cm.v0));
   int blk = cm.blk, chunk = cm.chunk;
   int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
   int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
@@ -429,6 +432,7 @@ __device__ __forceinline__ void g2p2g_body(const ChunkRec *recs, int n_chunks, c
   if (w < 0) return;
   __builtin_amdgcn_s_setprio(3);
   const ChunkRec cm = recs[w];
+  asm volatile("" ::"s"(cm.e0), "s"(cm.t0), "s"(cm.v0));  // (the whole record with the first request, see g2p_body)
   int blk = cm.blk, chunk = cm.chunk;
   int bz = blk % d.NB, by = (blk / d.NB) % d.NB, bx = blk / (d.NB * d.NB);
   int ox = 4 * bx - 1, oy = 4 * by - 1, oz = 4 * bz - 1;
