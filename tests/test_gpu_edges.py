@@ -283,3 +283,23 @@ def test_nodes_exactly_on_a_cuboid_face(mode, fuse_grid, oracle_lib, monkeypatch
         assert (d > 1e-4).sum() == 0, f"{(d > 1e-4).sum()} nodes classified differently after {n} substeps"
         assert rel(sim.state.particle_x.cpu().numpy(), o.x) < 1e-5
         assert np.abs(sim.state.particle_v.cpu().numpy() - o.v).max() < 1e-4 * max(np.abs(o.v).max(), 0.1)
+
+
+@pytest.mark.parametrize("subdiv", [2, 4])
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_body_face_splat_layouts(subdiv, split, oracle_lib, monkeypatch):
+    """The body-face splat (mpm_solver.py:829-880) in its four forms: bins of a few faces ((face, node) lanes; both passes in the p2g
+    launch = ONE pass through the seven-channel tile, MPMHIP_SPLIT_SPLAT=0, or pass 0 in front of the stress kernel and pass 1 in p2g)
+    and bins of hundreds of faces (lane = face with the DPP pre-reduction, two passes) -- a 320-face and a 5,120-face sphere under
+    the same sheet, against the oracle, and the two launch layouts against each other."""
+    monkeypatch.setenv("MPMHIP_SPLIT_SPLAT", split)
+    sc = scenes.sheet(n=40, n_grid=48, collider_subdiv=subdiv, span=(0.6, 1.4), y=1.215, name=f"splat-{subdiv}")
+    sc.dt = 1e-4
+    o, sim = _pair(sc, 60, "fast", fused=True)
+    st = sim.solver.stats()
+    assert st["n_collider_nodes"] > 100 and st["n_dropped"] == 0
+    x, v = sim.state.particle_x.cpu().numpy(), sim.state.particle_v.cpu().numpy()
+    assert rel(x, o.x) < 1e-5
+    assert np.abs(v - o.v).max() < 2e-4 * max(np.abs(o.v).max(), 0.1)
+    moved = np.abs(o.v[:, 1] + 9.8 * 60 * sc.dt) > 1e-3     # particles the sphere has slowed down: the collider is felt
+    assert moved.sum() > 50
