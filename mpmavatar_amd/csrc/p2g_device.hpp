@@ -630,6 +630,7 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
       unsigned esc_mask = 0;  // steps whose face left the tile margin since the faces were binned
 #pragma unroll
       for (int h = 0; h < SPLAT_SMALL / 8; h += 2) {
+        if (h * 8 >= fb.cnt) break;  // (workgroup-uniform: a bin of at most 16 faces -- the average is 13 -- is done after the first pair)
         float w[2];
         V3 a[2], fn[2];
         int off[2];
@@ -703,6 +704,8 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < SPLAT_SMALL / 8; ++it) {
+      wk[it] = 0.0f; fnk[it] = v3(0, 0, 0); basek[it] = 0;
+      if (it * 8 >= fb.cnt) continue;  // (workgroup-uniform: no face left for this step)
       const int q = it * 8 + fi;
       const bool have = q < fb.cnt && n < 27;
       const int jq = q < fb.cnt ? fb.start + q : fb.start;
