@@ -595,7 +595,10 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
     if ((unsigned)x < (unsigned)d.NB && (unsigned)y < (unsigned)d.NB && (unsigned)z < (unsigned)d.NB)
       nb_act = g.ab_flag[(x * d.NB + y) * d.NB + z] != 0;
   }
-  unsigned long long act_mask = __ballot(nb_act);
+  // (the one-pass path takes the ballot -- i.e. the wait for the flags -- right before its flush: in front of the tile clearing it was
+  // one more dependent memory level at the head of the workgroup)
+  const bool one_pass = PASSES == 3 && fb.cnt <= SPLAT_SMALL;
+  unsigned long long act_mask = one_pass ? 0ull : __ballot(nb_act);
   const int end = fb.start + fb.cnt;
   if (fb.cnt <= SPLAT_SMALL) {
     // SMALL BIN (the common case once the cloth has draped: ~740 bins of ~27 faces): lane = (face, stencil node), 8 faces x 32
@@ -606,6 +609,15 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
     const int fi = l >> 5, n = l & 31;
     const int ni = n / 9, nj = (n / 3) % 3, nk = n % 3;
     if (PASSES == 3) {  // one pass through a seven-channel tile (see SPLAT7_S)
+      // the first pair's face indices are requested together with the block flags, BEFORE the tile is cleared: behind the barrier they
+      // were a memory level of their own (record -> flags -> [clear, barrier] -> indices -> vertices; now record -> flags + indices -> vertices)
+      int pre_i[2][3];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = u * 8 + fi;
+        const int jq = q < fb.cnt ? fb.start + q : fb.start;
+        pre_i[u][0] = sa.fidx[3 * jq]; pre_i[u][1] = sa.fidx[3 * jq + 1]; pre_i[u][2] = sa.fidx[3 * jq + 2];
+      }
       for (int t = l; t < 7 * SPLAT7_S; t += PT) tile[t] = 0.0;
       __syncthreads();
       WGT(g, 0, 2);  // (debug build: bin record, block flags, tile cleared)
@@ -613,11 +625,13 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
       // steps are through.  With those inside the load loop (they may alias the vertex arrays) the compiler kept the four steps in
       // order and a bin paid index -> vertex latency four times: 5.3 us of the workgroup's 11 (profiles/r04_experiments.md 15); all
       // four steps' loads at once are 84 registers of raw vertex data and cost the whole kernel a wavefront per SIMD.
-      auto face_eval = [&](int it, float &w, V3 &a, V3 &fn, Stencil &s) -> bool {
+      auto face_eval = [&](int it, float &w, V3 &a, V3 &fn, Stencil &s, bool pre = false) -> bool {
         const int q = it * 8 + fi;
         const bool have = q < fb.cnt && n < 27;
         const int jq = q < fb.cnt ? fb.start + q : fb.start;
-        int i0 = sa.fidx[3 * jq], i1 = sa.fidx[3 * jq + 1], i2 = sa.fidx[3 * jq + 2];
+        int i0, i1, i2;
+        if (pre) { i0 = pre_i[it & 1][0]; i1 = pre_i[it & 1][1]; i2 = pre_i[it & 1][2]; }  // (it < 2 only)
+        else { i0 = sa.fidx[3 * jq]; i1 = sa.fidx[3 * jq + 1]; i2 = sa.fidx[3 * jq + 2]; }
         V3 p0 = mesh_point(sa.pts, sa.vel, sa.adv, i0), p1 = mesh_point(sa.pts, sa.vel, sa.adv, i1), p2 = mesh_point(sa.pts, sa.vel, sa.adv, i2);
         V3 u0 = load_v3(sa.vel + 3 * i0), u1 = load_v3(sa.vel + 3 * i1), u2 = load_v3(sa.vel + 3 * i2);
         V3 fp = v3((p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f);
@@ -637,7 +651,7 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           Stencil s;
-          const bool ok = face_eval(h + u, w[u], a[u], fn[u], s);
+          const bool ok = face_eval(h + u, w[u], a[u], fn[u], s, h == 0);
           const int lx = s.bx - ox, ly = s.by - oy, lz = s.bz - oz;
           const bool in_tile = !((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u);
           off[u] = (ok && in_tile) ? (lx + ni) * SPLAT7_SI + (ly + nj) * SPLAT7_SJ + (lz + nk) : -1;
@@ -677,6 +691,7 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
         }
       }
       WGT(g, 0, 3);  // faces loaded, LDS atomics of wavefront 0 out
+      act_mask = __ballot(nb_act);
       __syncthreads();
       WGT(g, 0, 4);
       for (int t = l; t < TILE3; t += PT) {  // (same rules as col_splat_flush<0> and <1>: a node without weight got nothing at all)
