@@ -162,6 +162,9 @@ def _main(out_stream):
     ap.add_argument("--weak-grid", type=int, default=256)
     ap.add_argument("--force-dist", action="store_true", help="diagnostics: run the sharded driver even with one rank "
                     "(launch under torch.distributed.run --nproc-per-node 1)")
+    ap.add_argument("--extras-budget", type=int, default=420, help="N > 1: seconds the measurements BEHIND the headline value (kernel events, "
+                    "shard floor, weak scaling, draped state) may take together; after that rank 0 prints the line as far as it got "
+                    "(\"extras\": \"timed out ...\") and every rank exits -- a stuck extra must not cost the run its headline number; 0 = off")
     ap.add_argument("--watchdog", type=int, default=1500, help="N > 1: seconds after which a rank that is still running dumps its "
                     "Python stacks to stderr and exits (a rank that died leaves the others in a collective for RCCL's 10 minutes per "
                     "call otherwise); 0 = off")
@@ -268,6 +271,25 @@ def _main(out_stream):
                    "dt": sc.dt, "mode": args.mode, "parallelism": f"slab{world}" if world > 1 else "single",
                    "exchange": transport},
     }
+
+    # N > 1: everything below this point is extra information around a headline value that is already measured.  It involves more
+    # collectives, a second sharded scene and thousands of further substeps on hardware this code has never run on: if it is not through
+    # within --extras-budget seconds, rank 0 prints the line as far as it got and all ranks leave (same timer on every rank).
+    extras_timer = None
+    if world > 1 and args.extras_budget > 0:
+        import threading
+
+        def _bail():
+            print(f"[bench] rank {rank}: extras budget used up, leaving", file=sys.stderr, flush=True)
+            if rank == 0:
+                snap = dict(out)
+                snap["extras"] = f"timed out after {args.extras_budget} s: the line holds what was finished by then"
+                print(json.dumps(snap, default=str), file=out_stream, flush=True)
+            os._exit(0)
+        extras_timer = threading.Timer(args.extras_budget, _bail)
+        extras_timer.daemon = True
+        extras_timer.start()
+        print(f"[bench] rank {rank}: extras budget {args.extras_budget} s", file=sys.stderr, flush=True)
 
     if not sharded:
         sv = sim.solver
@@ -467,6 +489,8 @@ def _main(out_stream):
                                   "substep_frac_of_hbm_peak": b_d["substep"] / (out["ms_per_step_draped"] * 1e-3) / 1e9 / HBM_PEAK_GBS})
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sc)
+    if extras_timer is not None:
+        extras_timer.cancel()
     if rank == 0:
         print(json.dumps(out), file=out_stream, flush=True)
     if sharded:

@@ -104,3 +104,19 @@ def test_bench_gpus_n_without_a_launcher():
     # the weak-scaling measurement builds a second sharded simulation (second communicator, second set of peer links) in the
     # same processes while the first is alive
     assert "error" not in o["weak_scaling"] and o["weak_scaling"]["value"] > 0, o["weak_scaling"]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_n_prints_its_headline_when_the_extras_run_out_of_time():
+    """--extras-budget: the measurements behind the headline value (kernel events, shard floor, weak scaling, draped state) of an N > 1 run
+    may not cost the run its number.  Two gloo ranks sharing the GPU, a draped phase far longer than the budget: still exactly one JSON
+    line, exit code 0, the value in it and a note that the extras were cut."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scene", "cube-8k", "--steps", "20", "--warmup", "5",
+           "--advance", "400000", "--no-cpu-baseline", "--no-weak", "--no-shard-floor", "--extras-budget", "4"]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(env, MPMHIP_DIST_BACKEND="gloo", OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(out) == 1, r.stdout[:500]
+    o = json.loads(out[0])
+    assert o["n_gpus"] == 2 and o["value"] > 0 and "timed out" in o["extras"] and "value_draped" not in o
