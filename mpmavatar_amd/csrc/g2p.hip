@@ -25,7 +25,7 @@ __global__ __launch_bounds__(PT) void k_g2p_halo(const ChunkRec *recs, int n_chu
 template <int STEPS, bool FX>
 __global__ __launch_bounds__(PT) void k_g2p2g(const ChunkRec *recs, int n_chunks, Bufs b, VAdj va, Dims d, float rpic, float dt, GridPtrs g,
                                                GridRead rd, SplatArgs sa, TradParams tp, GridParams gp, BCList bcl) {
-  __shared__ double tile[4 * TILE_PAD];
+  __shared__ double tile[P2G_TILE_DOUBLES];  // (col_splat_wg<3> runs in this launch too: its one-pass tile is 7 * SPLAT7_S doubles)
   __shared__ int esc[CHUNK];
   __shared__ int esc_n;
   __shared__ float red[8];

@@ -12,8 +12,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Order of the suite under `-x`: what proves parity with the reference runs FIRST -- the fixtures generated from
+# the imported reference, then the oracle comparisons, then the full-size statements -- and what measures (bench contract, soak)
+# runs LAST, so that nothing about timing or the box can keep a parity test from being reached.
+_ORDER = ["test_gpu_ref_golden", "test_gpu_parity", "test_gpu_golden", "test_gpu_edges", "test_gpu_api", "test_gpu_sort",
+          "test_gpu_g2p2g", "test_gpu_branch_flips", "test_gpu_mass_ratio", "test_gpu_fuzz", "test_frames", "test_render_inputs",
+          "test_io_formats", "test_gpu_fd", "test_dist", "test_gpu_fullsize"]
+_LAST = ["test_c_abi_demo", "test_gpu_soak", "test_bench_contract"]
+
+
+def _rank(item):
+    mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    if mod in _ORDER:
+        return _ORDER.index(mod)
+    if mod in _LAST:
+        return 1000 + _LAST.index(mod)
+    return 500
+
+
 def pytest_collection_modifyitems(config, items):
-    """A plain `pytest tests/` on a box without a GPU skips the gpu-marked tests instead of failing at device creation."""
+    """Parity tests first, measurements last (stable within a module).  A plain `pytest tests/` on a box without a GPU skips the
+    gpu-marked tests instead of failing at device creation."""
+    items.sort(key=_rank)
     import torch
     if torch.cuda.is_available():
         return

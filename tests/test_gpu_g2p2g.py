@@ -28,6 +28,10 @@ if material in ("metal", "foam", "plasticine"):
     params.update({{"yield_stress": 2.0, "hardening": 1, "xi": 0.1, "plastic_viscosity": 0.5}})
 sc = scenes.small_cube(material=material, params=params)
 sc.bcs = [("bounding_box", {{}}), ("surface_collider", {{"point": [0.0, 0.95, 0.0], "normal": [0.0, 1.0, 0.0]}})]
+if len(sys.argv) > 5:   # a body-mesh collider pushed up into the cube (see _with_body)
+    sys.path.insert(0, {root!r} + "/tests")
+    from test_gpu_g2p2g import _with_body
+    sc = _with_body(sc, int(sys.argv[5]))
 sim = harness.build_solver(sc, "cuda:0", mode="fast", rebin_interval=rebin)
 out = []
 for n in segs:
@@ -41,11 +45,24 @@ np.savez(sys.argv[4], **res)
 """
 
 
-def _run(tmp_path, material, rebin, segs, g2p2g):
+def _with_body(sc, subdiv):
+    """The small cube with a sphere mesh (centre on a block corner inside the cube's lower half, moving up at 0.5 m/s) as body
+    collider: subdiv 1 = 80 faces over 8 blocks (bins of ~10 faces: the one-pass seven-channel splat tile, SPLAT7_S), subdiv 3 =
+    1280 faces (bins of ~160: the two-pass splat)."""
+    from mpmavatar_amd import garment
+    mv, mf = garment.icosphere(subdiv, 0.1, (1.0, 1.0, 1.0))
+    sc.mesh_vertices, sc.mesh_faces = mv, mf
+    sc.mesh_v = np.tile(np.array([[0.0, 0.5, 0.0]], np.float32), (mv.shape[0], 1))
+    sc.mesh_friction = 0.5
+    return sc
+
+
+def _run(tmp_path, material, rebin, segs, g2p2g, body=None):
     import json
-    out = tmp_path / f"{material}_{rebin}_{g2p2g}.npz"
+    out = tmp_path / f"{material}_{rebin}_{g2p2g}_{body}.npz"
     env = dict(os.environ, MPMHIP_G2P2G=str(g2p2g))
-    r = subprocess.run([sys.executable, "-c", WORKER.format(root=ROOT), material, str(rebin), json.dumps(segs), str(out)],
+    r = subprocess.run([sys.executable, "-c", WORKER.format(root=ROOT), material, str(rebin), json.dumps(segs), str(out)]
+                       + ([str(body)] if body is not None else []),
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     return dict(np.load(out))
@@ -105,3 +122,22 @@ def test_changing_dt_flushes_with_the_pending_dt(oracle_lib):
         o.p2g2p(dt)
     x, v = sim.state.particle_x.detach().cpu().numpy(), sim.state.particle_v.detach().cpu().numpy()
     assert rel(x, o.x) < 1e-4 and rel(v, o.v) < 1e-4
+
+
+@pytest.mark.parametrize("subdiv", [1, 3])
+def test_fused_with_a_body_mesh_collider(tmp_path, oracle_lib, subdiv):
+    """the fused launch also runs the body-face splat workgroups (col_splat_wg<3>), whose one-pass tile is
+    7 * SPLAT7_S doubles -- larger than the four-channel p2g tile k_g2p2g used to declare.  Small bins (subdiv 1) take that path,
+    large bins (subdiv 3) the two-pass one; both against the two-launch sequence and against the oracle."""
+    from oracle.scene_adapter import oracle_from_scene, run_scene
+    a, b = _run(tmp_path, "jelly", 0, [1, 2, 37, 60], 1, body=subdiv), _run(tmp_path, "jelly", 0, [1, 2, 37, 60], 0, body=subdiv)
+    sc = _with_body(scenes.small_cube(material="jelly"), subdiv)
+    sc.bcs = [("bounding_box", {}), ("surface_collider", {"point": [0.0, 0.95, 0.0], "normal": [0.0, 1.0, 0.0]})]
+    o = oracle_from_scene(sc)
+    run_scene(o, sc, 100)
+    free = _run(tmp_path, "jelly", 0, [100], 1)
+    assert rel(free["particle_v"], o.v) > 1e-2      # the body really pushes the cube (a run without it ends elsewhere)
+    for k, ref in (("particle_x", o.x), ("particle_v", o.v), ("particle_F_trial", o.F_trial)):
+        assert rel(a[k], b[k]) < (1e-5 if k == "particle_x" else 1e-4), (k, rel(a[k], b[k]))
+        assert rel(a[k], ref) < 1e-4, (k, rel(a[k], ref))
+        assert rel(b[k], ref) < 1e-4, (k, rel(b[k], ref))
