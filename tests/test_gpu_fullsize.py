@@ -54,68 +54,136 @@ def test_s3_garment_120k_anisotropic_with_collider_50_substeps(oracle_lib):
     assert dv < 1.5 * envelope, (dv, envelope)
 
 
-def _follow(name, checkpoints):
-    """HIP (fused calls between the checkpoints) against the OpenMP oracle, and the oracle against ITSELF with another
-    thread count -- i.e. another summation order of its atomic adds, nothing else.  The second distance is the scene's own
-    sensitivity at full size (cloth with shear friction sits on the return mapping's R22 = 1 discontinuity, mpm_utils.py:196-204):
-    the envelope a correct implementation can be held to.  Rows: (substep, rel dx, per-particle rel dx, |dv| max, oracle self
-    |dv| max, 99.9th percentile of |dv|, of the oracle's self |dv|, max |v|)."""
+# ---- free-running trajectories at full size -------------------------------------------------------------------------------
+# Cloth with shear friction (gamma > 0) amplifies fp32 rounding up to a bounded level (tests/test_gpu_branch_flips.py measures it), so
+# a free-running velocity comparison cannot be a fixed 1e-4.  Round 4 held the MAXIMUM of |dv| to a factor of the oracle's distance
+# from ONE re-ordered copy of itself, and had to move that factor (3x -> 1.5x -> 2x / 2.5x) with the run: one sample of an
+# extreme-value statistic.  Round 5 replaces it by three statements:
+#   (a) x within 1e-4 at every checkpoint (strict, also per particle) -- as before;
+#   (b) the ONE-SUBSTEP MAP at every checkpoint, i.e. in the draped states too: the oracle is set to the HIP state, both advance one
+#       substep, x and v of ALL particles agree to 1e-4 (strict; measured ~1e-6) -- what the implementation computes per substep is
+#       the reference's, whatever the dynamics do with rounding afterwards;
+#   (c) the free-running |dv| as a DISTRIBUTION against an ensemble: K = 5 oracle runs that differ only in the order of their atomic
+#       adds (thread counts T, T-1, ... of the OpenMP build) give 10 pairwise distance distributions; the HIP run's distance to each
+#       of the five must lie in the range those ten span, widened by a fixed margin, at the median, the 90th, 99th and 99.9th
+#       percentile -- and the maximum (still an extreme-value statistic, of 1e5..5e5 particles) within MAX_MARGIN of the largest.
+# And (d): the same scenes WITHOUT the shear term (gamma = 0: no discontinuity in mpm_utils.py:196-204, nothing to amplify) hold the
+# north star's 1e-4 on x AND v over the full 1000 substeps, strictly (test_*_gamma0_*).
+QUANTILES = (0.5, 0.9, 0.99, 0.999)
+Q_MARGIN = 1.5        # HIP's quantile of |dv| within [min / 1.5, 1.5 max] of the ensemble's pairwise values
+MAX_MARGIN = 2.0      # the maximum over all particles: within 2 x the ensemble's largest (and never asked to be below it)
+K_ORACLES = 5
+
+
+def _dist_stats(a, b):
+    d = np.linalg.norm(np.asarray(a, np.float64) - b, axis=1)
+    return [float(np.quantile(d, q)) for q in QUANTILES] + [float(d.max())]
+
+
+def _follow(name, checkpoints, gamma0=False, k_oracles=K_ORACLES):
+    """-> scene, rows; a row = dict(substep, dx, ppx, dv_rel, vmax, hip = [stats of |v_hip - v_k|] per oracle k, pairs = [stats of
+    |v_j - v_k|] per oracle pair, one_step = (rel dx, rel dv, per-particle rel dv) of the one-substep map from identical inputs).
+    The K oracle runs are processes of their own (tests/oracle_worker.py) that advance side by side on the host's cores while the
+    GPU runs the HIP path; at a checkpoint c everybody has done c substeps, then one more (the HIP side's probe substep)."""
+    import subprocess
+    import sys
+    import tempfile
     from oracle.scene_adapter import omp_threads, oracle_from_scene, run_scene
+    from test_gpu_branch_flips import sync_oracle_to_hip
     sc = scenes.REGISTRY[name]()
-    oa = oracle_from_scene(sc, omp=True, n_threads=omp_threads())
-    ob = oracle_from_scene(scenes.REGISTRY[name](), omp=True, n_threads=max(omp_threads() // 3, 2))
-    sim = harness.build_solver(scenes.REGISTRY[name](), "cuda:0", mode="fast")
-    rows, done = [], 0
-    for cp in checkpoints:
-        run_scene(oa, sc, cp - done, k0=done)
-        run_scene(ob, sc, cp - done, k0=done)
-        harness.run(sim, cp - done, fused=True)
-        done = cp
-        x, v = sim.state.particle_x.cpu().numpy(), sim.state.particle_v.cpu().numpy()
-        dv, ds = np.linalg.norm(v - oa.v, axis=1), np.linalg.norm(ob.v - oa.v, axis=1)
-        rows.append((cp, rg.rel(x, oa.x), rg.rel_pp(x, oa.x), float(dv.max()), float(ds.max()), float(np.quantile(dv, 0.999)),
-                     float(np.quantile(ds, 0.999)), float(np.abs(oa.v).max()), rg.rel(ob.x, oa.x)))
-    st = sim.solver.stats()
-    assert st["n_dropped"] == 0
+    if gamma0:
+        sc.gamma = 0.0
+    T = omp_threads()
+    threads = [max(T - k, 2) for k in range(k_oracles)]
+    tmp = tempfile.mkdtemp(prefix="oracle_ensemble_")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, name, "1" if gamma0 else "0", str(t), os.path.join(tmp, f"o{k}.npz")]
+                              + [str(c) for c in checkpoints], stdout=subprocess.DEVNULL) for k, t in enumerate(threads)]
+    try:
+        probe = oracle_from_scene(sc, omp=True, n_threads=max(T // 2, 2))
+        sim = harness.build_solver(sc, "cuda:0", mode="fast")
+        hip, done = [], 0
+        for cp in checkpoints:
+            harness.run(sim, cp - done, fused=True)
+            x, v = sim.state.particle_x.cpu().numpy(), sim.state.particle_v.cpu().numpy()
+            # (b): the oracle takes the HIP state, both advance ONE substep; the HIP run then goes on from its own state
+            sync_oracle_to_hip(probe, sim)
+            run_scene(probe, sc, 1, k0=cp)
+            harness.run(sim, 1, fused=True)
+            done = cp + 1
+            x1, v1 = sim.state.particle_x.cpu().numpy(), sim.state.particle_v.cpu().numpy()
+            hip.append((x, v, (rg.rel(x1, probe.x), rg.rel(v1, probe.v), rg.rel_pp_scaled(v1, probe.v, 1e-2))))
+        assert sim.solver.stats()["n_dropped"] == 0
+        for pr in procs:
+            assert pr.wait(timeout=1500) == 0
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    orc = [np.load(os.path.join(tmp, f"o{k}.npz")) for k in range(k_oracles)]
+    rows = []
+    for cp, (x, v, one) in zip(checkpoints, hip):
+        ox, ov = [o[f"x_{cp}"] for o in orc], [o[f"v_{cp}"] for o in orc]
+        rows.append(dict(substep=cp, dx=max(rg.rel(x, a) for a in ox), ppx=max(rg.rel_pp(x, a) for a in ox), vmax=float(np.abs(ov[0]).max()),
+                         dv_rel=max(rg.rel(v, a) for a in ov), hip=[_dist_stats(v, a) for a in ov],
+                         pairs=[_dist_stats(ov[i], ov[j]) for i in range(len(ov)) for j in range(i + 1, len(ov))], one_step=one))
+    print(f"{name}: oracle ensemble of {k_oracles} (threads {threads}), seconds per member {[round(float(o['seconds'])) for o in orc]}")
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
     return sc, rows
 
 
-def _check(rows, what, max_factor=2.0, p_factor=2.0):
-    env_max = max(r[4] for r in rows)
-    env_p999 = max(r[6] for r in rows)
-    for cp, dx, ppx, dv, ds, dvq, dsq, vmax, dxs in rows:
-        print(f"{what} substep {cp}: x {dx:.1e}; |dv| max {dv:.2e} (oracle vs itself {ds:.2e}), p99.9 {dvq:.2e} ({dsq:.2e}), top speed {vmax:.2f}")
-        assert dx < 1e-4 and ppx < 1e-4, f"{what} substep {cp}: x {dx:.2e} (per particle {ppx:.2e})"
-        # v: 1e-4 of the top speed (north star), or -- where the oracle itself does not hold that against a change of its
-        # summation order -- 2 x its own distance from itself (round 4: was 3 x.  Measured ratios over four runs: maximum 0.6 ... 1.84, 99.9th
-        # percentile 0.9 ... 1.3 -- both are statistics of amplified rounding and move by +-50 % from run to run, the HIP path's flush
-        # atomics being unordered; 1.5 x would fail one run in a few) (max over the checkpoints: both are maxima over 1e5 particles)
-        bound = max(1e-4 * max(vmax, 1e-3), max_factor * env_max)
-        assert dv < bound, f"{what} substep {cp}: |dv| {dv:.2e} m/s, oracle vs itself {ds:.2e} (bound {bound:.2e})"
-        assert dvq < max(1e-4 * max(vmax, 1e-3), p_factor * env_p999), f"{what} substep {cp}: 99.9 % of |dv| within {dvq:.2e}, oracle {dsq:.2e}"
+def _check(rows, what):
+    names = [f"p{100 * q:g}" for q in QUANTILES] + ["max"]
+    for r in rows:
+        cp = r["substep"]
+        hip, pairs = np.array(r["hip"]), np.array(r["pairs"])
+        line = ", ".join(f"{n} {np.median(hip[:, i]):.1e} [{pairs[:, i].min():.1e}..{pairs[:, i].max():.1e}]" for i, n in enumerate(names))
+        print(f"{what} substep {cp}: x {r['dx']:.1e}; |dv| HIP-vs-oracle (median of {len(hip)}) [oracle-vs-oracle range of {len(pairs)} pairs]: "
+              f"{line}; top speed {r['vmax']:.2f}; one-substep map {r['one_step']}")
+        assert r["dx"] < 1e-4 and r["ppx"] < 1e-4, f"{what} substep {cp}: x {r['dx']:.2e} (per particle {r['ppx']:.2e})"
+        if r["one_step"] is not None:
+            ex, ev, evpp = r["one_step"]
+            assert ex < 1e-4 and ev < 1e-4, f"{what} substep {cp}: one-substep map dx {ex:.2e} dv {ev:.2e}"
+        floor = 1e-4 * max(r["vmax"], 1e-3)     # where the ensemble itself is below the north-star tolerance, that tolerance is the bound
+        for i, n in enumerate(names):
+            h = float(np.median(hip[:, i]))
+            lo, hi = float(pairs[:, i].min()), float(pairs[:, i].max())
+            margin = MAX_MARGIN if n == "max" else Q_MARGIN
+            assert h <= max(margin * hi, floor), f"{what} substep {cp}: {n} of |dv| {h:.2e} m/s above {margin} x the ensemble's {hi:.2e}"
+            # ... and not BELOW the ensemble either (a HIP run that stayed implausibly close to one oracle order would not be running the
+            # same dynamics): only meaningful where the ensemble has spread at all
+            if n != "max" and lo > floor:
+                assert h >= lo / margin, f"{what} substep {cp}: {n} of |dv| {h:.2e} m/s below the ensemble's {lo:.2e} / {margin}"
 
 
 def test_s3_one_frame_of_the_reference_cadence_400_substeps(oracle_lib):
     """One frame as the reference's drivers run it -- 400 substeps, the body advected by mesh_x + k dt mesh_v inside the library
-    (train_material_params.py:616-626) -- on the full-size garment with collider, mover and swaying body, in four fused calls of
-    100, against the OpenMP oracle at every call's end.  x within 1e-4 (also per particle).  v within 2 x the oracle's distance
-    from ITSELF under another summation order (measured here: the cloth QR of the HIP path is the oracle's bit for bit, what is
-    left is the rounding of the transfers, and the oracle moves by as much when only the order of its atomic adds changes:
-    3.6e-3 of the top speed at substep 100, profiles/r03_full_parity_garment-120k-aniso.json)."""
+    (train_material_params.py:616-626) -- on the full-size garment with collider, mover and swaying body, in fused calls of
+    100, against an ensemble of five OpenMP oracle runs at every call's end: statements (a), (b), (c) above."""
     sc, rows = _follow("garment-120k-aniso", [100, 200, 300, 400])
-    assert sc.n_elements == 79600 and sc.n_vertices == 40000
+    assert sc.n_elements == 79600 and sc.n_vertices == 40000 and sc.gamma > 0
     _check(rows, "S3")
 
 
 def test_s4_sheet_500k_1000_substeps_north_star_protocol(oracle_lib):
     """BASELINE.json's protocol on the headline workload in the driver-run suite: 497,762 particles, 256^3, 1000 substeps
-    against the OpenMP oracle (x and v after N substeps)."""
+    against the OpenMP oracle ensemble (x and v after N substeps): statements (a), (b), (c)."""
     sc, rows = _follow("sheet-500k", [100, 300, 600, 1000])
-    assert sc.n_particles == 497762 and sc.n_grid == 256
-    # the MAXIMUM of |dv| over 500k particles after 1000 substeps of amplified rounding is an extreme-value statistic: round 3 measured
-    # 0.5-1.0 x the oracle's self-distance, round 4 one run with 1.84 x (3.4e-3 against 1.9e-3 m/s) and one with 0.66 x.  The maximum
-    # keeps 2.5 x here; the 99.9th percentile -- the robust form of the same statement -- is held to 2 x like everything else.
-    _check(rows, "S4", max_factor=2.5)
+    assert sc.n_particles == 497762 and sc.n_grid == 256 and sc.gamma > 0
+    _check(rows, "S4")
+
+
+@pytest.mark.parametrize("name,n_p", [("garment-120k-aniso", 119600), ("sheet-500k", 497762)])
+def test_gamma0_cloth_holds_1e_4_on_x_and_v_for_1000_substeps(name, n_p, oracle_lib):
+    """(d): S3 (collider, mover, swaying body) and S4 (the headline sheet) without the shear term: 1000 substeps, x AND v of every
+    checkpoint within the north star's 1e-4 of the oracle -- strictly, no envelope (and the one-substep map beside it)."""
+    sc, rows = _follow(name, [100, 300, 600, 1000], gamma0=True, k_oracles=1)
+    assert sc.n_particles == n_p and sc.gamma == 0.0
+    for r in rows:
+        print(f"{name} gamma=0 substep {r['substep']}: rel dx {r['dx']:.2e} rel dv {r['dv_rel']:.2e} one-substep map {r['one_step']} top speed {r['vmax']:.2f}")
+        assert r["dx"] < 1e-4 and r["ppx"] < 1e-4 and r["dv_rel"] < 1e-4, r
+        assert r["one_step"][0] < 1e-4 and r["one_step"][1] < 1e-4, r
 
 
 def test_s4_sheet_500k_20_substeps(oracle_lib):
