@@ -56,11 +56,11 @@ def phase_bytes(sc, n_active, n_coll, n_mov):
 # argument selects the fused form; k_g2p<true> also does the grid stage)
 FUSED_BYTES_NOTE = ("fused loop: k_stress_elem<true> also finalizes the previous substep's elements (g2p_e's x/v/d1/d2 part), "
                     "k_g2p<true> also runs the grid stage; bytes are attributed to the launch that moves them")
-PHASE_KERNELS = {"p2g": ["k_p2g"], "g2p_v": ["k_g2p"], "grid_update": ["k_grid<true>"],
+PHASE_KERNELS = {"p2g": ["k_p2g"], "g2p_v": ["k_g2p", "k_g2p_stress"], "grid_update": ["k_grid<true>"],
                  "compute_stress_from_F_trial": ["k_stress_elem<true>", "k_stress_trad"], "g2p_e": ["k_elem_finalize"]}
 
 
-def pmc_traffic(phase, workload):
+def pmc_traffic(phase, workload, only=None):
     """HBM bytes per launch of a phase's kernels from the newest committed PMC summary (profiles/*_pmc.json, written by
     tools/summarize_prof.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command; reads
     carry the gfx950 x2 correction).  PMC counters cannot be collected from inside the process, so this is the profile of
@@ -71,7 +71,7 @@ def pmc_traffic(phase, workload):
         return None, None
     prof = json.load(open(files[-1]))
     tot = 0.0
-    for want in PHASE_KERNELS.get(phase, []):
+    for want in ([only] if only else PHASE_KERNELS.get(phase, [])):
         for k, e in prof["kernels"].items():
             if k == want or ("<" not in want and k.split("<")[0] == want):
                 tot += e["hbm_read_bytes"] + e["hbm_write_bytes"]
@@ -170,8 +170,11 @@ def _main(out_stream):
                     "call otherwise); 0 = off")
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
+    mark = lambda what: print(f"[bench +{time.perf_counter() - t_start:.1f}s] {what}", file=sys.stderr, flush=True)   # (stderr: where the time of a run goes)
     import torch
     from mpmavatar_amd import harness, scenes
+    mark("imports")
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs MI355X GPUs (the solver has no CPU path)")
@@ -248,9 +251,11 @@ def _main(out_stream):
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item())
 
+    mark("scene + solver built")
     if args.pre_advance > 0:
         run(args.pre_advance)
     run(args.warmup)
+    mark("warm-up done")
     # A window of K substeps is K x ~65 us: with the driver's K = 20 one window is 1.3 ms, shorter than the clock ramp of an idle GPU
     # and than a single re-sort, and one such sample was 14 % below the 400-substep figure.  Short windows are
     # therefore repeated back to back -- `windows` of exactly K substeps each, every one bracketed by barrier + synchronize -- and
@@ -272,6 +277,7 @@ def _main(out_stream):
                    "exchange": transport},
     }
 
+    mark("headline windows timed")
     # N > 1: everything below this point is extra information around a headline value that is already measured.  It involves more
     # collectives, a second sharded scene and thousands of further substeps on hardware this code has never run on: if it is not through
     # within --extras-budget seconds, rank 0 prints the line as far as it got and all ranks leave (same timer on every rank).
@@ -310,9 +316,14 @@ def _main(out_stream):
                 "p2g": pb["p2g"] + 116 * sc.n_traditional + 28 * n_col + 16 * n_mov,                   # + trad. stress, splats
                 "g2p_v": pb["g2p_v"] + 28 * n_act + 40 * n_col + 16 * n_mov,                            # + grid stage
             }
+            # round 5, cloth scenes: the g2p launch also finalizes the elements and runs the next substep's stress update (k_g2p_stress,
+            # "stress ahead"): a substep of the timed loop is TWO launches, and this one carries both phases' algorithmic bytes
+            ahead = cloth and sv.stats().get("stress_ahead_launches", 0) > 0
+            if ahead:
+                fused_bytes["g2p_v"] += fused_bytes["compute_stress_from_F_trial"]
             fused_bytes["g2p2g"] = fused_bytes["p2g"] + fused_bytes["g2p_v"]   # (traditional-only scenes: one launch does both)
-            fused_kernel = {"compute_stress_from_F_trial": "k_stress_elem<true>", "p2g": "k_p2g", "g2p_v": "k_g2p", "rebin": "re-sort",
-                            "g2p2g": "k_g2p2g"}
+            fused_kernel = {"compute_stress_from_F_trial": "k_stress_elem<true>", "p2g": "k_p2g", "g2p_v": "k_g2p_stress" if ahead else "k_g2p",
+                            "rebin": "re-sort", "g2p2g": "k_g2p2g"}
             sv.enable_profiling(True, fused=True)
             sv.time_profile.clear()
             sv.kernel_profile.clear()
@@ -336,13 +347,15 @@ def _main(out_stream):
                      "timed_by": "kernel start/stop stamps" if ks else "event bracket"}
                 if name == "rebin":
                     k["ms_per_substep"] = sum(samples) / n_prof
-                if name in fused_bytes and ms > 0 and (cloth or name != "compute_stress_from_F_trial"):
+                if ahead and name == "compute_stress_from_F_trial":
+                    k["note"] = "first substep of the call only: afterwards the stress update rides in k_g2p_stress"
+                if name in fused_bytes and ms > 0 and (cloth or name != "compute_stress_from_F_trial") and not (ahead and name == "compute_stress_from_F_trial"):
                     k["alg_bytes"] = fused_bytes[name]
                     k["GBps"] = fused_bytes[name] / (ms * 1e-3) / 1e9
                     k["frac"] = k["GBps"] / HBM_PEAK_GBS
                     if k["GBps"] > COPY_CEILING_GBS:
                         k["exceeds_copy_ceiling"] = True   # read `traffic_frac`, not `frac`, for this launch
-                    tr, src = pmc_traffic(name, args.scene)
+                    tr, src = pmc_traffic(name, args.scene, only=fused_kernel.get(name) if name == "g2p_v" else None)
                     if tr:
                         k["traffic"], k["traffic_GBps"], k["traffic_source"] = tr, tr / (ms * 1e-3) / 1e9, src
                         k["traffic_frac"] = k["traffic_GBps"] / HBM_PEAK_GBS
@@ -427,6 +440,7 @@ def _main(out_stream):
                            "channels_per_node": ch, "peers_of_rank0": len(box["ss"].static) - 1,
                            "halo_exchange_us": next((k["ms"] * 1e3 for k in kernels if k["phase"] == "halo_exchange"), None),
                            "re_partitions": box["ss"].migrations}
+    mark("kernel events")
     if sharded and world > 1 and not args.no_shard_floor:
         # What this N can reach at best: rank 0 runs ITS shard (owned particles + ghost copies) as an ordinary single-GPU scene, no
         # exchange at all -- the per-rank compute floor of the slab decomposition (three latency-floored launches per substep).
@@ -453,6 +467,7 @@ def _main(out_stream):
             out["shard_floor"] = {"error": f"{type(e).__name__}: {e}"}
         finally:
             barrier()               # (every rank, whatever happened on rank 0: the others wait here)
+    mark("shard floor")
     if sharded and world > 1 and not weak_only and not args.no_weak and (args.scene == "sheet-500k" or args.weak_n):
         # the regime the slab decomposition is made for: the same per-rank work at every N (one sheet's worth of particles per
         # rank: N stacked copies of the headline sheet in the same grid).  Reported beside the strong-scaling headline value.
@@ -475,6 +490,7 @@ def _main(out_stream):
             del wbox
         except Exception as e:  # noqa: BLE001 - the headline line must come out whatever happens here
             out["weak_scaling"] = {"error": f"{type(e).__name__}: {e}"}
+    mark("weak scaling")
     if args.advance > 0:
         # the steady state: after `advance` more substeps the sheet lies draped over the sphere, moves at metres per second and
         # the particle order is rebuilt every few dozen substeps; re-sorts inside the window are part of the number
@@ -492,8 +508,10 @@ def _main(out_stream):
             out["draped"].update({"n_active_nodes": st["n_active_nodes"], "n_collider_nodes": st["n_collider_nodes"],
                                   "fallback_particles": st["n_fallback_particles"],
                                   "substep_frac_of_hbm_peak": b_d["substep"] / (out["ms_per_step_draped"] * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    mark("draped state")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sc)
+        mark("cpu baseline")
     if extras_timer is not None:
         extras_timer.cancel()
     if rank == 0:

@@ -115,6 +115,9 @@ typedef struct {
                                    with an interval too long for their speed) and the results are not valid */
   int64_t g2p2g_launches;       /* fast mode, scenes of traditional particles only: substep boundaries that ran as ONE launch
                                    (g2p of substep n + stress and p2g of substep n + 1, csrc/g2p.hip k_g2p2g) */
+  int64_t stress_ahead_launches; /* fast mode, cloth scenes: substeps that ran as TWO launches -- the g2p launch also finalized the
+                                   elements and ran the next substep's compute_stress_from_F_trial (csrc/g2p.hip k_g2p_stress);
+                                   inside one mpmhip_steps call only, never across a call boundary */
 } mpmhip_stats;
 
 /* ---- lifetime ----------------------------------------------------------------- */

@@ -384,7 +384,7 @@ int mpmhip_steps(mpmhip_ctx *c, float dt, int32_t n, const float *mesh_x, const 
   for (int k = 0; k < n; ++k) {
     // mesh_x + substep_size*substep_local*mesh_v, train_material_params.py:623, evaluated inside the kernels
     StepArgs a{dt, mesh_x, mesh_v, (float)((double)dt * (double)k), k == n - 1, joint_traditional_v,
-               joint_traditional_v ? n_joint_t : 0, joint_verts_v, joint_faces_v};
+               joint_traditional_v ? n_joint_t : 0, joint_verts_v, joint_faces_v, k < n - 1};
     int rc = step_checked(c, a);
     if (rc) return rc;
   }

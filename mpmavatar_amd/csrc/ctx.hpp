@@ -50,6 +50,7 @@ struct StepArgs {
   const float *joint_t_v;
   int n_joint_t;
   const float *joint_v_v, *joint_f_v;
+  bool more = false;             // another substep of the same mpmhip_steps call follows at once (nothing reads particles in between)
 };
 
 struct Phase {
@@ -112,6 +113,7 @@ struct mpmhip_ctx {
   // and ScopedPhase reports both times (kernel, bracket).
   hipEvent_t kev0 = nullptr, kev1 = nullptr;
   bool kev_pending = false;
+  bool phase_open = false;  // a ScopedPhase bracket is open: the context has ONE ev0 / ev1 pair, an inner bracket would re-record it
 
   mpm::FastState *fast = nullptr;
   bool caller_dirty = true;    // caller arrays newer than the internal state (fast mode)
@@ -140,6 +142,11 @@ struct ScopedPhase {
   int idx;
   ScopedPhase(mpmhip_ctx *ctx, const char *name) : c(ctx), idx(-1) {
     if (!c->profiling && !c->prof_fused) return;
+    // nested bracket (e.g. the pending g2p flushed from inside the re-sort's bracket: rebin -> flush_elements -> flush_g2p): the
+    // outer phase keeps the event pair and its time includes the inner work (the inner one used to re-record ev0 and the
+    // outer "rebin" time was under-reported)
+    if (c->phase_open) return;
+    c->phase_open = true;
     for (size_t i = 0; i < c->phases.size(); ++i)
       if (c->phases[i].name == name || std::string(c->phases[i].name) == name) idx = (int)i;
     if (idx < 0) {
@@ -151,6 +158,7 @@ struct ScopedPhase {
   }
   ~ScopedPhase() {
     if (idx < 0) return;
+    c->phase_open = false;
     (void)hipEventRecord(c->ev1, c->stream);
     (void)hipEventSynchronize(c->ev1);
     float ms = 0.f, kms = 0.f;

@@ -263,7 +263,7 @@ static_assert(SIG_RING0 + SIG_RING_N <= SIG_WORDS && (SIG_RING_N & (SIG_RING_N -
 // [CNT_PAR0 + 2 * parity + {0, 1}] the same two flags per substep parity: the kernels of substep s raise slot s & 1 and the
 // p2g launch of substep s + 1 posts and clears it, so a ring entry holds exactly the flags of ONE finished substep (a plain
 // snapshot of the sticky flags raced with the workgroups of the posting launch that raise them)
-enum { CNT_FACE = 5, CNT_DRIFT = 6, CNT_PAR0 = 16, CNT_MMIN = 24, CNT_MMAX = 25, CNT_N = 32 };  // (MMIN / MMAX: smallest positive / largest
+enum { CNT_FACE = 5, CNT_DRIFT = 6, CNT_PAR0 = 16, CNT_MMIN = 24, CNT_MMAX = 25, CNT_NSEL = 26, CNT_N = 32 };  // (MMIN / MMAX: smallest positive / largest
                                                                                              // particle mass as float bits, k_mass_span)
 
 // Fused halo add (multi-GPU, peer-mapped halos): k_g2p<.., HALO = true> adds the neighbour rank's contribution to a shared
@@ -292,6 +292,8 @@ struct GridPtrs {
   float lookahead;  // substeps the early warning of the adaptive re-sort looks ahead (k_p2g)
   HaloIn halo;      // multi-GPU: see HaloIn
   int stagger, stagger_groups, stagger_first;  // p2g: first-round workgroups wait (wave slot % groups) * stagger * 1024 cycles
+  float *xprev;     // [3][n_v] vertex positions as p2g read them (cloth scenes; null otherwise): the stable copy the fused g2p + stress
+                    // launch gathers the element's corners at while vertex lanes of other workgroups move x in place (StressAhead)
   unsigned long long *trace;  // per-workgroup timeline (MPMHIP_DEBUG builds, mpmhip_debug_wgtrace); null otherwise
   int dbg;          // MPMHIP_DBG bitmask (MPMHIP_DEBUG builds only; perf experiments, results are wrong): 1 skip p2g flush, 2 skip the p2g
                     // scatter, 8 / 16 skip vertex-force / stress loads, 128 skip the LDS atomics only, 256 skip the splat workgroups, 2048 skip the clearing workgroups; 64 (results stay
@@ -485,6 +487,13 @@ __device__ __forceinline__ void stress_elem_body(int e, const Bufs &b, F3 *ef, c
     if (sel == 0 && ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u)) raise_drift(counters, step_id);
   }
 }
+
+// Arguments of the fused g2p + element finalize + stress launch (g2p_body<.., STRESS = true>, round 5): see "stress ahead" in g2p_device.hpp
+struct StressAhead {
+  F3 *ef;                 // corner forces [3][n_e] (+ the zero slot)
+  const int *face_slot;   // [3][n_e] element -> vertex slots (sorted order)
+  float friction_coeff;
+};
 
 // ------------------------------------------------------------------------------------------------
 // chunk tiles and chunk records: shared by p2g (p2g_device.hpp) and g2p (g2p_device.hpp)

@@ -186,6 +186,13 @@ struct FastState {
   Pinned<int> h_ranges, h_plist;
   Pinned<ChunkRec> h_chunks, h_chunks_g;
   bool elem_pending = false;  // element finalise of the last substep still to be done (fused into the next stress)
+  // stress ahead (round 5, g2p_device.hpp): the g2p launch of the substep before also finalized the elements and ran THIS substep's
+  // stress update; step_phase_a then has no stress launch.  Only ever set between two substeps of one mpmhip_steps call.
+  bool stress_ahead = true;        // feature switch (MPMHIP_STRESS_AHEAD=0 turns it off)
+  bool stress_done_ahead = false;  // the state flag
+  bool all_simulated = false;      // no particle with selection != 0 (counted at every import with the mass span)
+  bool rebin_polled = false;       // step_phase_b already looked at the drift flags for the coming substep
+  int64_t n_stress_ahead = 0;      // launches of k_g2p_stress (statistics)
   int steps_since_rebin = 0;
   hipEvent_t ev_flag = nullptr;
   bool flag_pending = false;
@@ -276,6 +283,7 @@ void launch_p2g(mpmhip_ctx *c, bool trad, bool jt, unsigned grid, int n_chunks, 
 void launch_stress_elem(mpmhip_ctx *c, int mode, const SplatArgs &sa);
 void launch_stress_trad(mpmhip_ctx *c, float dt);
 void launch_g2p(mpmhip_ctx *c, bool fused, bool two, float dt, const GridParams &gp, const BCList &bcl);
+void launch_g2p_stress(mpmhip_ctx *c, float dt, const GridParams &gp, const BCList &bcl);
 void launch_g2p2g(mpmhip_ctx *c, unsigned grid, float dt, const GridRead &rd, const SplatArgs &sa, const TradParams &tp, const GridParams &gp,
                   const BCList &bcl);
 

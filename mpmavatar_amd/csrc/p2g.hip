@@ -53,7 +53,6 @@ __global__ __launch_bounds__(PT) void k_p2g(const ChunkRec *recs, int n_chunks, 
   __shared__ float red[8];
   p2g_body<STEPS, TRAD, JT, FX>(recs, n_chunks, b, va, d, rpic, dt, g, sa, tp, tile, esc, esc_n, red);
 }
-
 }  // namespace
 
 // ---- launchers of the substep's kernels (the only places that name their template instantiations) -------------------------

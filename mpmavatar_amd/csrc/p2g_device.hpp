@@ -572,7 +572,10 @@ __device__ __forceinline__ void col_splat_flush(const double *tile, int ox, int 
 // pairs -- so that a bin costs one clearing, one scatter and one flush instead of two of each with five barriers in between.  The
 // workgroup tile is 7 * 536 doubles = 30 KB instead of 24.6 KB: still five workgroups per CU (VGPR-bound at five).
 constexpr int SPLAT7_SI = 67, SPLAT7_SJ = 8, SPLAT7_S = 536;  // 7*67 + 7*8 + 7 = 532 < 536
-constexpr int P2G_TILE_DOUBLES = 7 * SPLAT7_S > 4 * TILE_PAD ? 7 * SPLAT7_S : 4 * TILE_PAD;
+#ifndef SPLAT_ONEPASS
+#define SPLAT_ONEPASS 1  // experiment switch: 0 = small bins take the two-pass path through the four-channel tile (24.6 KB per workgroup)
+#endif
+constexpr int P2G_TILE_DOUBLES = (SPLAT_ONEPASS && 7 * SPLAT7_S > 4 * TILE_PAD) ? 7 * SPLAT7_S : 4 * TILE_PAD;
 constexpr int SPLAT_SMALL = 32;  // faces per bin up to which the splat workgroup maps lanes to (face, node) pairs
 // PASSES: bit 0 = the weight / velocity pass (w, w v_face: collider channels 0-3, sets col_flag), bit 1 = the normal pass (w n:
 // channels 4-6).  3 = both in one workgroup, as rounds 1-3 did.  Round 4: in cloth scenes the two passes ride in DIFFERENT
@@ -597,7 +600,7 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
   }
   // (the one-pass path takes the ballot -- i.e. the wait for the flags -- right before its flush: in front of the tile clearing it was
   // one more dependent memory level at the head of the workgroup)
-  const bool one_pass = PASSES == 3 && fb.cnt <= SPLAT_SMALL;
+  const bool one_pass = PASSES == 3 && SPLAT_ONEPASS && fb.cnt <= SPLAT_SMALL;
   unsigned long long act_mask = one_pass ? 0ull : __ballot(nb_act);
   const int end = fb.start + fb.cnt;
   if (fb.cnt <= SPLAT_SMALL) {
@@ -608,7 +611,7 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
     // second (normal) pass through the four-channel tile.
     const int fi = l >> 5, n = l & 31;
     const int ni = n / 9, nj = (n / 3) % 3, nk = n % 3;
-    if (PASSES == 3) {  // one pass through a seven-channel tile (see SPLAT7_S)
+    if (PASSES == 3 && SPLAT_ONEPASS) {  // one pass through a seven-channel tile (see SPLAT7_S)
       // the first pair's face indices are requested together with the block flags, BEFORE the tile is cleared: behind the barrier they
       // were a memory level of their own (record -> flags -> [clear, barrier] -> indices -> vertices; now record -> flags + indices -> vertices)
       int pre_i[2][3];
@@ -927,6 +930,12 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
     if ((unsigned)fx > 5u || (unsigned)fy > 5u || (unsigned)fz > 5u) raise_drift(g.counters, g.step_id);
   }
   WGT(g, 0, 2);  // particle loads + first adjacency batch here, tile cleared
+  // (stress ahead, g2p_device.hpp) the vertex positions of this substep, kept for the g2p launch: its element lanes gather at their
+  // corners while vertex lanes of other workgroups move b.all's x in place
+  if (g.xprev && valid && cls == 2) {
+    const int vl = s - d.n_nv;
+    g.xprev[vl] = raw.x.x; g.xprev[d.n_v + vl] = raw.x.y; g.xprev[2 * d.n_v + vl] = raw.x.z;
+  }
   P2GParticle q = p2g_finish<TRAD>(raw, b, va, valid, cls, s, d, rpic, dt, w_v, tp);
   FxScale fs{1.0f, 1.0f, 1.0f, 1.0f};
   if (FX) {

@@ -322,6 +322,10 @@ __global__ void k_mass_span(const float *mass, const int *sel, int n, int *count
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
   if ((threadIdx.x & 63) == 0) { atomicMin(counters + CNT_MMIN, lo); atomicMax(counters + CNT_MMAX, hi); }
+  // ... and whether any particle is NOT simulated (selection != 0: frozen, or a ghost copy): the fused g2p + stress launch moves an
+  // element's corners itself and only covers scenes in which every corner moves (FastState::all_simulated)
+  unsigned long long ns = __ballot(i < n && sel[i] != 0);
+  if ((threadIdx.x & 63) == 0 && ns) atomicAdd(counters + CNT_NSEL, (int)__popcll(ns));
 }
 
 
@@ -591,7 +595,7 @@ int do_import(mpmhip_ctx *c) {
                        f->dist ? 1 : 0);
     // mass span of the scene: decides between the fixed-point and the fp64 chunk tile of p2g at the next re-sort (see rebin)
     MPM_HIP_CHECK(c, hipMemsetD32Async((hipDeviceptr_t)(f->g.counters + CNT_MMIN), 0x7f7fffff, 1, c->stream));
-    MPM_HIP_CHECK(c, hipMemsetD32Async((hipDeviceptr_t)(f->g.counters + CNT_MMAX), 0, 1, c->stream));
+    MPM_HIP_CHECK(c, hipMemsetD32Async((hipDeviceptr_t)(f->g.counters + CNT_MMAX), 0, 2, c->stream));   // (MMAX and NSEL)
     hipLaunchKernelGGL(k_mass_span, nblk(d.n_p), TPB, 0, c->stream, (const float *)c->st.particle_mass, (const int *)c->st.particle_selection,
                        d.n_p, f->g.counters);
     f->mass_span_pending = true;
@@ -773,7 +777,7 @@ int rebin(mpmhip_ctx *c) {
       hipLaunchKernelGGL(k_fbin_compact, nblk(cap_A), TPB, 0, s, f->alist, f->rcnt, cap_A, f->fb_start, f->fb_cnt, f->fbins, cap_fb);
     MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 32, f->rcnt, RC_N * sizeof(int), hipMemcpyDeviceToHost, s));
     if (f->mass_span_pending)
-      MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 44, f->g.counters + CNT_MMIN, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+      MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 44, f->g.counters + CNT_MMIN, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
     MPM_HIP_CHECK(c, hipStreamSynchronize(s));  // the one wait of a re-sort
     if (f->mass_span_pending) {
       // The fixed-point chunk tile gives every chunk ONE scale, from the sum of its lanes' bounds: a particle whose mass is
@@ -784,6 +788,7 @@ int rebin(mpmhip_ctx *c) {
       memcpy(&lo, f->h_pin + 44, 4); memcpy(&hi, f->h_pin + 45, 4);
       f->mass_span = (hi > 0.0f && lo < 3.0e38f) ? hi / lo : 1.0f;
       f->p2g_fixed_now = f->p2g_fixed && (f->p2g_fixed_forced || f->mass_span <= 1.0e5f);
+      f->all_simulated = f->h_pin[46] == 0;
       f->mass_span_pending = false;
     }
     const int *h = f->h_pin + 32;

@@ -191,6 +191,17 @@ class ShardedSim:
     migrations: int = 0
 
 
+def global_p2g_tile(sc: Scene) -> str:
+    """The p2g accumulator every rank of a sharded run uses: "f64" when the masses of the simulated particles of the WHOLE scene span
+    more than 1e5 (the threshold of MPMHIP_P2G_TILE_AUTO, csrc/resort.hip), else "fixed"."""
+    m = np.asarray(sc.vol, np.float64) * float(sc.density)
+    if sc.selection is not None:
+        m = m[np.asarray(sc.selection) == 0]
+    m = m[m > 0]
+    span = float(m.max() / m.min()) if m.size else 1.0
+    return "f64" if span > 1.0e5 else "fixed"
+
+
 def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int = 0, _carry: dict = None, _cuts=None) -> ShardedSim:
     """Collective.  ``_carry`` / ``_cuts`` (re-partition only): per-particle state in GLOBAL order to continue from and the slab
     boundaries to cut at, see repartition()."""
@@ -198,28 +209,53 @@ def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int 
     import torch
     import torch.distributed as dist
     from . import harness
-    shard = partition(sc, world, _cuts)[rank]
-    sim = harness.build_solver(shard.scene, device, mode="fast")
-    sv = sim.solver
-    if _carry is not None:
-        _apply_carry(sim, shard, sc, _carry)
-    sv._bind(sim.model, sim.state)
-    sv._call("mpmhip_dist_enable")
-    ghost_g2p = os.environ.get("MPMHIP_DIST_GHOST_G2P", "1") != "0"
-    sv._call("mpmhip_dist_set_ghost_mode", 1 if ghost_g2p else 0)
-    ss = ShardedSim(shard, sim, dist.get_backend(), int(rebin_interval), ghost_g2p=ghost_g2p)
-    ss.global_scene = sc
     dev = torch.device(device)
-    i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.int32), device=dev)
-    for q in sorted(set(shard.send_p) | set(shard.recv_p)):
-        ss.static[q] = dict(send_p=i32(shard.send_p[q]), recv_p=i32(shard.recv_p[q]), send_e=i32(shard.send_e[q]),
-                            recv_e=i32(shard.recv_e[q]))
-        n_s = 6 * len(shard.send_p[q]) + 3 * len(shard.send_e[q])
-        n_r = 6 * len(shard.recv_p[q]) + 3 * len(shard.recv_e[q])
-        ss.static[q]["gs"] = torch.zeros(max(n_s, 1), dtype=torch.float32, device=dev)
-        ss.static[q]["gr"] = torch.zeros(max(n_r, 1), dtype=torch.float32, device=dev)
-    nb = sv._lib.mpmhip_dist_num_blocks(sv._ctx)
-    ss.static["map"] = torch.zeros(nb, dtype=torch.uint8, device=dev)
+    backend = dist.get_backend()
+    # (1) Everything that can fail on ONE rank alone -- host memory for the partition, device memory for the solver and the exchange
+    # buffers -- runs BEFORE the first collective of the build, and the ranks vote on it: a rank that raised here used to go straight
+    # to its caller's all_reduce while the others were inside the peer-handle exchange below (mismatched collectives: a hang or
+    # undefined results on RCCL instead of the clean collective error repartition() promises).
+    ss, err = None, None
+    try:
+        shard = partition(sc, world, _cuts)[rank]
+        # MPMHIP_P2G_TILE_AUTO means "the SCENE's masses span more than 1e5" (include/mpmhip.h): a rank decides it from the particles it
+        # holds, so with slabs every rank would decide from its own shard and ranks could run different accumulator numerics on the
+        # halo blocks they share.  The global scene is on every rank here: decide once, the same everywhere.
+        sim = harness.build_solver(shard.scene, device, mode="fast", p2g_tile=global_p2g_tile(sc))
+        sv = sim.solver
+        if _carry is not None:
+            _apply_carry(sim, shard, sc, _carry)
+        sv._bind(sim.model, sim.state)
+        sv._call("mpmhip_dist_enable")
+        ghost_g2p = os.environ.get("MPMHIP_DIST_GHOST_G2P", "1") != "0"
+        sv._call("mpmhip_dist_set_ghost_mode", 1 if ghost_g2p else 0)
+        ss = ShardedSim(shard, sim, backend, int(rebin_interval), ghost_g2p=ghost_g2p)
+        ss.global_scene = sc
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.int32), device=dev)
+        for q in sorted(set(shard.send_p) | set(shard.recv_p)):
+            ss.static[q] = dict(send_p=i32(shard.send_p[q]), recv_p=i32(shard.recv_p[q]), send_e=i32(shard.send_e[q]),
+                                recv_e=i32(shard.recv_e[q]))
+            n_s = 6 * len(shard.send_p[q]) + 3 * len(shard.send_e[q])
+            n_r = 6 * len(shard.recv_p[q]) + 3 * len(shard.recv_e[q])
+            ss.static[q]["gs"] = torch.zeros(max(n_s, 1), dtype=torch.float32, device=dev)
+            ss.static[q]["gr"] = torch.zeros(max(n_r, 1), dtype=torch.float32, device=dev)
+        nb = sv._lib.mpmhip_dist_num_blocks(sv._ctx)
+        ss.static["map"] = torch.zeros(nb, dtype=torch.uint8, device=dev)
+    except Exception as e:  # noqa: BLE001 - reported collectively right below
+        err = e
+    if world > 1:
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32)
+        if backend == "nccl":
+            ok = ok.to(dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            if ss is not None:
+                ss.sim.solver.close()
+            raise RuntimeError("mpmavatar_amd.dist.build_sharded: the local part of the build failed on "
+                               + ("this rank: " + repr(err) if err is not None else "another rank") + " (every rank raises)") from err
+    elif err is not None:
+        raise err
+    # (2) the collective part: transport set-up (communicator, peer links)
     want = os.environ.get("MPMHIP_DIST_TRANSPORT", "rccl" if ss.backend == "nccl" else "torch")
     if want == "rccl":
         # every rank must end up on the same transport: agree on success before switching

@@ -49,6 +49,26 @@ def variant_slice(rank: int, world: int, n: int = len(DELTAS)) -> range:
     return range(lo, hi)
 
 
+def request_hw_queues(n: int = 8) -> bool:
+    """One hardware queue per HIP stream for the concurrent FD step.  The ROCm runtime multiplexes all HIP streams of a process onto
+    GPU_MAX_HW_QUEUES = 4 hardware queues; four solver contexts on four streams beside torch's own then share queues and take turns
+    (36.0 k substeps/s at the S3 size with the default, 45.3 k with 8, nothing more with 16: profiles/HISTORY.md).  The runtime reads the
+    variable at its FIRST HIP call, so this only works before anything in the process touched the device: call it (or export the
+    variable) before the first torch.cuda / solver call.  A value the user set wins.  Returns True when the setting will take effect;
+    warns and returns False when the device is already initialised (the FD step still runs, on shared queues)."""
+    import os
+    import warnings
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        return True                      # the user's (or an earlier call's) choice
+    if torch.cuda.is_initialized():
+        warnings.warn("mpmavatar_amd.fd: the HIP runtime is already initialised, GPU_MAX_HW_QUEUES cannot be raised any more; the "
+                      "concurrent finite-difference contexts will share hardware queues (about -20 % throughput).  Call "
+                      "mpmavatar_amd.fd.request_hw_queues() or export GPU_MAX_HW_QUEUES=8 before the first CUDA/HIP call.", stacklevel=2)
+        return False
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(n))
+    return True
+
+
 class MaterialFD:
     """train_material_params.py:575-728 on top of the shim.  ``scene`` supplies the garment (vertices, faces, collider
     mesh, joints, fixed nu / gamma / kappa); ``frames`` the driving motion and targets."""
@@ -77,6 +97,8 @@ class MaterialFD:
             self.concurrent, self.sims, self.pool = False, [], None
             return
         self.concurrent = bool(concurrent) and len(self.variants) > 1
+        if self.concurrent:
+            request_hw_queues()          # (opt-in by use: only the concurrent contexts want it; no import side effect)
         n_ctx = len(self.variants) if self.concurrent else 1
         self.streams = [torch.cuda.Stream(self.device) for _ in range(n_ctx)] if self.concurrent else [None]
         self.sims = []

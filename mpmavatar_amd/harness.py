@@ -26,7 +26,7 @@ class Sim:
     steps_done: int = 0
 
 
-def build_solver(sc: Scene, device="cuda:0", mode=None, rebin_interval=0) -> Sim:
+def build_solver(sc: Scene, device="cuda:0", mode=None, rebin_interval=0, p2g_tile="auto") -> Sim:
     dev = torch.device(device)
     t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
     n_p, n_e, n_v, n_t = sc.n_particles, sc.n_elements, sc.n_vertices, sc.n_traditional
@@ -47,7 +47,7 @@ def build_solver(sc: Scene, device="cuda:0", mode=None, rebin_interval=0) -> Sim
     model.init_other_params(n_grid=sc.n_grid, grid_lim=sc.grid_lim, device=dev)
     solver = MPMWARP(n_p, n_e, n_v, n_grid=sc.n_grid, grid_lim=sc.grid_lim, mesh_vertices=sc.mesh_vertices,
                      mesh_faces=sc.mesh_faces, num_joint_t=0, num_joint_v=sc.num_joint_v, num_joint_f=sc.num_joint_f,
-                     device=dev, mode=mode, rebin_interval=rebin_interval)
+                     device=dev, mode=mode, rebin_interval=rebin_interval, p2g_tile=p2g_tile)
     solver.set_parameters_dict(model, state, sc.params)
     state.reset_state(n_v, t(sc.x).clone(), t(sc.d).clone(), None, t(sc.v).clone(), tensor_R_inv=t(sc.R_inv).clone(),
                       device=dev, requires_grad=True)

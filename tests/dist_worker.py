@@ -42,7 +42,20 @@ def _sway_garment():
     return scenes.garment_cylinder(n_theta=32, n_h=24, n_grid=48, aniso=True, collider_subdiv=2, n_steps=200, sway=(0.5, 50.0, 20))
 
 
-SCENES = {"crossing": _crossing_cube, "sway": _sway_garment, "demohold": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=(10, 5, 64)),
+def _wide_sheet():
+    """A sheet wide enough for eight x-slabs of two to three grid blocks each (19 blocks of 4 cells across on a 128^3 grid; 27,266
+    particles): the 4- and 8-rank runs of the in-library loop."""
+    return scenes.sheet(n=96, n_grid=128, collider_subdiv=3, n_steps=100, span=(0.4, 1.6), y=1.22, sphere_r=0.2, sphere_c=(1.0, 0.98, 1.0),
+                        name="sheet-96x96")
+
+
+def _wide_sheet8():
+    """The same for eight ranks: the headline sheet's extent on its 256^3 grid (51 blocks across, 6.4 per slab: every shared block
+    has ONE neighbour rank, as on the real workload), thinned to 128 x 128 vertices (48,770 particles)."""
+    return scenes.sheet(n=128, n_grid=256, collider_subdiv=3, n_steps=100, name="sheet-128x128")
+
+
+SCENES = {"widesheet8": _wide_sheet8, "widesheet": _wide_sheet, "crossing": _crossing_cube, "sway": _sway_garment, "demohold": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=(10, 5, 64)),
           "garment": scenes.small_garment, "sheet": scenes.small_sheet, "cube": scenes.small_cube, "fastcube": _fast_cube,
           "demo": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=False)}
 

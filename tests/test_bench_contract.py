@@ -49,6 +49,7 @@ def test_live_bench_prints_exactly_one_json_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scene", "cube-8k", "--steps", "40", "--warmup", "10",
                         "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    print("\n".join(l for l in r.stderr.splitlines() if l.startswith("[bench +")))
     out = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(out) == 1, r.stdout[:500]
     _check(json.loads(out[0]), with_cpu=False)

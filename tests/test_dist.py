@@ -189,6 +189,26 @@ def test_in_library_loop_with_several_ranks(world, scene, steps, rebin, ghost_g2
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("halo", ["peer", "rccl"])
+@pytest.mark.parametrize("world", [4, 8])
+def test_in_library_loop_with_four_and_eight_ranks(world, halo):
+    """What `bench.py --gpus 4` / `--gpus 8` runs on a node -- `mpmhip_rccl_steps`, one process per rank -- with 4 and 8 ranks over the
+    RCCL stand-in on ONE GPU (the first contact with a real node must not be the first time the loop sees eight
+    ranks): interior ranks with two neighbours each, eight communicator members, 7 + 7 peer links, collective re-sorts every 8
+    substeps.  Result: the single context's trajectory; every rank takes the same re-sort decisions."""
+    import re
+    out = _launch(world, "gpu", "widesheet8" if world == 8 else "widesheet", 40,
+                  extra_env=_mock_rccl_env(MPMHIP_TEST_REBIN=8, MPMHIP_DIST_HALO=halo, MPMHIP_VERBOSE=1))
+    assert "max rel dx" in out and "(rccl, halos: " in out
+    assert out.count("halos: peer-mapped" if halo == "peer" else "halos: send/recv") == world, out[-2000:]
+    n = [int(x) for x in re.findall(r"rank \d+: (\d+) collective re-sorts", out)]
+    assert len(n) == world and len(set(n)) == 1
+    if halo == "peer":   # slabs of more than four blocks: every shared block has ONE neighbour rank, the fused halo path runs on every rank
+        fused = [int(x) for x in re.findall(r"fused halo substeps (\d+)", out)]
+        assert len(fused) == world and min(fused) > 0, out[-2000:]
+
+
+@pytest.mark.gpu
 def test_peer_link_failure_on_one_rank_sends_every_rank_back_to_send_recv():
     """The decision for peer-mapped halos is collective: rank 1 reports that its links failed (MPMHIP_LINK_FAULT), and
     all three ranks keep their halos on the send/recv groups -- with the same result."""

@@ -93,14 +93,17 @@ def _follow(name, checkpoints, gamma0=False, k_oracles=K_ORACLES):
     sc = scenes.REGISTRY[name]()
     if gamma0:
         sc.gamma = 0.0
+    # The members share the host's cores (the GPU boxes give the container 16: cpu.max): T // K threads each, the remainder to the
+    # first.  Members with the SAME thread count still differ from each other -- the interleaving of the threads' atomic adds is a
+    # race -- by as much as members with different counts (measured: 1.1e-6 .. 2.0e-6 m/s on a 48 x 48 sheet either way).
     T = omp_threads()
-    threads = [max(T - k, 2) for k in range(k_oracles)]
+    threads = [max(T // k_oracles + (1 if k < T % k_oracles else 0), 2) for k in range(k_oracles)] if k_oracles > 1 else [T]
     tmp = tempfile.mkdtemp(prefix="oracle_ensemble_")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, name, "1" if gamma0 else "0", str(t), os.path.join(tmp, f"o{k}.npz")]
                               + [str(c) for c in checkpoints], stdout=subprocess.DEVNULL) for k, t in enumerate(threads)]
     try:
-        probe = oracle_from_scene(sc, omp=True, n_threads=max(T // 2, 2))
+        probe = oracle_from_scene(sc, omp=True, n_threads=max(T // 4, 2) if k_oracles > 1 else T)
         sim = harness.build_solver(sc, "cuda:0", mode="fast")
         hip, done = [], 0
         for cp in checkpoints:

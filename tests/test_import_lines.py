@@ -52,10 +52,15 @@ def test_facade_from_the_package():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
-def test_package_import_asks_for_one_hardware_queue_per_stream():
-    """Importing the package sets GPU_MAX_HW_QUEUES for the four-context FD step unless the user chose a value (mpmavatar_amd/__init__.py)."""
+def test_hardware_queues_are_requested_by_the_fd_step_not_by_the_import():
+    """importing the package must not change the queue behaviour of every HIP user of the host process.  The concurrent FD
+    step asks for one hardware queue per stream itself (fd.request_hw_queues): sets GPU_MAX_HW_QUEUES when nothing has touched the
+    device yet, keeps a value the user chose."""
     import subprocess, sys
-    code = "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import mpmavatar_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
-    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip() == "8"
-    code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '2'; import mpmavatar_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
-    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip() == "2"
+    code = "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import mpmavatar_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))"
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip() == "None"
+    code = ("import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); from mpmavatar_amd import fd; print(os.environ.get('GPU_MAX_HW_QUEUES'), "
+            "fd.request_hw_queues(), os.environ['GPU_MAX_HW_QUEUES'])")
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split() == ["None", "True", "8"]
+    code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '2'; from mpmavatar_amd import fd; print(fd.request_hw_queues(), os.environ['GPU_MAX_HW_QUEUES'])"
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split() == ["True", "2"]

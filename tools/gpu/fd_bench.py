@@ -6,6 +6,7 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mpmavatar_amd import fd, scenes
+fd.request_hw_queues()   # before the first HIP call of the process (the sequential leg comes first and would initialise the device)
 
 a = [int(x) for x in sys.argv[1:]]
 n_theta, n_h, n_grid, n_frames, substeps = (a + [200, 200, 128, 2, 400][len(a):])[:5]
