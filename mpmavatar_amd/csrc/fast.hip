@@ -195,6 +195,7 @@ int fast_init(mpmhip_ctx *c) {
   f->p2g_fixed_now = f->p2g_fixed;
   if (const char *e = getenv("MPMHIP_G2P2G")) f->g2p2g = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_STRESS_AHEAD")) f->stress_ahead = atoi(e) != 0;
+  if (const char *e = getenv("MPMHIP_STRESS_AHEAD_MAX")) f->stress_ahead_max_chunks = atoi(e);
   if (const char *e = getenv("MPMHIP_SPLIT_SPLAT")) f->split_splat = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_SPLIT_SPLAT_MAX")) f->split_splat_max_chunks = atoi(e);
   if (const char *e = getenv("MPMHIP_G2P2G_MAX")) f->g2p2g_max_chunks = atoi(e);
@@ -623,9 +624,13 @@ int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
   } else {
     // Stress ahead (g2p_device.hpp): this launch also finalizes the elements and runs the NEXT substep's stress update -- when that
     // substep follows at once (a.more), on the same order of the particles (no re-sort in front of it: decided HERE, with the flags
-    // step_phase_a would look at), in a scene the fused form covers (cloth, every particle simulated, one rank, no pre-p2g operation).
-    bool ahead = f->stress_ahead && fused && a.more && d.n_e > 0 && d.n_v > 0 && f->g2p_two_pass && !f->g2p_mflag && !f->dist && !f->g.halo.slot &&
-                 f->all_simulated && c->pre.empty() && f->g.host_sig && f->g.xprev && f->n_chunks_g == f->n_chunks && !(MPMHIP_DEBUG && f->g.dbg);
+    // step_phase_a would look at), in a scene the fused form covers (cloth only, every particle simulated, one rank, no pre-p2g
+    // operation) -- and whose chunk list fits ONE round of this kernel's workgroups (113 VGPRs: 1,024 slots).  There a launch lasts as
+    // long as a workgroup lives and the launch saved is worth more than the three corner gathers per element cost (garment-120k-aniso
+    // 25.5 -> 26.3 k substeps/s); with several rounds the gathers' VALU and LDS time is paid in full (sheet-500k: 34.5 us against
+    // 17.8 + 15.1 for the two launches, -6 %; profiles/r05_experiments.md).
+    bool ahead = f->stress_ahead && fused && a.more && d.n_e > 0 && d.n_v > 0 && d.n_t == 0 && f->g2p_two_pass && !f->g2p_mflag && !f->dist && !f->g.halo.slot &&
+                 f->all_simulated && c->pre.empty() && f->g.host_sig && f->g.xprev && f->n_chunks_g == f->n_chunks && f->n_chunks_g <= f->stress_ahead_max_chunks && !(MPMHIP_DEBUG && f->g.dbg);
     if (ahead) {
       int rc2 = poll_drift_flags(c);
       if (rc2) return rc2;

@@ -189,6 +189,7 @@ struct FastState {
   // stress ahead (round 5, g2p_device.hpp): the g2p launch of the substep before also finalized the elements and ran THIS substep's
   // stress update; step_phase_a then has no stress launch.  Only ever set between two substeps of one mpmhip_steps call.
   bool stress_ahead = true;        // feature switch (MPMHIP_STRESS_AHEAD=0 turns it off)
+  int stress_ahead_max_chunks = 1024;  // ... for chunk lists of at most one round of k_g2p_stress workgroups (MPMHIP_STRESS_AHEAD_MAX)
   bool stress_done_ahead = false;  // the state flag
   bool all_simulated = false;      // no particle with selection != 0 (counted at every import with the mass span)
   bool rebin_polled = false;       // step_phase_b already looked at the drift flags for the coming substep

@@ -40,12 +40,6 @@ __device__ __forceinline__ G2PResult g2p_finish(const Stencil &s, const Dims &d,
 // wavefronts it spills 21 registers: 21.4 us).  So B128 is a template parameter and the launcher picks it where occupancy is not what
 // bounds the launch: chunk lists of at most one round, and the single-sweep kernels of traditional scenes (117 -> 121 VGPRs, four
 // wavefronts either way).
-#ifndef SA_EARLY_SLOTS
-#define SA_EARLY_SLOTS 0
-#endif
-#ifndef SA_GLOBAL
-#define SA_GLOBAL 1
-#endif
 #ifndef G2P_D3_SWEEP
 #define G2P_D3_SWEEP 1  // experiment switch: second sweep of cloth-only wavefronts through g2p_gather_grad_d3
 #endif
@@ -225,13 +219,17 @@ __device__ __forceinline__ V3 g2p_advect(V3 x, V3 v, const Dims &d, float dt) { 
   V3 nx = x + dt * v;
   return v3(fminf(fmaxf(nx.x, a_min), a_max), fminf(fmaxf(nx.y, a_min), a_max), fminf(fmaxf(nx.z, a_min), a_max));
 }
+// g2p_e :838-853: element position / velocity = mean of the moved corners / their velocities, d1, d2 = edge vectors
+__device__ __forceinline__ void elem_from_corners(V3 c1, V3 c2, V3 c3, V3 u1, V3 u2, V3 u3, V3 &xe, V3 &ve, V3 &d1, V3 &d2) {
+  ve = v3((u1.x + u2.x + u3.x) / 3.0f, (u1.y + u2.y + u3.y) / 3.0f, (u1.z + u2.z + u3.z) / 3.0f);
+  xe = v3((c1.x + c2.x + c3.x) / 3.0f, (c1.y + c2.y + c3.y) / 3.0f, (c1.z + c2.z + c3.z) / 3.0f);
+  d1 = c2 - c1; d2 = c3 - c1;
+}
 // element finalize (g2p_e :838-857) + compute_stress_from_F_trial of the next substep for element s, from the moved corners
-__device__ __forceinline__ void elem_stress_ahead(const Bufs &b, const StressAhead &sx, int s, V3 c1, V3 c2, V3 c3, V3 u1, V3 u2, V3 u3,
-                                                  V3 d3n, float gamma, float kappa, V3 rinv, float vol, float mu, float lam, int ox,
-                                                  int oy, int oz, const Dims &d, const GridPtrs &g) {
-  V3 ve = v3((u1.x + u2.x + u3.x) / 3.0f, (u1.y + u2.y + u3.y) / 3.0f, (u1.z + u2.z + u3.z) / 3.0f);
-  V3 xe = v3((c1.x + c2.x + c3.x) / 3.0f, (c1.y + c2.y + c3.y) / 3.0f, (c1.z + c2.z + c3.z) / 3.0f);
-  M3 dm = m3_cols(c2 - c1, c3 - c1, d3n);
+__device__ __forceinline__ void elem_stress_ahead(const Bufs &b, const StressAhead &sx, int s, V3 xe, V3 ve, V3 d1, V3 d2, V3 d3n, int ox,
+                                                  int oy, int oz, const Dims &d, const GridPtrs &g, float gamma, float kappa, V3 rinv, float vol,
+                                                  float mu, float lam) {
+  M3 dm = m3_cols(d1, d2, d3n);
   QR3 q = qr_cloth(dm);
   float r02, r12, r22;
   V3 d3 = anisotropy_return_mapping(q, gamma, kappa, sx.friction_coeff, r02, r12, r22);
@@ -376,13 +374,6 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
     x = ld3(b.all, A_X, sx_);
     d3 = v3(b.el.at(E_D + 2, se), b.el.at(E_D + 5, se), b.el.at(E_D + 8, se));
   }
-  // (stress ahead) the element's corner slots go out with the first burst; the corners themselves (a dependent level) are
-  // requested after the tile staging below, so that their latency lies under the first sweep and their registers do not
-  int cs1 = 0, cs2 = 0, cs3 = 0;
-  if (STRESS && SA_EARLY_SLOTS) {
-    int se = (valid && cls == 0) ? s : 0;
-    cs1 = sx.face_slot[se]; cs2 = sx.face_slot[d.n_e + se]; cs3 = sx.face_slot[2 * d.n_e + se];
-  }
   constexpr int NPT = TILE3 / PT;  // tile nodes per thread
   int nbk[NPT], nlk[NPT], hsl[NPT];
   float am[NPT], apx[NPT], apy[NPT], apz[NPT];
@@ -490,13 +481,17 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
       WGT(g, 1, 4);  // first sweep (v, C) of wavefront 0 stored
       if (__any(fit && cls != 2)) {  // elements and traditional particles also need grad v
         asm volatile("" : "+v"(xg.x), "+v"(xg.y), "+v"(xg.z));  // a fresh stencil: nothing of the first sweep stays live
-        if (G2P_D3_SWEEP && !__any(fit && cls == 1)) {  // cloth only: (grad v) d3 with three accumulators (g2p_gather_grad_d3)
+        if (STRESS || (G2P_D3_SWEEP && !__any(fit && cls == 1))) {  // cloth only: (grad v) d3 with three accumulators (g2p_gather_grad_d3); STRESS: scenes without traditional particles only
+          // (stress ahead: both arms end in the same register value d3n; with a stencil of its own per arm LLVM does not hoist the 27
+          // tile reads they have in common in front of the branch -- 81 registers)
+          if (STRESS) asm volatile("" : "+v"(xg.x), "+v"(xg.y), "+v"(xg.z));
           V3 gd = g2p_gather_grad_d3<B128>(tile, ox, oy, oz, xg, d3, d);
           if (fit && cls == 0) {
             d3n = d3 + dt * gd;
             if (!STRESS) { b.el.at(E_D + 2, s) = d3n.x; b.el.at(E_D + 5, s) = d3n.y; b.el.at(E_D + 8, s) = d3n.z; }
           }
         } else {
+          if (STRESS) asm volatile("" : "+v"(xg.x), "+v"(xg.y), "+v"(xg.z));
           M3 rF = g2p_gather_grad<B128>(tile, ox, oy, oz, xg, d);
           if (STRESS && fit && cls == 0) d3n = (m3_identity() + dt * rF) * d3;
           else if (fit && cls != 2) g2p_write_grad(b, cls, s, d3, rF, d, dt);
@@ -521,16 +516,13 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
     // ---- stress ahead: v at the three corners (from the tile where the corner's stencil lies in it, which is the rule; from the
     // global grid otherwise), the corners moved, element finalize, stress update of the next substep ----
     asm volatile("" : "+v"(d3n.x), "+v"(d3n.y), "+v"(d3n.z), "+v"(s));   // (nothing of the sweeps stays live across this point)
-    // the corners of this lane's element as p2g read them (requested here, not in front of the sweeps: nine registers through both
-    // sweeps cost the launch a wavefront per SIMD; the other wavefronts of the CU cover the wait)
-    if (!SA_EARLY_SLOTS) {
-      int se0 = el ? s : 0;
-      cs1 = sx.face_slot[se0]; cs2 = sx.face_slot[d.n_e + se0]; cs3 = sx.face_slot[2 * d.n_e + se0];
-    }
-    const int a1 = el ? cs1 : 0, a2 = el ? cs2 : 0, a3 = el ? cs3 : 0;
-    V3 xc1 = v3(g.xprev[a1], g.xprev[d.n_v + a1], g.xprev[2 * d.n_v + a1]);
-    V3 xc2 = v3(g.xprev[a2], g.xprev[d.n_v + a2], g.xprev[2 * d.n_v + a2]);
-    V3 xc3 = v3(g.xprev[a3], g.xprev[d.n_v + a3], g.xprev[2 * d.n_v + a3]);
+    // the corner slots and the corners as p2g read them are requested HERE, not in front of the sweeps: twelve registers through both
+    // sweeps cost the launch a wavefront per SIMD (135 instead of 115 VGPRs); the other wavefronts of the CU cover the two waits
+    const int se = el ? s : 0;
+    int cs1 = sx.face_slot[se], cs2 = sx.face_slot[d.n_e + se], cs3 = sx.face_slot[2 * d.n_e + se];
+    V3 xc1 = v3(g.xprev[cs1], g.xprev[d.n_v + cs1], g.xprev[2 * d.n_v + cs1]);
+    V3 xc2 = v3(g.xprev[cs2], g.xprev[d.n_v + cs2], g.xprev[2 * d.n_v + cs2]);
+    V3 xc3 = v3(g.xprev[cs3], g.xprev[d.n_v + cs3], g.xprev[2 * d.n_v + cs3]);
     unsigned need = 0;  // bit c: corner c + 1 has to be gathered from the global grid
     auto corner = [&](V3 xc, unsigned bit) -> V3 {
       int lx = (int)(xc.x * d.inv_dx - 0.5f) - ox, ly = (int)(xc.y * d.inv_dx - 0.5f) - oy, lz = (int)(xc.z * d.inv_dx - 0.5f) - oz;
@@ -550,17 +542,18 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
     V3 u3 = corner(xc3, 4u);
     asm volatile("" : "+v"(u3.x), "+v"(u3.y), "+v"(u3.z));
     __builtin_amdgcn_sched_barrier(0);
-    const int se = el ? s : 0;
     float gamma = b.el.at(E_GAMMA, se), kappa = b.el.at(E_KAPPA, se);
     V3 rinv = ld3(b.el, E_RINV, se);
     float vol = b.nv.at(N_VOL, se), mu = b.nv.at(N_MU, se), lam = b.nv.at(N_LAM, se);
-    if (el && need == 0)
-      elem_stress_ahead(b, sx, s, g2p_advect(xc1, u1, d, dt), g2p_advect(xc2, u2, d, dt), g2p_advect(xc3, u3, d, dt), u1, u2, u3, d3n, gamma,
-                        kappa, rinv, vol, mu, lam, ox, oy, oz, d, g);
+    V3 xe, ve, d1, d2;
+    if (el && need == 0) {
+      elem_from_corners(g2p_advect(xc1, u1, d, dt), g2p_advect(xc2, u2, d, dt), g2p_advect(xc3, u3, d, dt), u1, u2, u3, xe, ve, d1, d2);
+      elem_stress_ahead(b, sx, s, xe, ve, d1, d2, d3n, ox, oy, oz, d, g, gamma, kappa, rinv, vol, mu, lam);
+    }
     // An element with a corner whose stencil has left the tile (rare: the corner lies within a cell of an element that is itself at
     // the edge of the drift margin) takes all three corners from the global grid, in a region of its own: a rolled loop, its inputs
     // made opaque like those of the out-of-margin path above, so that nothing of it is kept live across the tile path.
-    if (SA_GLOBAL && __any(el && need != 0)) {
+    if (__any(el && need != 0)) {
       asm volatile("" : "+v"(s), "+v"(d3n.x), "+v"(d3n.y), "+v"(d3n.z), "+v"(cs1), "+v"(cs2), "+v"(cs3));
       if (el && need != 0) {
         V3 c1 = v3(0, 0, 0), c2 = c1, c3 = c1, w1 = c1, w2 = c1, w3 = c1;
@@ -572,8 +565,9 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
           V3 xn = g2p_advect(xq, uq, d, dt);
           if (cidx == 0) { c1 = xn; w1 = uq; } else if (cidx == 1) { c2 = xn; w2 = uq; } else { c3 = xn; w3 = uq; }
         }
-        elem_stress_ahead(b, sx, s, c1, c2, c3, w1, w2, w3, d3n, b.el.at(E_GAMMA, s), b.el.at(E_KAPPA, s), ld3(b.el, E_RINV, s), b.nv.at(N_VOL, s),
-                          b.nv.at(N_MU, s), b.nv.at(N_LAM, s), ox, oy, oz, d, g);
+        elem_from_corners(c1, c2, c3, w1, w2, w3, xe, ve, d1, d2);
+        elem_stress_ahead(b, sx, s, xe, ve, d1, d2, d3n, ox, oy, oz, d, g, b.el.at(E_GAMMA, s), b.el.at(E_KAPPA, s), ld3(b.el, E_RINV, s), b.nv.at(N_VOL, s),
+                          b.nv.at(N_MU, s), b.nv.at(N_LAM, s));
         atomicAdd(g.counters + 0, 1);
       }
     }

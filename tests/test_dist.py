@@ -189,13 +189,15 @@ def test_in_library_loop_with_several_ranks(world, scene, steps, rebin, ghost_g2
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("halo", ["peer", "rccl"])
-@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("world,halo", [(4, "peer"), (4, "rccl"), (8, "rccl")])
 def test_in_library_loop_with_four_and_eight_ranks(world, halo):
     """What `bench.py --gpus 4` / `--gpus 8` runs on a node -- `mpmhip_rccl_steps`, one process per rank -- with 4 and 8 ranks over the
     RCCL stand-in on ONE GPU (the first contact with a real node must not be the first time the loop sees eight
     ranks): interior ranks with two neighbours each, eight communicator members, 7 + 7 peer links, collective re-sorts every 8
-    substeps.  Result: the single context's trajectory; every rank takes the same re-sort decisions."""
+    substeps.  Result: the single context's trajectory; every rank takes the same re-sort decisions.
+    (Eight ranks run the send/recv halos only: with peer-mapped halos a rank's kernels spin on a flag its neighbour's kernel raises,
+    and eight processes time-slicing ONE GPU do not get the neighbour scheduled inside the flag timeout -- "a peer-mapped halo never
+    arrived", measured; on a node every rank has its own GPU.  Four ranks sharing the GPU do.)"""
     import re
     out = _launch(world, "gpu", "widesheet8" if world == 8 else "widesheet", 40,
                   extra_env=_mock_rccl_env(MPMHIP_TEST_REBIN=8, MPMHIP_DIST_HALO=halo, MPMHIP_VERBOSE=1))

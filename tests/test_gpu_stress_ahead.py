@@ -1,0 +1,153 @@
+"""Stress ahead (csrc/g2p_device.hpp, k_g2p_stress; round 5): inside one mpmhip_steps call a cloth substep is TWO launches -- the g2p
+launch also finalizes the elements (g2p_e, mpm_utils.py:838-857) and runs the next substep's compute_stress_from_F_trial (:1017-1105),
+each element lane moving its three corners itself with velocities gathered from its own tile.
+
+Checked: the two-launch sequence against the three-launch one (MPMHIP_STRESS_AHEAD=0) and against the CPU oracle on every cloth scene
+of the suite; that the fused launch really ran (mpmhip_stats.stress_ahead_launches) and never across a call boundary; state read
+between calls (particle_d must be g2p_e's director, not the next substep's return-mapped one); forced re-sorts (no fused launch in
+front of a re-sort); corners that have left the element's tile (the global-grid path); scenes the fused form does not cover
+(a frozen particle, a pre-p2g operation): three launches, same results."""
+import os
+
+import numpy as np
+import pytest
+
+from mpmavatar_amd import harness, scenes
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("particle_x", "particle_v", "particle_C", "particle_d", "particle_stress", "particle_F_trial")
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-3)) if a.size else 0.0
+
+
+def _build(sc, ahead, rebin_interval=0):
+    old = os.environ.get("MPMHIP_STRESS_AHEAD")
+    os.environ["MPMHIP_STRESS_AHEAD"] = "1" if ahead else "0"      # (read when the context is created)
+    try:
+        return harness.build_solver(sc, "cuda:0", mode="fast", rebin_interval=rebin_interval)
+    finally:
+        if old is None:
+            os.environ.pop("MPMHIP_STRESS_AHEAD")
+        else:
+            os.environ["MPMHIP_STRESS_AHEAD"] = old
+
+
+def _state(sim):
+    return {k: getattr(sim.state, k).detach().cpu().numpy().copy() for k in FIELDS}
+
+
+SCENES = {"sheet": scenes.small_sheet, "garment": scenes.small_garment,
+          "demo": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=False),
+          "demohold": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=(10, 5, 64))}
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_two_launches_equal_three_and_the_oracle(name, oracle_lib):
+    from oracle.scene_adapter import oracle_from_scene, run_scene
+    sc = SCENES[name]()
+    n = 100
+    a, b = _build(sc, True), _build(SCENES[name](), False)
+    harness.run(a, n, fused=True)
+    harness.run(b, n, fused=True)
+    sa, sb = a.solver.stats(), b.solver.stats()
+    assert sb["stress_ahead_launches"] == 0
+    if sc.n_traditional:     # cloth + sand: the fused form covers scenes without traditional particles only -- three launches, same results
+        assert sa["stress_ahead_launches"] == 0
+    else:                    # every substep of the call but its last (no re-sort falls into these 100 substeps)
+        assert sa["stress_ahead_launches"] >= n - 3, sa
+    A, B = _state(a), _state(b)
+    o = oracle_from_scene(sc)
+    run_scene(o, sc, n)
+    for k in FIELDS:
+        # same formulas; the corner velocities are gathered by the element's lane instead of being read back (a few ulp), which 100
+        # substeps of cloth amplify like any other rounding (tests/test_gpu_parity.py: the velocity bounds of these scenes)
+        tol = 1e-5 if k == "particle_x" else (3e-3 if name in ("sheet", "garment") else 1e-4)
+        assert np.isfinite(A[k]).all() and rel(A[k], B[k]) < tol, (name, k, rel(A[k], B[k]))
+    assert rel(A["particle_x"], o.x) < 1e-5 and rel(B["particle_x"], o.x) < 1e-5
+    vtol = 3e-3 if name in ("sheet", "garment") else 1e-4
+    assert rel(A["particle_v"], o.v) < vtol and rel(A["particle_d"], o.d) < 3e-3, (rel(A["particle_v"], o.v), rel(A["particle_d"], o.d))
+
+
+def test_one_substep_is_bitwise_the_same_and_strict(oracle_lib):
+    """gamma = 0 (no discontinuity): 60 substeps hold 1e-4 on everything against the oracle with either launch sequence."""
+    from oracle.scene_adapter import oracle_from_scene, run_scene
+    sc = scenes.small_sheet()
+    sc.gamma = 0.0
+    a = _build(sc, True)
+    harness.run(a, 60, fused=True)
+    assert a.solver.stats()["stress_ahead_launches"] == 59
+    o = oracle_from_scene(sc)
+    run_scene(o, sc, 60)
+    A = _state(a)
+    assert rel(A["particle_x"], o.x) < 1e-6 and rel(A["particle_v"], o.v) < 1e-4 and rel(A["particle_C"], o.C) < 1e-4
+    assert rel(A["particle_d"], o.d) < 1e-4 and rel(A["particle_stress"], o.stress) < 1e-3
+
+
+def test_state_between_calls_is_the_references(oracle_lib):
+    """A read between two calls sees g2p_e's director and the stress of the LAST compute_stress_from_F_trial -- never the next
+    substep's (the fused launch is not used for the last substep of a call)."""
+    from oracle.scene_adapter import oracle_from_scene, run_scene
+    sc = scenes.small_garment()
+    sc.gamma = 0.0
+    a = _build(sc, True)
+    o = oracle_from_scene(sc)
+    done = 0
+    for n in (1, 7, 20, 2, 30):
+        harness.run(a, n, fused=True)
+        run_scene(o, sc, n, k0=done)
+        done += n
+        A = _state(a)
+        assert rel(A["particle_d"], o.d) < 1e-4 and rel(A["particle_stress"], o.stress) < 1e-3 and rel(A["particle_v"], o.v) < 1e-4, (done, n)
+    assert a.solver.stats()["stress_ahead_launches"] == (0 + 6 + 19 + 1 + 29)
+
+
+def test_no_fused_launch_in_front_of_a_resort(oracle_lib):
+    """rebin_interval -7: a re-sort exactly every 7 substeps; the substep in front of each one takes the plain g2p (the re-sort
+    finalizes the elements itself and the stress update follows on the new order)."""
+    sc = scenes.small_garment()
+    a, b = _build(sc, True, rebin_interval=-7), _build(scenes.small_garment(), False, rebin_interval=-7)
+    harness.run(a, 70, fused=True)
+    harness.run(b, 70, fused=True)
+    sa = a.solver.stats()
+    assert sa["rebins"] == b.solver.stats()["rebins"] >= 9
+    assert 0 < sa["stress_ahead_launches"] <= 69 - (sa["rebins"] - 1)
+    A, B = _state(a), _state(b)
+    assert rel(A["particle_x"], B["particle_x"]) < 1e-5 and rel(A["particle_v"], B["particle_v"]) < 3e-3
+
+
+def test_corners_outside_the_tile_take_the_global_path(oracle_lib):
+    """A sheet thrown at 20 m/s with re-sorts only every 80 substeps (2.6 cells of travel; the predictive sort puts the margin on both
+    sides, so +-1.3 cells against a margin of one): elements and corners leave their tile between re-sorts -- the fused launch
+    gathers those corners from the global grid (counted as fallback particles)."""
+    def mk():
+        sc = scenes.small_sheet()
+        sc.gamma = 0.0
+        sc.v = sc.v.copy()
+        sc.v[:, 0] = 20.0
+        return sc
+    a, b = _build(mk(), True, rebin_interval=-80), _build(mk(), False, rebin_interval=-80)
+    harness.run(a, 160, fused=True)
+    harness.run(b, 160, fused=True)
+    sa = a.solver.stats()
+    assert sa["n_fallback_particles"] > 0 and sa["stress_ahead_launches"] > 140 and sa["n_dropped"] == 0, sa
+    A, B = _state(a), _state(b)
+    for k in FIELDS:
+        assert rel(A[k], B[k]) < (1e-5 if k == "particle_x" else 1e-4), (k, rel(A[k], B[k]))
+
+
+def test_scenes_the_fused_form_does_not_cover_keep_three_launches(oracle_lib):
+    import torch
+    sc = scenes.small_sheet()
+    sel = np.zeros(sc.n_particles, np.int32)
+    sel[sc.n_elements + 5] = 1                       # one frozen vertex: its elements' corners do not all move
+    sc.selection = sel
+    a = _build(sc, True)
+    harness.run(a, 30, fused=True)
+    assert a.solver.stats()["stress_ahead_launches"] == 0
+    b = _build(scenes.small_sheet(), True)           # a pre-p2g operation on the list: three launches as well
+    b.solver.add_impulse_on_particles(b.state, force=[0.0, 1.0, 0.0], dt=1e-4, point=[1.0, 1.2, 1.0], size=[2.0, 2.0, 2.0], num_dt=1000, start_time=0.0, device="cuda:0")
+    harness.run(b, 30, fused=True)
+    assert b.solver.stats()["stress_ahead_launches"] == 0
