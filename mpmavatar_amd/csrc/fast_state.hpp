@@ -188,7 +188,8 @@ struct FastState {
   bool elem_pending = false;  // element finalise of the last substep still to be done (fused into the next stress)
   // stress ahead (round 5, g2p_device.hpp): the g2p launch of the substep before also finalized the elements and ran THIS substep's
   // stress update; step_phase_a then has no stress launch.  Only ever set between two substeps of one mpmhip_steps call.
-  bool stress_ahead = true;        // feature switch (MPMHIP_STRESS_AHEAD=0 turns it off)
+  bool stress_ahead = false;       // feature switch: OFF by default (MPMHIP_STRESS_AHEAD=1 turns it on) -- +3 % on a one-round scene at t = 0,
+                                   // -10 % in its steady state, -6 % on the headline scene (profiles/r05_experiments.md 4)
   int stress_ahead_max_chunks = 1024;  // ... for chunk lists of at most one round of k_g2p_stress workgroups (MPMHIP_STRESS_AHEAD_MAX)
   bool stress_done_ahead = false;  // the state flag
   bool all_simulated = false;      // no particle with selection != 0 (counted at every import with the mass span)
