@@ -90,7 +90,7 @@ def test_hip_reproduces_the_traced_substep(name, mode):
         # largest), but the QUOTIENT at a node that only received weights of 1e-3 and less has correspondingly fewer digits.
         # Such a node hands its velocity back with the same tiny weights (the particles above hold 5e-5).  So: momentum at
         # every node, velocity at the nodes that carry at least 1e-4 of the heaviest node's mass (measured <= 6e-5; all nodes in
-        # the fp64-tile mode below: <= 2e-5).  profiles/r03_p2g_fixed_point.md
+        # the fp64-tile mode below: <= 2e-5).  profiles/archive/r03_p2g_fixed_point.md
         assert rg.rel(m[..., None] * v_out, ref_m[..., None] * ref_v, floor=1e-12) < tol
         act &= ref_m >= 1e-4 * ref_m.max()
     assert rg.rel(v_out[act], ref_v[act]) < 2e-4

@@ -18,7 +18,7 @@ def test_resorts_arrive_in_time(name, substeps):
     assert bool(torch.isfinite(x).all() and torch.isfinite(v).all())
     assert float(x.min()) >= 0.0 and float(x.max()) <= sim.scene.grid_lim
     assert st["n_dropped"] == 0
-    # cumulative particle-substeps on the slow path: 0 in every recorded run (profiles/r02_soak.txt); the bound leaves room
+    # cumulative particle-substeps on the slow path: 0 in every recorded run (profiles/archive/r02_soak.txt); the bound leaves room
     # for a handful of strongly accelerated particles (the path is correct, only slow) out of ~1e9 particle-substeps
     assert st["n_fallback_particles"] <= 1000, st
     assert st["rebins"] >= 2                            # the scene did move through its tiles
