@@ -75,8 +75,9 @@ QUANTILES = (0.5, 0.9, 0.99, 0.999)
 # yet) are noisy in the ENSEMBLE ITSELF -- its ten pair values of p99 span 2.1e-5 .. 9.1e-5 in one run and 6.7e-5 .. 1.0e-4 in another --
 # and the HIP path enters that phase from a larger per-substep rounding difference (one-substep map 7e-7 of the top speed: FMA
 # contraction, fixed-point tile) than a re-ordering of the oracle's own sums (1e-7), so it gets there a few substeps earlier.  Observed
-# ratio HIP / ensemble maximum over 80 (checkpoint, statistic) values of two full runs: <= 1.50 (round 5 first used 1.5 and failed at
-# 1.5006).
+# ratio HIP / ensemble maximum over the (checkpoint, statistic) values above the tolerance floor in five full runs: <= 1.60 (round 5
+# first used 1.5 and failed at 1.5006; profiles/r05_fullsize_margin_runs.txt).  Where the ensemble's own ten values span more than a
+# factor of two the margin is that span (capped at four): the tolerance follows the ensemble's own noise.
 Q_MARGIN = 2.0
 MAX_MARGIN = 2.0
 K_ORACLES = 5
@@ -159,7 +160,9 @@ def _check(rows, what):
         for i, n in enumerate(names):
             h = float(np.median(hip[:, i]))
             lo, hi = float(pairs[:, i].min()), float(pairs[:, i].max())
-            margin = MAX_MARGIN if n == "max" else Q_MARGIN
+            # the fixed factor of two -- or, where the ensemble's OWN ten values of this statistic span more than that (transition
+            # phases: some pairs have reached the saturated level, others not yet), the factor they span, at most four
+            margin = min(max(MAX_MARGIN if n == "max" else Q_MARGIN, hi / max(lo, 1e-30)), 4.0)
             assert h <= max(margin * hi, floor), f"{what} substep {cp}: {n} of |dv| {h:.2e} m/s above {margin} x the ensemble's {hi:.2e}"
             # ... and not BELOW the ensemble either (a HIP run that stayed implausibly close to one oracle order would not be running the
             # same dynamics): only meaningful where the ensemble has spread at all
