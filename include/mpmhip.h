@@ -118,6 +118,7 @@ typedef struct {
   int64_t stress_ahead_launches; /* fast mode, cloth scenes: substeps that ran as TWO launches -- the g2p launch also finalized the
                                    elements and ran the next substep's compute_stress_from_F_trial (csrc/g2p.hip k_g2p_stress);
                                    inside one mpmhip_steps call only, never across a call boundary */
+  int64_t batched_substeps;     /* substeps this context advanced inside mpmhip_steps_multi (csrc/batch.hip) */
 } mpmhip_stats;
 
 /* ---- lifetime ----------------------------------------------------------------- */
@@ -194,6 +195,14 @@ int mpmhip_step(mpmhip_ctx *ctx, float dt, const float *mesh_x, const float *mes
 int mpmhip_steps(mpmhip_ctx *ctx, float dt, int32_t n, const float *mesh_x, const float *mesh_v,
                  const float *joint_traditional_v, int32_t n_joint_t, const float *joint_verts_v,
                  const float *joint_faces_v);
+/* The same for SEVERAL contexts in lock step, one launch per phase for all of them (csrc/batch.hip): the four independent simulations
+   of the caller's finite-difference training step (train_material_params.py:583-631) as one joint substep loop.  All contexts must be
+   fast-mode contexts on ONE HIP stream (mpmhip_config.stream); every array argument has n_ctx entries (or is NULL as a whole), an
+   entry has the meaning of the corresponding mpmhip_steps argument.  Results are those of n_ctx separate mpmhip_steps calls, bit for
+   bit: the same device code runs on every context's own data. */
+int mpmhip_steps_multi(mpmhip_ctx *const *ctxs, int32_t n_ctx, float dt, int32_t n, const float *const *mesh_x, const float *const *mesh_v,
+                       const float *const *joint_traditional_v, const int32_t *n_joint_t, const float *const *joint_verts_v,
+                       const float *const *joint_faces_v);
 int mpmhip_synchronize(mpmhip_ctx *ctx);
 /* MPMWARP.time (never reset by reset_state, quirk Q3) */
 double mpmhip_get_time(const mpmhip_ctx *ctx);

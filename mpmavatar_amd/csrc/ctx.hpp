@@ -181,6 +181,8 @@ int baseline_add_mover_storage(mpmhip_ctx *ctx, Mover &mv);
 int fast_init(mpmhip_ctx *ctx);
 void fast_destroy(mpmhip_ctx *ctx);
 int fast_step(mpmhip_ctx *ctx, const StepArgs &a);
+int fast_steps_multi(mpmhip_ctx **cs, int nc, const StepArgs *base, int n);
+bool fast_batch_single(const mpmhip_ctx *ctx);
 int fast_pull(mpmhip_ctx *ctx);
 int fast_export_grid(mpmhip_ctx *ctx, float *m, float *v_in, float *v_out);
 int fast_stats(mpmhip_ctx *ctx, mpmhip_stats *out);

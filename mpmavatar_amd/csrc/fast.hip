@@ -195,6 +195,7 @@ int fast_init(mpmhip_ctx *c) {
   f->p2g_fixed_now = f->p2g_fixed;
   if (const char *e = getenv("MPMHIP_G2P2G")) f->g2p2g = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_STRESS_AHEAD")) f->stress_ahead = atoi(e) != 0;
+  if (const char *e = getenv("MPMHIP_BATCH_SINGLE")) f->batch_single = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_STRESS_AHEAD_MAX")) f->stress_ahead_max_chunks = atoi(e);
   if (const char *e = getenv("MPMHIP_SPLIT_SPLAT")) f->split_splat = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_SPLIT_SPLAT_MAX")) f->split_splat_max_chunks = atoi(e);
@@ -754,6 +755,7 @@ int fast_stats(mpmhip_ctx *c, mpmhip_stats *out) {
   out->rebins = f->rebins;
   out->g2p2g_launches = f->n_g2p2g;
   out->stress_ahead_launches = f->n_stress_ahead;
+  out->batched_substeps = f->n_batched;
   out->n_active_blocks = f->n_A;
   int *dcnt = f->g.counters + 4;
   if (f->grid_dirty) {  // fused substeps do not count collider / mover nodes: count the last substep now

@@ -1,7 +1,7 @@
 // fast_state.hpp -- host-side state of the fast back end (FastState and what hangs on it) and the functions its translation
 // units share.
 #pragma once
-#include "g2p_device.hpp"
+#include "batch_args.hpp"
 
 namespace mpm {
 
@@ -195,6 +195,17 @@ struct FastState {
   bool all_simulated = false;      // no particle with selection != 0 (counted at every import with the mass span)
   bool rebin_polled = false;       // step_phase_b already looked at the drift flags for the coming substep
   int64_t n_stress_ahead = 0;      // launches of k_g2p_stress (statistics)
+  // batched launches (batch.hip, mpmhip_steps_multi): while `batching` is set the launchers of the three hot kernels record their
+  // arguments here instead of launching; the multi-context driver issues one launch per phase for all its contexts
+  bool batching = false, pend_stress = false, pend_p2g = false, pend_g2p = false;
+  StressB ps;
+  P2GB pp;
+  G2PB pg;
+  BCList *bcl_dev = nullptr;       // device copy of the BC list the batched g2p reads
+  BCList bcl_host{};               // ... and what it holds
+  bool bcl_valid = false;
+  int64_t n_batched = 0;           // substeps that ran through batched launches (statistics)
+  bool batch_single = false;       // MPMHIP_BATCH_SINGLE=1: mpmhip_steps of this context goes through the batched launches too
   int steps_since_rebin = 0;
   hipEvent_t ev_flag = nullptr;
   bool flag_pending = false;
@@ -286,6 +297,11 @@ void launch_stress_elem(mpmhip_ctx *c, int mode, const SplatArgs &sa);
 void launch_stress_trad(mpmhip_ctx *c, float dt);
 void launch_g2p(mpmhip_ctx *c, bool fused, bool two, float dt, const GridParams &gp, const BCList &bcl);
 void launch_g2p_stress(mpmhip_ctx *c, float dt, const GridParams &gp, const BCList &bcl);
+// batch.hip
+int batch_flush_ctx(mpmhip_ctx *c);   // launch what this context has recorded, by itself (a launcher met a form the batch does not cover)
+int fast_steps_multi(mpmhip_ctx **cs, int nc, const StepArgs *base, int n);
+// api.hip
+void mesh_store_launch(mpmhip_ctx *c, const StepArgs &a);
 void launch_g2p2g(mpmhip_ctx *c, unsigned grid, float dt, const GridRead &rd, const SplatArgs &sa, const TradParams &tp, const GridParams &gp,
                   const BCList &bcl);
 

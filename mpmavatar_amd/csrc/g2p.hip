@@ -1,6 +1,7 @@
 // g2p.hip -- g2p with the fused grid stage (k_g2p, k_g2p_halo) and the fused g2p -> p2g launch (k_g2p2g), and their launchers.
 // (split out of fast.hip in round 4; shared device code: fast_device.hpp, shared host state: fast_state.hpp)
 #include "fast_state.hpp"
+#include <cstring>
 
 namespace mpm {
 
@@ -46,6 +47,20 @@ void launch_g2p(mpmhip_ctx *c, bool fused, bool two, float dt, const GridParams 
   FastState *f = c->fast;
   const Dims &d = f->d;
   const Bufs &b = f->buf[f->cur];
+  if (f->batching) {  // (mpmhip_steps_multi) the fused two-sweep form of cloth scenes is recorded for the batched launch
+    if (fused && two && !f->g.halo.slot && !f->g2p_mflag && !c->prof_fused && !f->g.trace) {
+      if (!f->bcl_valid || memcmp(&f->bcl_host, &bcl, sizeof(BCList)) != 0) {   // (rare: the BC list changed -- a moving cuboid, a new BC)
+        if (!f->bcl_dev && hipMalloc((void **)&f->bcl_dev, sizeof(BCList)) == hipSuccess) f->allocs.push_back((void *)f->bcl_dev);
+        f->bcl_host = bcl;
+        (void)hipMemcpyAsync(f->bcl_dev, &f->bcl_host, sizeof(BCList), hipMemcpyHostToDevice, c->stream);
+        f->bcl_valid = true;
+      }
+      f->pg = G2PB{f->chunks_g, f->n_chunks_g, (int)xcd_grid(f->n_chunks_g), b, d, dt, lean(f->g), gp, f->bcl_dev};
+      f->pend_g2p = true;
+      return;
+    }
+    (void)batch_flush_ctx(c);
+  }
 #define G2P_ARGS xcd_grid(f->n_chunks_g), PT, f->chunks_g, f->n_chunks_g, b, d, dt, f->g, gp, bcl
   // (two-sweep kernel: ds_read_b128 costs it its fifth wavefront per SIMD -- taken where a launch is at most one round of workgroups)
   const bool wide = f->n_chunks_g <= 1280;

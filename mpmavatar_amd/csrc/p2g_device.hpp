@@ -856,9 +856,9 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
 template <int STEPS, bool TRAD, bool JT, bool FX>
 __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, const Bufs &b, const VAdj &va, const Dims &d, float rpic,
                                          float dt, const GridPtrs &g, const SplatArgs &sa, const TradParams &tp, double *tile, int *esc,
-                                         int &esc_n, float *red) {
+                                         int &esc_n, float *red, int bid) {
   WGT(g, 0, 0);
-  if (blockIdx.x == 0 && threadIdx.x == 0 && g.host_sig) {
+  if (bid == 0 && threadIdx.x == 0 && g.host_sig) {
     // progress + drift flag for the host (plain stores into pinned host memory instead of a copy + event every few
     // substeps: on the stream those cost a blit kernel and ~10-20 us of idle queue each).  Everything before this launch
     // has completed, so substep step_id - 1 is done and its parity slot of the flags holds every warning it raised (final: the
@@ -875,8 +875,8 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
   // The splat workgroups go in front of the chunks (e0 = 0: the longest workgroups of the launch start first) or behind them
   // (e0 = xcd_grid(n_chunks), MPMHIP_SPLAT_FIRST_MAX): measured the same to 1 % early and in the draped state, where ~740 of them
   // take more than half of the first-round slots -- the dispatcher evens it out.
-  if ((int)blockIdx.x >= sa.e0 && (int)blockIdx.x < sa.e0 + sa.n_extra) {
-    int e = (int)blockIdx.x - sa.e0;
+  if (bid >= sa.e0 && bid < sa.e0 + sa.n_extra) {
+    int e = bid - sa.e0;
     if (DBG(g, 256)) return;
     if (e < sa.n_fbins) {   // (8192 / 16384: ablation switches)
       if (DBG(g, 8192)) {}
@@ -888,19 +888,19 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
     wg_done(sa.pack);
     return;
   }
-  if ((int)blockIdx.x >= sa.z_first) {  // ... and the clearing workgroups last: they fill the tail of the launch
-    if (sa.pack.n_wg && (int)blockIdx.x >= sa.pack.first) {  // (multi-GPU) halo pack, once everything in front has scattered
+  if (bid >= sa.z_first) {  // ... and the clearing workgroups last: they fill the tail of the launch
+    if (sa.pack.n_wg && bid >= sa.pack.first) {  // (multi-GPU) halo pack, once everything in front has scattered
       pack_wait(sa.pack, g.counters + 10);
-      halo_pack_wg<true>(sa.pack.tb, g, (int)blockIdx.x - sa.pack.first);
+      halo_pack_wg<true>(sa.pack.tb, g, bid - sa.pack.first);
       return;
     }
-    if (!DBG(g, 2048)) zero_blocks_wg(sa.z, (int)blockIdx.x - sa.z_first);
+    if (!DBG(g, 2048)) zero_blocks_wg(sa.z, bid - sa.z_first);
     WGT(g, 0, 6);
     return;
   }
-  int w = xcd_slice((int)blockIdx.x - (sa.e0 == 0 ? sa.n_extra : 0), n_chunks);
+  int w = xcd_slice(bid - (sa.e0 == 0 ? sa.n_extra : 0), n_chunks);
   if (w < 0) { wg_done(sa.pack); return; }
-  if (g.stagger > 0 && (int)blockIdx.x < g.stagger_first) {
+  if (g.stagger > 0 && bid < g.stagger_first) {
     // The workgroups of the first round all start within a microsecond, load together and then scatter together: memory
     // system and VALU / LDS pipelines take turns idling, and a first-round workgroup lives 12.4 us against 9.0 us for one
     // of the desynchronised second round (profiles/r03_wg_timeline.md).  Stagger them per CU by the wave slot they landed in.

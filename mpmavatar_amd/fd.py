@@ -75,7 +75,7 @@ class MaterialFD:
 
     def __init__(self, scene: Scene, frames: Sequence[Frame], *, init=(1.0, 1.0, 1.0), ranges=((0.1, 10.0), (0.1, 10.0), (0.5, 1.5)),
                  lrs=(0.05, 0.05, 0.005), iterations=100, frame_dt=1.0 / 25, substeps=400, scale=1.0, shift=(0.0, 0.0, 0.0),
-                 device="cuda:0", concurrent=True, mode=None, variants: Optional[Sequence[int]] = None, build=True):
+                 device="cuda:0", concurrent=True, mode=None, variants: Optional[Sequence[int]] = None, build=True, batched=False):
         self.sc, self.frames = scene, list(frames)
         self.device = torch.device(device)
         self.iterations = int(iterations)
@@ -96,11 +96,14 @@ class MaterialFD:
         if not build:   # optimiser / bookkeeping only (host-side tests)
             self.concurrent, self.sims, self.pool = False, [], None
             return
-        self.concurrent = bool(concurrent) and len(self.variants) > 1
+        # batched (round 5): the variants' contexts on ONE stream, stepped in lock step with one launch per phase for all of them
+        # (MPMWARP.p2g2p_n_multi -> mpmhip_steps_multi, csrc/batch.hip) instead of one stream + host thread per variant
+        self.batched = bool(batched) and len(self.variants) > 1
+        self.concurrent = bool(concurrent) and len(self.variants) > 1 and not self.batched
         if self.concurrent:
             request_hw_queues()          # (opt-in by use: only the concurrent contexts want it; no import side effect)
-        n_ctx = len(self.variants) if self.concurrent else 1
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(n_ctx)] if self.concurrent else [None]
+        n_ctx = len(self.variants) if (self.concurrent or self.batched) else 1
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(n_ctx)] if self.concurrent else [None] * n_ctx
         self.sims = []
         for s in self.streams:
             with torch.cuda.stream(s) if s is not None else _null():
@@ -141,10 +144,42 @@ class MaterialFD:
                 record.append(cloth.detach().cpu().numpy().copy())
         return float((loss / len(self._frames)).item())
 
+    def _prepare(self, sim, D: float, E: float, H: float):
+        """The per-simulation set-up of ``simulate`` (:584-609)."""
+        sc, dev = self.sc, self.device
+        st, md, sv = sim.state, sim.model, sim.solver
+        scaled = self._verts0 * np.array([[1.0, H, 1.0]], np.float32)
+        R_inv = torch.as_tensor(garment.compute_rest_dir_inv_from_vf(scaled, sc.faces), device=dev)
+        st.reset_state(sc.n_vertices, self._x0.clone(), self._d0.clone(), None, self._v0.clone(), tensor_R_inv=R_inv, device=dev,
+                       requires_grad=True)
+        st.set_require_grad(True)
+        ones = torch.ones(sc.n_particles, dtype=torch.float32, device=dev)
+        st.reset_density(ones * D, None, dev, update_mass=True)
+        sv.set_E_nu_from_torch(md, ones * (E * 100.0), ones * sc.nu, ones * sc.gamma, ones * sc.kappa, dev)
+        sv.prepare_mu_lam(md, st, dev)
+
+    def simulate_batched(self, jobs) -> List[float]:
+        """All variants frame by frame, every frame's substeps as ONE joint call for all of them."""
+        from .warp_mpm import MPMWARP
+        sc, dev, k = self.sc, self.device, len(jobs)
+        sims = self.sims[:k]
+        for sim, p in zip(sims, jobs):
+            self._prepare(sim, *p)
+        loss = [torch.zeros((), dtype=torch.float32, device=dev) for _ in range(k)]
+        for f in self._frames:
+            MPMWARP.p2g2p_n_multi([s.solver for s in sims], [s.model for s in sims], [s.state for s in sims], self.substep_size, self.substeps,
+                                  mesh_x=[f["mesh_x"]] * k, mesh_v=[f["mesh_v"]] * k, joint_verts_v=[f["jv"]] * k, joint_faces_v=[f["jf"]] * k)
+            for i, sim in enumerate(sims):
+                cloth = self.sim2wld(sim.state.particle_x[sc.n_elements:])
+                loss[i] = loss[i] + torch.nn.functional.mse_loss(cloth, f["target"])
+        return [float((l / len(self._frames)).item()) for l in loss]
+
     def losses(self, D: float, E: float, H: float) -> List[float]:
         """Losses of this process's variants at (D, E, H) + DELTAS[i]."""
         jobs = [(D + DELTAS[i][0], E + DELTAS[i][1], H + DELTAS[i][2]) for i in self.variants]
-        if not self.concurrent:
+        if self.batched:
+            out = self.simulate_batched(jobs)
+        elif not self.concurrent:
             out = [self.simulate(self.sims[0], *p) for p in jobs]
         else:
             def work(k):
