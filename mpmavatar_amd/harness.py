@@ -24,6 +24,7 @@ class Sim:
     joint_verts_v: torch.Tensor = None
     joint_faces_v: torch.Tensor = None
     steps_done: int = 0
+    mesh_static: bool = False
 
 
 def build_solver(sc: Scene, device="cuda:0", mode=None, rebin_interval=0, p2g_tile="auto") -> Sim:
@@ -65,6 +66,7 @@ def build_solver(sc: Scene, device="cuda:0", mode=None, rebin_interval=0, p2g_ti
     sim = Sim(sc, solver, state, model)
     if sc.mesh_vertices is not None:
         sim.mesh_x0, sim.mesh_v = t(sc.mesh_vertices), t(sc.mesh_v)
+        sim.mesh_static = not np.any(np.asarray(sc.mesh_v))
     if sc.joint_verts_v is not None:
         sim.joint_verts_v, sim.joint_faces_v = t(sc.joint_verts_v), t(sc.joint_faces_v).reshape(-1, 3)
     return sim
@@ -93,6 +95,8 @@ def run(sim: Sim, n_steps: int, fused: bool = False):
         if sc.mesh_sway is not None:
             mx, mv = sc.body_at(step)
             return t(mx), t(mv)
+        if sim.mesh_static:   # a body at rest: no advection kernel, no temporary per call (the caller's mesh_x + k dt mesh_v with mesh_v = 0)
+            return sim.mesh_x0, sim.mesh_v
         return sim.mesh_x0 + np.float32(sc.dt * step) * sim.mesh_v, sim.mesh_v
 
     end = sim.steps_done + n_steps
