@@ -217,6 +217,8 @@ def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int 
     # undefined results on RCCL instead of the clean collective error repartition() promises).
     ss, err = None, None
     try:
+        if os.environ.get("MPMHIP_TEST_FAIL_BUILD_RANK") == str(rank):   # (tests: a rank whose local build fails)
+            raise MemoryError("injected failure of the local build (MPMHIP_TEST_FAIL_BUILD_RANK)")
         shard = partition(sc, world, _cuts)[rank]
         # MPMHIP_P2G_TILE_AUTO means "the SCENE's masses span more than 1e5" (include/mpmhip.h): a rank decides it from the particles it
         # holds, so with slabs every rank would decide from its own shard and ranks could run different accumulator numerics on the

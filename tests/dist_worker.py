@@ -111,6 +111,16 @@ def main():
         # one GPU per rank when the box has them (needed by the in-library RCCL transport); otherwise the ranks share cuda:0
         dev = f"cuda:{rank}" if torch.cuda.device_count() >= world else "cuda:0"
         torch.cuda.set_device(dev)
+        if os.environ.get("MPMHIP_TEST_FAIL_BUILD_RANK"):   # every rank must get the collective error, none may hang
+            try:
+                mdist.build_sharded(sc, dev, rank, world)
+                print(f"dist rank {rank}: build_sharded did not raise", flush=True)
+                sys.exit(1)
+            except RuntimeError as e:
+                print(f"dist rank {rank}: collective build error: {e}", flush=True)
+                dist.barrier()              # ... and the process group is still usable
+                dist.destroy_process_group()
+                sys.exit(0)
         ss = mdist.build_sharded(sc, dev, rank, world, rebin_interval=int(os.environ.get("MPMHIP_TEST_REBIN", "8")))
         ss.migrate_fraction = float(os.environ.get("MPMHIP_TEST_MIGRATE", "0"))
         chunk = int(os.environ.get("MPMHIP_TEST_RUN_CHUNK", str(steps)))

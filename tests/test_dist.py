@@ -228,6 +228,17 @@ def test_in_library_loop_migration_over_the_stand_in():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bad", [0, 2])
+def test_a_rank_whose_local_build_fails_takes_every_rank_out_cleanly(bad):
+    """ADVICE r4: build_sharded votes on the local part of the build BEFORE its first collective.  Rank `bad` fails there (injected);
+    all three ranks raise the same collective RuntimeError -- the failing one with its cause, the others with "another rank" -- nobody
+    waits in a collective the failed rank never enters, and the process group works afterwards."""
+    out = _launch(3, "gpu", "sheet", 10, timeout=300, extra_env={"MPMHIP_TEST_FAIL_BUILD_RANK": str(bad)})
+    assert out.count("collective build error") == 3, out[-2000:]
+    assert out.count("on this rank") == 1 and out.count("another rank") == 2, out[-2000:]
+
+
+@pytest.mark.gpu
 def test_sharded_staged_sand_release():
     """run_demo.py:524 in the sharded driver: each rank holds its share (a suffix of its owned traditional particles) of the
     sand the mover still pins, and lets go of it on the global schedule.  Must match the single context, which is checked
