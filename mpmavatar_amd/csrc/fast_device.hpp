@@ -116,7 +116,10 @@ __device__ __forceinline__ bool in_grid(int x, int y, int z, int G) {
 // grid block, so runs of XCD_RUN consecutive items (neighbouring tiles) are given to the same XCD to share its L2,
 // while successive runs rotate over the 8 XCDs so that a spatially concentrated load (e.g. the blocks around the
 // body collider) is spread over the whole chip instead of landing on one or two XCDs.
-constexpr int XCD_RUN = 16;
+#ifndef MPM_XCD_RUN
+#define MPM_XCD_RUN 16  // (experiment switch; 8 and 32 measured in round 5)
+#endif
+constexpr int XCD_RUN = MPM_XCD_RUN;
 __device__ __forceinline__ int xcd_slice(int w, int n) {
   int xcd = w & 7, idx = w >> 3;
   int i = ((idx / XCD_RUN) * 8 + xcd) * XCD_RUN + (idx % XCD_RUN);
