@@ -115,10 +115,9 @@ typedef struct {
                                    with an interval too long for their speed) and the results are not valid */
   int64_t g2p2g_launches;       /* fast mode, scenes of traditional particles only: substep boundaries that ran as ONE launch
                                    (g2p of substep n + stress and p2g of substep n + 1, csrc/g2p.hip k_g2p2g) */
-  int64_t stress_ahead_launches; /* fast mode, cloth scenes: substeps that ran as TWO launches -- the g2p launch also finalized the
-                                   elements and ran the next substep's compute_stress_from_F_trial (csrc/g2p.hip k_g2p_stress);
-                                   inside one mpmhip_steps call only, never across a call boundary */
-  int64_t batched_substeps;     /* substeps this context advanced inside mpmhip_steps_multi (csrc/batch.hip) */
+  int32_t p2g_tile_in_use;      /* fast mode: the accumulator p2g's chunk tile runs on NOW -- MPMHIP_P2G_TILE_FIXED or MPMHIP_P2G_TILE_F64
+                                   (what MPMHIP_P2G_TILE_AUTO resolved to at the last import; 0 in baseline mode) */
+  int32_t reserved_;
 } mpmhip_stats;
 
 /* ---- lifetime ----------------------------------------------------------------- */
@@ -195,14 +194,6 @@ int mpmhip_step(mpmhip_ctx *ctx, float dt, const float *mesh_x, const float *mes
 int mpmhip_steps(mpmhip_ctx *ctx, float dt, int32_t n, const float *mesh_x, const float *mesh_v,
                  const float *joint_traditional_v, int32_t n_joint_t, const float *joint_verts_v,
                  const float *joint_faces_v);
-/* The same for SEVERAL contexts in lock step, one launch per phase for all of them (csrc/batch.hip): the four independent simulations
-   of the caller's finite-difference training step (train_material_params.py:583-631) as one joint substep loop.  All contexts must be
-   fast-mode contexts on ONE HIP stream (mpmhip_config.stream); every array argument has n_ctx entries (or is NULL as a whole), an
-   entry has the meaning of the corresponding mpmhip_steps argument.  Results are those of n_ctx separate mpmhip_steps calls, bit for
-   bit: the same device code runs on every context's own data. */
-int mpmhip_steps_multi(mpmhip_ctx *const *ctxs, int32_t n_ctx, float dt, int32_t n, const float *const *mesh_x, const float *const *mesh_v,
-                       const float *const *joint_traditional_v, const int32_t *n_joint_t, const float *const *joint_verts_v,
-                       const float *const *joint_faces_v);
 int mpmhip_synchronize(mpmhip_ctx *ctx);
 /* MPMWARP.time (never reset by reset_state, quirk Q3) */
 double mpmhip_get_time(const mpmhip_ctx *ctx);
@@ -242,6 +233,12 @@ int mpmhip_dist_set_ghost_mode(mpmhip_ctx *ctx, int32_t ghosts_gather);
 int mpmhip_dist_ghost_pack(mpmhip_ctx *ctx);   /* fill every peer's ghost_send */
 int mpmhip_dist_ghost_unpack(mpmhip_ctx *ctx); /* apply every peer's ghost_recv */
 int mpmhip_dist_num_blocks(const mpmhip_ctx *ctx); /* size of the active-block byte map */
+/* MPMHIP_P2G_TILE_AUTO in a sharded run: the smallest positive and the largest mass over the simulated particles of ALL ranks (the
+ * caller all-reduces them).  The tile decision of every later import is taken from max(this rank's span, max_mass / min_mass), so
+ * every rank switches to the fp64 tile together -- ranks that share halo blocks must not run different accumulator numerics -- and
+ * from the masses actually bound (reset_density(update_mass) after the build included), never from a description of the scene.
+ * AUTO is only ever widened to fp64 this way, never forced to the fixed-point tile.  min_mass <= 0: forget the global span. */
+int mpmhip_dist_set_mass_span(mpmhip_ctx *ctx, float min_mass, float max_mass);
 /* this rank's early-warning drift flag (1: some particle is about to leave the tile margin of the block it was sorted
  * into; cleared by the next re-sort).  Synchronous.  A sharded driver max-reduces it over the ranks to decide on a
  * collective re-sort -- the single-GPU adaptive policy (mpmhip_config.rebin_interval = 0) made collective. */

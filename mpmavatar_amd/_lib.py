@@ -54,7 +54,7 @@ class ModelScalars(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("substeps", C.c_int64), ("rebins", C.c_int64), ("n_active_blocks", C.c_int32),
                 ("n_active_nodes", C.c_int32), ("n_collider_nodes", C.c_int32), ("n_mover_nodes", C.c_int32),
-                ("n_fallback_particles", C.c_int32), ("n_dropped", C.c_int32), ("g2p2g_launches", C.c_int64), ("stress_ahead_launches", C.c_int64), ("batched_substeps", C.c_int64)]
+                ("n_fallback_particles", C.c_int32), ("n_dropped", C.c_int32), ("g2p2g_launches", C.c_int64), ("p2g_tile_in_use", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class DistPeer(C.Structure):
@@ -89,13 +89,13 @@ SIGNATURES = {
     "mpmhip_add_velocity_rotation": (C.c_int, [vp, f3, f3, f3, f3, C.c_float, C.c_float, vp, C.c_float, C.c_float]),
     "mpmhip_step": (C.c_int, [vp, C.c_float, vp, vp, vp, C.c_int32, vp, vp]),
     "mpmhip_steps": (C.c_int, [vp, C.c_float, C.c_int32, vp, vp, vp, C.c_int32, vp, vp]),
-    "mpmhip_steps_multi": (C.c_int, [vp, C.c_int32, C.c_float, C.c_int32, vp, vp, vp, vp, vp, vp]),
     "mpmhip_cov_from_F": (C.c_int, [C.c_int32, vp, vp, vp, C.c_int32, vp]),
     "mpmhip_face_frames": (C.c_int, [C.c_int32, vp, vp, vp, C.c_int32, vp, vp, vp, vp]),
     "mpmhip_bind_gaussians": (C.c_int, [C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mpmhip_render_inputs": (C.c_int, [C.c_int32, vp, C.c_int32, C.c_int32] + [vp] * 18),
     "mpmhip_dist_enable": (C.c_int, [vp]),
     "mpmhip_dist_set_ghost_mode": (C.c_int, [vp, C.c_int32]),
+    "mpmhip_dist_set_mass_span": (C.c_int, [vp, C.c_float, C.c_float]),
     "mpmhip_dist_ghost_pack": (C.c_int, [vp]),
     "mpmhip_dist_ghost_unpack": (C.c_int, [vp]),
     "mpmhip_dist_num_blocks": (C.c_int, [vp]),

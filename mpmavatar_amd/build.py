@@ -16,9 +16,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libmpmhip.so")
-FAST_SOURCES = ["fast.hip", "resort.hip", "p2g.hip", "g2p.hip", "dist.hip", "batch.hip"]   # the fast back end (one translation unit until round 4)
+FAST_SOURCES = ["fast.hip", "resort.hip", "p2g.hip", "g2p.hip", "dist.hip"]   # the fast back end (one translation unit until round 4)
 SOURCES = ["api.hip", "common.hip", "baseline.hip"] + FAST_SOURCES + ["frames.hip"]
-HEADERS = ["ctx.hpp", "mpm_math.hpp", "bc.hpp", "fast_device.hpp", "p2g_device.hpp", "g2p_device.hpp", "batch_args.hpp", "fast_state.hpp", os.path.join("..", "..", "include", "mpmhip.h")]
+HEADERS = ["ctx.hpp", "mpm_math.hpp", "bc.hpp", "fast_device.hpp", "p2g_device.hpp", "g2p_device.hpp", "fast_state.hpp", os.path.join("..", "..", "include", "mpmhip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast-honor-pragmas",
          "-Wall", "-Wno-unused-function"]

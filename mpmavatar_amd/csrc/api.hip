@@ -381,16 +381,6 @@ int mpmhip_steps(mpmhip_ctx *c, float dt, int32_t n, const float *mesh_x, const 
                  const float *joint_faces_v) {
   CHECK_CTX(c);
   if (n < 0) return fail(c, MPMHIP_ERR_INVALID, "steps: n < 0");
-  if (fast_mode(c) && c->fast && fast_batch_single(c) && !c->profiling && !c->prof_fused && n > 0) {
-    // (MPMHIP_BATCH_SINGLE=1, experiment) the one context through the batched launches: their arguments come from a table in the kernel-
-    // argument segment, read on demand, instead of ~1 KB of by-value arguments that the kernel entry loads into SGPRs
-    if (!c->st_bound || !c->md_bound) return fail(c, MPMHIP_ERR_STATE, "step: state/model not bound");
-    if (n_joint_t < 0 || n_joint_t > c->n_trad) return fail(c, MPMHIP_ERR_INVALID, "step: n_joint_t out of range");
-    if ((mesh_x || mesh_v) && !c->mesh_points) return fail(c, MPMHIP_ERR_STATE, "step: mesh_x/mesh_v given but no body mesh");
-    StepArgs base{dt, mesh_x, mesh_v, 0.0f, false, joint_traditional_v, joint_traditional_v ? n_joint_t : 0, joint_verts_v, joint_faces_v, false};
-    mpmhip_ctx *one[1] = {c};
-    return fast_steps_multi(one, 1, &base, n);
-  }
   for (int k = 0; k < n; ++k) {
     // mesh_x + substep_size*substep_local*mesh_v, train_material_params.py:623, evaluated inside the kernels
     StepArgs a{dt, mesh_x, mesh_v, (float)((double)dt * (double)k), k == n - 1, joint_traditional_v,
@@ -410,31 +400,6 @@ void mesh_store_launch(mpmhip_ctx *c, const StepArgs &a) {
 }  // namespace mpm
 }  // extern "C++"
 
-int mpmhip_steps_multi(mpmhip_ctx *const *ctxs, int32_t n_ctx, float dt, int32_t n, const float *const *mesh_x, const float *const *mesh_v,
-                       const float *const *joint_traditional_v, const int32_t *n_joint_t, const float *const *joint_verts_v,
-                       const float *const *joint_faces_v) {
-  if (!ctxs || n_ctx < 1 || n_ctx > 64) return MPMHIP_ERR_INVALID;
-  std::vector<mpmhip_ctx *> cs(ctxs, ctxs + n_ctx);
-  std::vector<StepArgs> base((size_t)n_ctx);
-  for (int i = 0; i < n_ctx; ++i) {
-    mpmhip_ctx *c = cs[i];
-    CHECK_CTX(c);
-    if (n < 0) return fail(c, MPMHIP_ERR_INVALID, "steps_multi: n < 0");
-    if (!fast_mode(c) || !c->fast) return fail(c, MPMHIP_ERR_INVALID, "steps_multi: fast mode only");
-    if (c->stream != cs[0]->stream) return fail(c, MPMHIP_ERR_INVALID, "steps_multi: the contexts must share one HIP stream (mpmhip_config.stream)");
-    if (c->profiling || c->prof_fused) return fail(c, MPMHIP_ERR_STATE, "steps_multi: not while profiling");
-    if (!c->st_bound || !c->md_bound) return fail(c, MPMHIP_ERR_STATE, "steps_multi: state/model not bound");
-    for (int j = 0; j < i; ++j) if (cs[j] == c) return fail(c, MPMHIP_ERR_INVALID, "steps_multi: a context is listed twice");
-    const float *mx = mesh_x ? mesh_x[i] : nullptr, *mv = mesh_v ? mesh_v[i] : nullptr;
-    const float *jt = joint_traditional_v ? joint_traditional_v[i] : nullptr;
-    const int njt = (jt && n_joint_t) ? n_joint_t[i] : 0;
-    if (njt < 0 || njt > c->n_trad) return fail(c, MPMHIP_ERR_INVALID, "steps_multi: n_joint_t out of range");
-    if ((mx || mv) && !c->mesh_points) return fail(c, MPMHIP_ERR_STATE, "steps_multi: mesh_x/mesh_v given but no body mesh");
-    base[(size_t)i] = StepArgs{dt, mx, mv, 0.0f, false, jt, njt, joint_verts_v ? joint_verts_v[i] : nullptr, joint_faces_v ? joint_faces_v[i] : nullptr, false};
-  }
-  return fast_steps_multi(cs.data(), n_ctx, base.data(), n);
-}
-
 int mpmhip_dist_enable(mpmhip_ctx *c) {
   CHECK_CTX(c);
   if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
@@ -444,6 +409,12 @@ int mpmhip_dist_set_ghost_mode(mpmhip_ctx *c, int32_t ghosts_gather) {
   CHECK_CTX(c);
   if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
   return fast_dist_set_ghost_mode(c, ghosts_gather);
+}
+int mpmhip_dist_set_mass_span(mpmhip_ctx *c, float min_mass, float max_mass) {
+  CHECK_CTX(c);
+  if (!fast_mode(c)) return fail(c, MPMHIP_ERR_INVALID, "dist: only the fast mode shards across GPUs");
+  if (min_mass > 0.0f && !(max_mass >= min_mass)) return fail(c, MPMHIP_ERR_INVALID, "dist_set_mass_span: max_mass < min_mass");
+  return fast_dist_set_mass_span(c, min_mass, max_mass);
 }
 int mpmhip_dist_ghost_pack(mpmhip_ctx *c) {
   CHECK_CTX(c);

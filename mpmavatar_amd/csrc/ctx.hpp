@@ -181,8 +181,6 @@ int baseline_add_mover_storage(mpmhip_ctx *ctx, Mover &mv);
 int fast_init(mpmhip_ctx *ctx);
 void fast_destroy(mpmhip_ctx *ctx);
 int fast_step(mpmhip_ctx *ctx, const StepArgs &a);
-int fast_steps_multi(mpmhip_ctx **cs, int nc, const StepArgs *base, int n);
-bool fast_batch_single(const mpmhip_ctx *ctx);
 int fast_pull(mpmhip_ctx *ctx);
 int fast_export_grid(mpmhip_ctx *ctx, float *m, float *v_in, float *v_out);
 int fast_stats(mpmhip_ctx *ctx, mpmhip_stats *out);
@@ -195,6 +193,7 @@ int fast_add_mover_storage(mpmhip_ctx *ctx, Mover &mv);
 
 int fast_dist_enable(mpmhip_ctx *ctx);
 int fast_dist_set_ghost_mode(mpmhip_ctx *ctx, int ghosts_gather);
+int fast_dist_set_mass_span(mpmhip_ctx *ctx, float min_mass, float max_mass);
 int fast_dist_ghosts(mpmhip_ctx *ctx, int send);
 int fast_dist_num_blocks(const mpmhip_ctx *ctx);
 int64_t fast_dist_halo_bytes(const mpmhip_ctx *ctx);

@@ -129,6 +129,15 @@ int fast_dist_set_ghost_mode(mpmhip_ctx *c, int ghosts_gather) {
   c->fast->steps_since_rebin = 1 << 30;
   return MPMHIP_OK;
 }
+// the mass span of the whole sharded scene (all ranks): see mpmhip_dist_set_mass_span
+int fast_dist_set_mass_span(mpmhip_ctx *c, float min_mass, float max_mass) {
+  FastState *f = c->fast;
+  f->global_mass_span = min_mass > 0.0f ? max_mass / min_mass : 0.0f;
+  // (an import whose own span has already been read decides again; a pending one decides in rebin with the value just stored)
+  if (!f->mass_span_pending)
+    f->p2g_fixed_now = f->p2g_fixed && (f->p2g_fixed_forced || std::max(f->mass_span, f->global_mass_span) <= 1.0e5f);
+  return MPMHIP_OK;
+}
 int fast_dist_num_blocks(const mpmhip_ctx *c) { return (int)c->fast->nblocks; }
 int64_t fast_dist_halo_bytes(const mpmhip_ctx *c) {  // bytes this rank sends per substep in the halo exchange (all peers)
   int CH = c->movers.empty() ? 4 : 8;

@@ -194,9 +194,6 @@ int fast_init(mpmhip_ctx *c) {
   if (const char *e = getenv("MPMHIP_P2G_TILE")) { f->p2g_fixed = std::string(e) != "f64"; f->p2g_fixed_forced = std::string(e) == "fx"; }
   f->p2g_fixed_now = f->p2g_fixed;
   if (const char *e = getenv("MPMHIP_G2P2G")) f->g2p2g = atoi(e) != 0;
-  if (const char *e = getenv("MPMHIP_STRESS_AHEAD")) f->stress_ahead = atoi(e) != 0;
-  if (const char *e = getenv("MPMHIP_BATCH_SINGLE")) f->batch_single = atoi(e) != 0;
-  if (const char *e = getenv("MPMHIP_STRESS_AHEAD_MAX")) f->stress_ahead_max_chunks = atoi(e);
   if (const char *e = getenv("MPMHIP_SPLIT_SPLAT")) f->split_splat = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_SPLIT_SPLAT_MAX")) f->split_splat_max_chunks = atoi(e);
   if (const char *e = getenv("MPMHIP_G2P2G_MAX")) f->g2p2g_max_chunks = atoi(e);
@@ -215,7 +212,6 @@ int fast_init(mpmhip_ctx *c) {
   if ((rc = dalloc(c, &f->inv, (size_t)d.n_p))) return rc;
   if ((rc = dalloc(c, &f->face_slot, (size_t)3 * d.n_e))) return rc;
   if ((rc = dalloc(c, &f->eforce, (size_t)3 * d.n_e + 1))) return rc;
-  if (d.n_e && d.n_v && (rc = dalloc(c, &f->g.xprev, (size_t)3 * d.n_v))) return rc;
   if ((rc = dalloc(c, &f->adj_cnt, (size_t)d.n_v + 1))) return rc;
   if ((rc = dalloc(c, &f->order, (size_t)d.n_p))) return rc;
   if ((rc = dalloc(c, &f->iota, (size_t)d.n_p))) return rc;
@@ -369,9 +365,8 @@ int flush_g2p(mpmhip_ctx *c) {
 }
 
 // Look at the drift flags the device has posted (ring in pinned host memory, or the copied flag of contexts without one) and turn a
-// raised flag into "re-sort before the next substep" (steps_since_rebin = 1 << 30).  Called once per substep: at the head of
-// step_phase_a -- or, when the g2p launch of the substep before wants to know whether it may run the coming substep's stress update
-// already (stress ahead), by that substep's step_phase_b (rebin_polled).
+// raised flag into "re-sort before the next substep" (steps_since_rebin = 1 << 30).  Called once per substep, at the head of
+// step_phase_a.
 static int poll_drift_flags(mpmhip_ctx *c) {
   FastState *f = c->fast;
   hipStream_t s = c->stream;
@@ -436,8 +431,7 @@ int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     // the next copy is issued the host waits for the previous one, which also bounds how far the host may run
     // ahead of the GPU (<= 16 substeps) -- otherwise a fused mpmhip_steps(n) would have enqueued all n substeps
     // long before the first flag arrives.
-    if (f->rebin_polled) f->rebin_polled = false;   // (the g2p launch of the substep before already looked: stress ahead)
-    else if ((rc = poll_drift_flags(c))) return rc;
+    if ((rc = poll_drift_flags(c))) return rc;
     if (f->steps_since_rebin >= f->rebin_interval) {
       ScopedPhase ph(c, "rebin");
       // predictive sort: aim at the middle of the next interval, estimated from the one that just ended
@@ -511,7 +505,7 @@ int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   // ... where the p2g launch is at most one round of workgroups, i.e. as long as a workgroup's life is the launch's length
   // (garment-120k-aniso: stress 9.7 -> 12.0 us, p2g 20.0 -> 16.4 us, 24.7 k -> 25.6 k substeps/s; with several rounds of chunk
   // workgroups the splat hides among them and the split only lengthens the stress launch: sheet-500k -1 %, profiles/r04_experiments.md)
-  const bool split_splat = f->split_splat && has_col && sa.n_fbins > 0 && d.n_e > 0 && f->elem_pending && !f->stress_done_ahead && !c->profiling && !f->dist &&
+  const bool split_splat = f->split_splat && has_col && sa.n_fbins > 0 && d.n_e > 0 && f->elem_pending && !c->profiling && !f->dist &&
                            f->n_chunks <= f->split_splat_max_chunks && !(MPMHIP_DEBUG && f->g.dbg);
   sa.splat_passes = split_splat ? 2 : 3;
   sa.n_extra = (sa.n_fbins + sa.n_mov_wg + 7) & ~7;
@@ -541,8 +535,7 @@ int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
   }
   f->g.step_id = (int)++f->sig_seq;
   if (f->stagger_auto >= 0) f->g.stagger = (f->n_chunks >= 2 * 1280 && !c->profiling) ? f->stagger_auto : 0;
-  const bool stress_here = d.n_e && !f->stress_done_ahead;  // (stress ahead: the g2p launch of the substep before did it)
-  f->stress_done_ahead = false;
+  const bool stress_here = d.n_e > 0;
   if (stress_here || (d.n_t && !trad_fused)) {  // (no empty event bracket when the stress update rides in p2g)
     ScopedPhase ph(c, "compute_stress_from_F_trial");
     if (stress_here) {
@@ -623,31 +616,8 @@ int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
     f->g2p_pending = true;
     f->pend_gp = gp; f->pend_bcl = bcl; f->pend_dt = dt;
   } else {
-    // Stress ahead (g2p_device.hpp): this launch also finalizes the elements and runs the NEXT substep's stress update -- when that
-    // substep follows at once (a.more), on the same order of the particles (no re-sort in front of it: decided HERE, with the flags
-    // step_phase_a would look at), in a scene the fused form covers (cloth only, every particle simulated, one rank, no pre-p2g
-    // operation) -- and whose chunk list fits ONE round of this kernel's workgroups (113 VGPRs: 1,024 slots).  There a launch lasts as
-    // long as a workgroup lives and the launch saved is worth more than the three corner gathers per element cost (garment-120k-aniso
-    // 25.5 -> 26.3 k substeps/s); with several rounds the gathers' VALU and LDS time is paid in full (sheet-500k: 34.5 us against
-    // 17.8 + 15.1 for the two launches, -6 %; profiles/r05_experiments.md).
-    bool ahead = f->stress_ahead && fused && a.more && d.n_e > 0 && d.n_v > 0 && d.n_t == 0 && f->g2p_two_pass && !f->g2p_mflag && !f->dist && !f->g.halo.slot &&
-                 f->all_simulated && c->pre.empty() && f->g.host_sig && f->g.xprev && f->n_chunks_g == f->n_chunks && f->n_chunks_g <= f->stress_ahead_max_chunks && !(MPMHIP_DEBUG && f->g.dbg);
-    if (ahead) {
-      int rc2 = poll_drift_flags(c);
-      if (rc2) return rc2;
-      f->rebin_polled = true;
-      ahead = f->steps_since_rebin + 1 < f->rebin_interval;   // (phase_c counts this substep; a raised flag has set 1 << 30)
-    }
     ScopedPhase ph(c, "g2p_v");
-    if (f->n_chunks_g) {
-      if (ahead) {
-        launch_g2p_stress(c, dt, gp, bcl);
-        f->stress_done_ahead = true;
-        f->n_stress_ahead += 1;
-      } else {
-        launch_g2p(c, fused, f->g2p_two_pass, dt, gp, bcl);
-      }
-    }
+    if (f->n_chunks_g) launch_g2p(c, fused, f->g2p_two_pass, dt, gp, bcl);
   }
   if (fused) {
     f->grid_dirty = true;
@@ -667,7 +637,7 @@ int step_phase_c(mpmhip_ctx *c, const StepArgs &a) {
   (void)rc; (void)d; (void)s;
   // unprofiled: the element finalize is deferred into the next substep's stress kernel (k_stress_elem<true>); multi-GPU
   // ranks have unpacked their ghost vertices by now, so the same holds there
-  f->elem_pending = d.n_e > 0 && !f->stress_done_ahead;   // (stress ahead: the g2p launch finalized the elements itself)
+  f->elem_pending = d.n_e > 0;
   if (c->profiling || (f->g.dbg & 64)) {
     ScopedPhase ph(c, "g2p_e");
     flush_elements(c);
@@ -754,8 +724,7 @@ int fast_stats(mpmhip_ctx *c, mpmhip_stats *out) {
   flush_g2p(c);  // (a pending g2p counts its out-of-margin particles too)
   out->rebins = f->rebins;
   out->g2p2g_launches = f->n_g2p2g;
-  out->stress_ahead_launches = f->n_stress_ahead;
-  out->batched_substeps = f->n_batched;
+  out->p2g_tile_in_use = f->p2g_fixed_now ? MPMHIP_P2G_TILE_FIXED : MPMHIP_P2G_TILE_F64;
   out->n_active_blocks = f->n_A;
   int *dcnt = f->g.counters + 4;
   if (f->grid_dirty) {  // fused substeps do not count collider / mover nodes: count the last substep now

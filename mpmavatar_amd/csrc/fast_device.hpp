@@ -295,8 +295,6 @@ struct GridPtrs {
   float lookahead;  // substeps the early warning of the adaptive re-sort looks ahead (k_p2g)
   HaloIn halo;      // multi-GPU: see HaloIn
   int stagger, stagger_groups, stagger_first;  // p2g: first-round workgroups wait (wave slot % groups) * stagger * 1024 cycles
-  float *xprev;     // [3][n_v] vertex positions as p2g read them (cloth scenes; null otherwise): the stable copy the fused g2p + stress
-                    // launch gathers the element's corners at while vertex lanes of other workgroups move x in place (StressAhead)
   unsigned long long *trace;  // per-workgroup timeline (MPMHIP_DEBUG builds, mpmhip_debug_wgtrace); null otherwise
   int dbg;          // MPMHIP_DBG bitmask (MPMHIP_DEBUG builds only; perf experiments, results are wrong): 1 skip p2g flush, 2 skip the p2g
                     // scatter, 8 / 16 skip vertex-force / stress loads, 128 skip the LDS atomics only, 256 skip the splat workgroups, 2048 skip the clearing workgroups; 64 (results stay
@@ -490,13 +488,6 @@ __device__ __forceinline__ void stress_elem_body(int e, const Bufs &b, F3 *ef, c
     if (sel == 0 && ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u)) raise_drift(counters, step_id);
   }
 }
-
-// Arguments of the fused g2p + element finalize + stress launch (g2p_body<.., STRESS = true>, round 5): see "stress ahead" in g2p_device.hpp
-struct StressAhead {
-  F3 *ef;                 // corner forces [3][n_e] (+ the zero slot)
-  const int *face_slot;   // [3][n_e] element -> vertex slots (sorted order)
-  float friction_coeff;
-};
 
 // ------------------------------------------------------------------------------------------------
 // chunk tiles and chunk records: shared by p2g (p2g_device.hpp) and g2p (g2p_device.hpp)

@@ -1,7 +1,7 @@
 // fast_state.hpp -- host-side state of the fast back end (FastState and what hangs on it) and the functions its translation
 // units share.
 #pragma once
-#include "batch_args.hpp"
+#include "g2p_device.hpp"
 
 namespace mpm {
 
@@ -101,6 +101,7 @@ struct FastState {
                                   // neutral early and late -- profiles/r03_experiments.md -- so they stay in front)
   bool p2g_fixed_now = true, p2g_fixed_forced = false, mass_span_pending = false;  // the tile in use (decided per import from the mass span)
   float mass_span = 1.0f;
+  float global_mass_span = 0.0f;  // sharded runs: the span over ALL ranks' simulated particles (mpmhip_dist_set_mass_span); 0: not set
   bool p2g_fixed = true;       // p2g's chunk tile in packed fixed point (k_p2g<.., FX = true>); MPMHIP_P2G_TILE=f64: the fp64 tile
   bool g2p_mflag = false;      // g2p asks m_flag before it loads a block's accumulators (one more dependent memory level at the head
                                // of every workgroup; the default loads them with the particle positions): MPMHIP_G2P_MFLAG=1
@@ -186,26 +187,7 @@ struct FastState {
   Pinned<int> h_ranges, h_plist;
   Pinned<ChunkRec> h_chunks, h_chunks_g;
   bool elem_pending = false;  // element finalise of the last substep still to be done (fused into the next stress)
-  // stress ahead (round 5, g2p_device.hpp): the g2p launch of the substep before also finalized the elements and ran THIS substep's
-  // stress update; step_phase_a then has no stress launch.  Only ever set between two substeps of one mpmhip_steps call.
-  bool stress_ahead = false;       // feature switch: OFF by default (MPMHIP_STRESS_AHEAD=1 turns it on) -- +3 % on a one-round scene at t = 0,
-                                   // -10 % in its steady state, -6 % on the headline scene (profiles/r05_experiments.md 4)
-  int stress_ahead_max_chunks = 1024;  // ... for chunk lists of at most one round of k_g2p_stress workgroups (MPMHIP_STRESS_AHEAD_MAX)
-  bool stress_done_ahead = false;  // the state flag
   bool all_simulated = false;      // no particle with selection != 0 (counted at every import with the mass span)
-  bool rebin_polled = false;       // step_phase_b already looked at the drift flags for the coming substep
-  int64_t n_stress_ahead = 0;      // launches of k_g2p_stress (statistics)
-  // batched launches (batch.hip, mpmhip_steps_multi): while `batching` is set the launchers of the three hot kernels record their
-  // arguments here instead of launching; the multi-context driver issues one launch per phase for all its contexts
-  bool batching = false, pend_stress = false, pend_p2g = false, pend_g2p = false;
-  StressB ps;
-  P2GB pp;
-  G2PB pg;
-  BCList *bcl_dev = nullptr;       // device copy of the BC list the batched g2p reads
-  BCList bcl_host{};               // ... and what it holds
-  bool bcl_valid = false;
-  int64_t n_batched = 0;           // substeps that ran through batched launches (statistics)
-  bool batch_single = false;       // MPMHIP_BATCH_SINGLE=1: mpmhip_steps of this context goes through the batched launches too
   int steps_since_rebin = 0;
   hipEvent_t ev_flag = nullptr;
   bool flag_pending = false;
@@ -296,10 +278,6 @@ void launch_p2g(mpmhip_ctx *c, bool trad, bool jt, unsigned grid, int n_chunks, 
 void launch_stress_elem(mpmhip_ctx *c, int mode, const SplatArgs &sa);
 void launch_stress_trad(mpmhip_ctx *c, float dt);
 void launch_g2p(mpmhip_ctx *c, bool fused, bool two, float dt, const GridParams &gp, const BCList &bcl);
-void launch_g2p_stress(mpmhip_ctx *c, float dt, const GridParams &gp, const BCList &bcl);
-// batch.hip
-int batch_flush_ctx(mpmhip_ctx *c);   // launch what this context has recorded, by itself (a launcher met a form the batch does not cover)
-int fast_steps_multi(mpmhip_ctx **cs, int nc, const StepArgs *base, int n);
 // api.hip
 void mesh_store_launch(mpmhip_ctx *c, const StepArgs &a);
 void launch_g2p2g(mpmhip_ctx *c, unsigned grid, float dt, const GridRead &rd, const SplatArgs &sa, const TradParams &tp, const GridParams &gp,

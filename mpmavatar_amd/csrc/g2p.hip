@@ -15,13 +15,6 @@ __global__ __launch_bounds__(PT) void k_g2p(const ChunkRec *recs, int n_chunks, 
   g2p_body<FUSED, TWO_PASS, MFLAG, false, B128>(recs, n_chunks, b, d, dt, g, gp, bcl, tile, (int)blockIdx.x);
 }
 
-// g2p + element finalize + the next substep's stress update ("stress ahead", g2p_device.hpp): the cloth substep's second launch
-__global__ __launch_bounds__(PT) void k_g2p_stress(const ChunkRec *recs, int n_chunks, Bufs b, Dims d, float dt, GridPtrs g, GridParams gp,
-                                                   BCList bcl, StressAhead sx) {
-  __shared__ float4 tile[TILE_PAD];
-  g2p_body<true, true, false, false, false, true>(recs, n_chunks, b, d, dt, g, gp, bcl, tile, (int)blockIdx.x, sx);
-}
-
 // multi-GPU: fused halo add (see HaloIn)
 template <bool TWO_PASS>
 __global__ __launch_bounds__(PT) void k_g2p_halo(const ChunkRec *recs, int n_chunks, Bufs b, Dims d, float dt, GridPtrs g, GridParams gp,
@@ -47,20 +40,6 @@ void launch_g2p(mpmhip_ctx *c, bool fused, bool two, float dt, const GridParams 
   FastState *f = c->fast;
   const Dims &d = f->d;
   const Bufs &b = f->buf[f->cur];
-  if (f->batching) {  // (mpmhip_steps_multi) the fused two-sweep form of cloth scenes is recorded for the batched launch
-    if (fused && two && !f->g.halo.slot && !f->g2p_mflag && !c->prof_fused && !f->g.trace) {
-      if (!f->bcl_valid || memcmp(&f->bcl_host, &bcl, sizeof(BCList)) != 0) {   // (rare: the BC list changed -- a moving cuboid, a new BC)
-        if (!f->bcl_dev && hipMalloc((void **)&f->bcl_dev, sizeof(BCList)) == hipSuccess) f->allocs.push_back((void *)f->bcl_dev);
-        f->bcl_host = bcl;
-        (void)hipMemcpyAsync(f->bcl_dev, &f->bcl_host, sizeof(BCList), hipMemcpyHostToDevice, c->stream);
-        f->bcl_valid = true;
-      }
-      f->pg = G2PB{f->chunks_g, f->n_chunks_g, (int)xcd_grid(f->n_chunks_g), b, d, dt, lean(f->g), gp, f->bcl_dev};
-      f->pend_g2p = true;
-      return;
-    }
-    (void)batch_flush_ctx(c);
-  }
 #define G2P_ARGS xcd_grid(f->n_chunks_g), PT, f->chunks_g, f->n_chunks_g, b, d, dt, f->g, gp, bcl
   // (two-sweep kernel: ds_read_b128 costs it its fifth wavefront per SIMD -- taken where a launch is at most one round of workgroups)
   const bool wide = f->n_chunks_g <= 1280;
@@ -79,12 +58,6 @@ void launch_g2p(mpmhip_ctx *c, bool fused, bool two, float dt, const GridParams 
     else kstamp_launch(c, k_g2p<true, false, false, true>, G2P_ARGS);
   }
 #undef G2P_ARGS
-}
-// the same with the element finalize and the next substep's stress update at the tail of the element lanes (k_g2p_stress)
-void launch_g2p_stress(mpmhip_ctx *c, float dt, const GridParams &gp, const BCList &bcl) {
-  FastState *f = c->fast;
-  const StressAhead sx{f->eforce, f->face_slot, c->sc.friction_coeff};
-  kstamp_launch(c, k_g2p_stress, xcd_grid(f->n_chunks_g), PT, f->chunks_g, f->n_chunks_g, f->buf[f->cur], f->d, dt, f->g, gp, bcl, sx);
 }
 // k_g2p2g: g2p of the substep before (gp, bcl, read side rd) + stress and p2g of this one, see the kernel
 void launch_g2p2g(mpmhip_ctx *c, unsigned grid, float dt, const GridRead &rd, const SplatArgs &sa, const TradParams &tp, const GridParams &gp,

@@ -176,78 +176,6 @@ __device__ __forceinline__ V3 g2p_gather_grad_d3(const float4 *tile, int ox, int
   return d.inv_dx * acc;
 }
 
-// ---- stress ahead (round 5): two launches per cloth substep ----------------------------------------------------------------
-// The reference's order between two p2g launches is g2p_v / g2p_e (vertices move, elements take the mean of their moved corners and
-// new edge vectors d1, d2; mpm_utils.py:716-857) -> compute_stress_from_F_trial of the NEXT substep (:1017-1105: QR, anisotropic
-// return mapping, Kirchhoff stress, corner forces).  Rounds 1-4 ran the second half as a launch of its own (k_stress_elem<true>),
-// because an element needs the NEW positions of its three corners and those are written by other lanes -- mostly of other workgroups
-// -- of the g2p launch.  But a corner's new position is x_c + dt v(x_c), a gather from the same grid nodes: an element lies within
-// a cell of its corners, so their stencils sit in the element's own 8^3 tile (its block's nodes plus the drift margin), and the
-// element's lane can evaluate v at its three corners itself -- 3 x 27 tile reads, the velocity part of the gather only -- instead
-// of waiting for a kernel boundary.  The corners are read where p2g left them (GridPtrs::xprev, written by the vertex lanes of
-// THIS substep's p2g: vertex lanes of the running launch overwrite b.all's x in place).  With that the element finalize and the whole
-// stress update run at the tail of the element's g2p lane, the director never goes back to memory between the two, and a cloth
-// substep is p2g + g2p: 18 vertex loads per element (72 B), the d3 round trip and one launch floor (10-15 us) less.
-// The host uses this launch only when the next substep is certain to follow with nothing in between that reads particles (not for
-// the last substep of an mpmhip_steps call, not in front of a re-sort, not with pre-p2g operations, frozen particles or ghosts).
-// velocity part of the gather (same operation order as g2p_gather_vC's nv)
-template <bool B128>
-__device__ __forceinline__ V3 g2p_gather_v(const float4 *tile, int ox, int oy, int oz, V3 x, const Dims &d) {
-  Stencil s = make_stencil(x, d.inv_dx);
-  int base = tile_idx(s.bx - ox, s.by - oy, s.bz - oz);
-  V3 nv = v3(0, 0, 0);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    float wx = bspline_w(i, s.fx.x);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float wy = bspline_w(j, s.fx.y);
-      V3 s0 = v3(0, 0, 0);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        float wzk = sel3(k, s.w0.z, s.w1.z, s.w2.z);
-        const float4 t4 = tile_read<B128>(tile, base + tile_idx(i, j, k));
-        s0 = s0 + wzk * v3(t4.x, t4.y, t4.z);
-      }
-      nv = nv + (wx * wy) * s0;
-    }
-  }
-  return nv;
-}
-__device__ __forceinline__ V3 g2p_advect(V3 x, V3 v, const Dims &d, float dt) {  // g2p_v :776-781 (position clamp)
-  float a_min = (1.0f / d.inv_dx) * 2.0f, a_max = d.grid_lim - (1.0f / d.inv_dx) * 2.0f;
-  V3 nx = x + dt * v;
-  return v3(fminf(fmaxf(nx.x, a_min), a_max), fminf(fmaxf(nx.y, a_min), a_max), fminf(fmaxf(nx.z, a_min), a_max));
-}
-// g2p_e :838-853: element position / velocity = mean of the moved corners / their velocities, d1, d2 = edge vectors
-__device__ __forceinline__ void elem_from_corners(V3 c1, V3 c2, V3 c3, V3 u1, V3 u2, V3 u3, V3 &xe, V3 &ve, V3 &d1, V3 &d2) {
-  ve = v3((u1.x + u2.x + u3.x) / 3.0f, (u1.y + u2.y + u3.y) / 3.0f, (u1.z + u2.z + u3.z) / 3.0f);
-  xe = v3((c1.x + c2.x + c3.x) / 3.0f, (c1.y + c2.y + c3.y) / 3.0f, (c1.z + c2.z + c3.z) / 3.0f);
-  d1 = c2 - c1; d2 = c3 - c1;
-}
-// element finalize (g2p_e :838-857) + compute_stress_from_F_trial of the next substep for element s, from the moved corners
-__device__ __forceinline__ void elem_stress_ahead(const Bufs &b, const StressAhead &sx, int s, V3 xe, V3 ve, V3 d1, V3 d2, V3 d3n, int ox,
-                                                  int oy, int oz, const Dims &d, const GridPtrs &g, float gamma, float kappa, V3 rinv, float vol,
-                                                  float mu, float lam) {
-  M3 dm = m3_cols(d1, d2, d3n);
-  QR3 q = qr_cloth(dm);
-  float r02, r12, r22;
-  V3 d3 = anisotropy_return_mapping(q, gamma, kappa, sx.friction_coeff, r02, r12, r22);
-  M3 stress;
-  V3 f1, f2, f3;
-  kirchhoff_anisotropy(q, r02, r12, r22, d3, rinv, vol, mu, lam, gamma, kappa, stress, f1, f2, f3);
-  st3(b.all, A_V, s, ve);
-  st3(b.all, A_X, s, xe);
-  b.el.at(E_D + 2, s) = d3.x; b.el.at(E_D + 5, s) = d3.y; b.el.at(E_D + 8, s) = d3.z;
-  st9(b.nv, N_STRESS, s, stress);
-  sx.ef[s] = F3{f1.x, f1.y, f1.z};
-  sx.ef[d.n_e + s] = F3{f2.x, f2.y, f2.z};
-  sx.ef[2 * d.n_e + s] = F3{f3.x, f3.y, f3.z};
-  // drift check against the block this element was sorted into (k_stress_elem<true> does the same after its finalize)
-  int nbx = (int)(xe.x * d.inv_dx - 0.5f) - ox, nby = (int)(xe.y * d.inv_dx - 0.5f) - oy, nbz = (int)(xe.z * d.inv_dx - 0.5f) - oz;
-  if ((unsigned)nbx > 5u || (unsigned)nby > 5u || (unsigned)nbz > 5u) raise_drift(g.counters, g.step_id);
-}
-
 // same sums for a particle that drifted out of its tile margin: rolled loop over the global grid (zero outside
 // active blocks); kept small so that it does not set the kernel's register budget
 template <bool FUSED, bool HALO = false>
@@ -341,11 +269,9 @@ __device__ __forceinline__ void g2p_write(const Bufs &b, int cls, int s, V3 x, V
 // level less at the head of every workgroup for more L2 traffic; node values are identical (an unflagged block holds zeros).
 // HALO = true (multi-GPU, needs MFLAG = false): blocks shared with a neighbour rank get its contribution added on the way
 // (HaloIn), after the workgroup has seen the neighbour's flag for this substep.
-template <bool FUSED, bool TWO_PASS, bool MFLAG, bool HALO = false, bool B128 = false, bool STRESS = false>
+template <bool FUSED, bool TWO_PASS, bool MFLAG, bool HALO = false, bool B128 = false>
 __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, const Bufs &b, const Dims &d, float dt, const GridPtrs &g,
-                                         const GridParams &gp, const BCList &bcl, float4 *tile, int wg,
-                                         const StressAhead &sx = StressAhead{nullptr, nullptr, 0.0f}) {
-  static_assert(!STRESS || (FUSED && TWO_PASS && !HALO), "stress ahead rides in the fused two-sweep launch of cloth scenes");
+                                         const GridParams &gp, const BCList &bcl, float4 *tile, int wg) {
   WGT(g, 1, 0);
   // The front of a g2p workgroup is a chain of memory latencies (record -> positions + accumulators -> grid stage): few
   // instructions, long waits.  Its wavefronts get issue priority over wavefronts that are in the VALU / LDS-bound sweeps of another
@@ -459,8 +385,6 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
   __syncthreads();
   __builtin_amdgcn_s_setprio(0);
   WGT(g, 1, 3);  // tile complete
-  const bool el = STRESS && valid && cls == 0;
-  V3 d3n = d3;  // (stress ahead) the director after g2p_e, kept in registers for the stress update below
   {
     // lanes without a particle in the tile margin gather from the tile corner (in range, result unused)
     bool fit = valid && !escaped;
@@ -481,20 +405,15 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
       WGT(g, 1, 4);  // first sweep (v, C) of wavefront 0 stored
       if (__any(fit && cls != 2)) {  // elements and traditional particles also need grad v
         asm volatile("" : "+v"(xg.x), "+v"(xg.y), "+v"(xg.z));  // a fresh stencil: nothing of the first sweep stays live
-        if (STRESS || (G2P_D3_SWEEP && !__any(fit && cls == 1))) {  // cloth only: (grad v) d3 with three accumulators (g2p_gather_grad_d3); STRESS: scenes without traditional particles only
-          // (stress ahead: both arms end in the same register value d3n; with a stencil of its own per arm LLVM does not hoist the 27
-          // tile reads they have in common in front of the branch -- 81 registers)
-          if (STRESS) asm volatile("" : "+v"(xg.x), "+v"(xg.y), "+v"(xg.z));
+        if (G2P_D3_SWEEP && !__any(fit && cls == 1)) {  // cloth only: (grad v) d3 with three accumulators (g2p_gather_grad_d3)
           V3 gd = g2p_gather_grad_d3<B128>(tile, ox, oy, oz, xg, d3, d);
           if (fit && cls == 0) {
-            d3n = d3 + dt * gd;
-            if (!STRESS) { b.el.at(E_D + 2, s) = d3n.x; b.el.at(E_D + 5, s) = d3n.y; b.el.at(E_D + 8, s) = d3n.z; }
+            V3 d3n = d3 + dt * gd;
+            b.el.at(E_D + 2, s) = d3n.x; b.el.at(E_D + 5, s) = d3n.y; b.el.at(E_D + 8, s) = d3n.z;
           }
         } else {
-          if (STRESS) asm volatile("" : "+v"(xg.x), "+v"(xg.y), "+v"(xg.z));
           M3 rF = g2p_gather_grad<B128>(tile, ox, oy, oz, xg, d);
-          if (STRESS && fit && cls == 0) d3n = (m3_identity() + dt * rF) * d3;
-          else if (fit && cls != 2) g2p_write_grad(b, cls, s, d3, rF, d, dt);
+          if (fit && cls != 2) g2p_write_grad(b, cls, s, d3, rF, d, dt);
         }
       }
     }
@@ -508,70 +427,7 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
     if (escaped) {
       G2PResult r = g2p_gather_global<FUSED, HALO>(x, d, g, gp, bcl);
       g2p_write(b, cls, s, x, d3, r, ox, oy, oz, d, dt, g);
-      if (STRESS && cls == 0) d3n = (m3_identity() + dt * r.F) * d3;
       atomicAdd(g.counters + 0, 1);
-    }
-  }
-  if (STRESS && __any(el)) {
-    // ---- stress ahead: v at the three corners (from the tile where the corner's stencil lies in it, which is the rule; from the
-    // global grid otherwise), the corners moved, element finalize, stress update of the next substep ----
-    asm volatile("" : "+v"(d3n.x), "+v"(d3n.y), "+v"(d3n.z), "+v"(s));   // (nothing of the sweeps stays live across this point)
-    // the corner slots and the corners as p2g read them are requested HERE, not in front of the sweeps: twelve registers through both
-    // sweeps cost the launch a wavefront per SIMD (135 instead of 115 VGPRs); the other wavefronts of the CU cover the two waits
-    const int se = el ? s : 0;
-    int cs1 = sx.face_slot[se], cs2 = sx.face_slot[d.n_e + se], cs3 = sx.face_slot[2 * d.n_e + se];
-    V3 xc1 = v3(g.xprev[cs1], g.xprev[d.n_v + cs1], g.xprev[2 * d.n_v + cs1]);
-    V3 xc2 = v3(g.xprev[cs2], g.xprev[d.n_v + cs2], g.xprev[2 * d.n_v + cs2]);
-    V3 xc3 = v3(g.xprev[cs3], g.xprev[d.n_v + cs3], g.xprev[2 * d.n_v + cs3]);
-    unsigned need = 0;  // bit c: corner c + 1 has to be gathered from the global grid
-    auto corner = [&](V3 xc, unsigned bit) -> V3 {
-      int lx = (int)(xc.x * d.inv_dx - 0.5f) - ox, ly = (int)(xc.y * d.inv_dx - 0.5f) - oy, lz = (int)(xc.z * d.inv_dx - 0.5f) - oz;
-      bool in = el && !((unsigned)lx > 5u || (unsigned)ly > 5u || (unsigned)lz > 5u);
-      if (el && !in) need |= bit;
-      V3 xq = in ? xc : v3((float)(ox + 2) * d.dx, (float)(oy + 2) * d.dx, (float)(oz + 2) * d.dx);
-      return g2p_gather_v<B128>(tile, ox, oy, oz, xq, d);
-    };
-    // (one corner after the other: left alone the scheduler interleaves the three gathers' 81 tile reads with everything around
-    // them and the kernel needs 258 VGPRs)
-    V3 u1 = corner(xc1, 1u);
-    asm volatile("" : "+v"(u1.x), "+v"(u1.y), "+v"(u1.z), "+v"(xc2.x), "+v"(xc2.y), "+v"(xc2.z));
-    __builtin_amdgcn_sched_barrier(0);
-    V3 u2 = corner(xc2, 2u);
-    asm volatile("" : "+v"(u2.x), "+v"(u2.y), "+v"(u2.z), "+v"(xc3.x), "+v"(xc3.y), "+v"(xc3.z));
-    __builtin_amdgcn_sched_barrier(0);
-    V3 u3 = corner(xc3, 4u);
-    asm volatile("" : "+v"(u3.x), "+v"(u3.y), "+v"(u3.z));
-    __builtin_amdgcn_sched_barrier(0);
-    float gamma = b.el.at(E_GAMMA, se), kappa = b.el.at(E_KAPPA, se);
-    V3 rinv = ld3(b.el, E_RINV, se);
-    float vol = b.nv.at(N_VOL, se), mu = b.nv.at(N_MU, se), lam = b.nv.at(N_LAM, se);
-    V3 xe, ve, d1, d2;
-    if (el && need == 0) {
-      elem_from_corners(g2p_advect(xc1, u1, d, dt), g2p_advect(xc2, u2, d, dt), g2p_advect(xc3, u3, d, dt), u1, u2, u3, xe, ve, d1, d2);
-      elem_stress_ahead(b, sx, s, xe, ve, d1, d2, d3n, ox, oy, oz, d, g, gamma, kappa, rinv, vol, mu, lam);
-    }
-    // An element with a corner whose stencil has left the tile (rare: the corner lies within a cell of an element that is itself at
-    // the edge of the drift margin) takes all three corners from the global grid, in a region of its own: a rolled loop, its inputs
-    // made opaque like those of the out-of-margin path above, so that nothing of it is kept live across the tile path.
-    if (__any(el && need != 0)) {
-      asm volatile("" : "+v"(s), "+v"(d3n.x), "+v"(d3n.y), "+v"(d3n.z), "+v"(cs1), "+v"(cs2), "+v"(cs3));
-      if (el && need != 0) {
-        V3 c1 = v3(0, 0, 0), c2 = c1, c3 = c1, w1 = c1, w2 = c1, w3 = c1;
-#pragma unroll 1
-        for (int cidx = 0; cidx < 3; ++cidx) {
-          const int a = cidx == 0 ? cs1 : (cidx == 1 ? cs2 : cs3);
-          V3 xq = v3(g.xprev[a], g.xprev[d.n_v + a], g.xprev[2 * d.n_v + a]);
-          V3 uq = g2p_gather_global<FUSED, HALO>(xq, d, g, gp, bcl).v;
-          V3 xn = g2p_advect(xq, uq, d, dt);
-          if (cidx == 0) { c1 = xn; w1 = uq; } else if (cidx == 1) { c2 = xn; w2 = uq; } else { c3 = xn; w3 = uq; }
-        }
-        elem_from_corners(c1, c2, c3, w1, w2, w3, xe, ve, d1, d2);
-        elem_stress_ahead(b, sx, s, xe, ve, d1, d2, d3n, ox, oy, oz, d, g, b.el.at(E_GAMMA, s), b.el.at(E_KAPPA, s), ld3(b.el, E_RINV, s), b.nv.at(N_VOL, s),
-                          b.nv.at(N_MU, s), b.nv.at(N_LAM, s));
-        // (not counted as a fallback particle: the element itself is inside its margin -- with the predictive sort an element may sit
-        // on the margin's last cell right after a re-sort, and a corner half a cell further is outside; ~6 elements per substep on
-        // the 120k garment)
-      }
     }
   }
   WGT(g, 1, 6);

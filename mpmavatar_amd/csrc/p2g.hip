@@ -63,15 +63,6 @@ void launch_p2g(mpmhip_ctx *c, bool trad, bool jt, unsigned grid, int n_chunks, 
   const Dims &d = f->d;
   const Bufs &b = f->buf[f->cur];
   const float rpic = c->sc.rpic_damping;
-  if (f->batching) {  // (mpmhip_steps_multi) the cloth form is recorded for the batched launch; anything else goes out by itself, behind
-                      // what this context has recorded so far
-    if (!trad && !jt && f->p2g_fixed_now && !sa.pack.n_wg && !f->g.halo.slot && !c->prof_fused && !c->profiling && !f->g.trace) {
-      f->pp = P2GB{f->chunks, n_chunks, (int)grid, b, f->va(), d, rpic, dt, lean(f->g), lean(sa)};
-      f->pend_p2g = true;
-      return;
-    }
-    (void)batch_flush_ctx(c);
-  }
 #define P2G_ARGS grid, PT, f->chunks, n_chunks, b, f->va(), d, rpic, dt, f->g, sa, tp
   if (!f->p2g_fixed_now) {  // mpmhip_config.p2g_tile = F64, or particle masses that span more than 1e5
     if (trad && jt) kstamp_launch(c, k_p2g<3, true, true, false>, P2G_ARGS);
@@ -89,12 +80,6 @@ void launch_stress_elem(mpmhip_ctx *c, int mode, const SplatArgs &sa) {
   const Dims &d = f->d;
   const Bufs &b = f->buf[f->cur];
   hipStream_t s = c->stream;
-  if (f->batching && mode != 0 && !c->prof_fused && !f->g.trace) {  // (mpmhip_steps_multi) recorded for the batched launch
-    const int n_splat = mode == 2 ? sa.n_fbins : 0;
-    f->ps = StressB{b, f->eforce, d, c->sc.friction_coeff, f->face_slot, f->keys[1], f->blk_bits, n_splat, (int)nblk(d.n_e) + n_splat, lean(f->g), lean(sa)};
-    f->pend_stress = true;
-    return;
-  }
   if (mode == 2)
     kstamp_launch(c, k_stress_elem_splat, nblk(d.n_e) + (unsigned)sa.n_fbins, TPB, b, f->eforce, d, c->sc.friction_coeff, f->face_slot,
                   f->keys[1], f->blk_bits, sa.n_fbins, f->g, sa);

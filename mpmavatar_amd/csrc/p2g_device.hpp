@@ -930,12 +930,6 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
     if ((unsigned)fx > 5u || (unsigned)fy > 5u || (unsigned)fz > 5u) raise_drift(g.counters, g.step_id);
   }
   WGT(g, 0, 2);  // particle loads + first adjacency batch here, tile cleared
-  // (stress ahead, g2p_device.hpp) the vertex positions of this substep, kept for the g2p launch: its element lanes gather at their
-  // corners while vertex lanes of other workgroups move b.all's x in place
-  if (g.xprev && valid && cls == 2) {
-    const int vl = s - d.n_nv;
-    g.xprev[vl] = raw.x.x; g.xprev[d.n_v + vl] = raw.x.y; g.xprev[2 * d.n_v + vl] = raw.x.z;
-  }
   P2GParticle q = p2g_finish<TRAD>(raw, b, va, valid, cls, s, d, rpic, dt, w_v, tp);
   FxScale fs{1.0f, 1.0f, 1.0f, 1.0f};
   if (FX) {

@@ -787,7 +787,7 @@ int rebin(mpmhip_ctx *c) {
       float lo, hi;
       memcpy(&lo, f->h_pin + 44, 4); memcpy(&hi, f->h_pin + 45, 4);
       f->mass_span = (hi > 0.0f && lo < 3.0e38f) ? hi / lo : 1.0f;
-      f->p2g_fixed_now = f->p2g_fixed && (f->p2g_fixed_forced || f->mass_span <= 1.0e5f);
+      f->p2g_fixed_now = f->p2g_fixed && (f->p2g_fixed_forced || std::max(f->mass_span, f->global_mass_span) <= 1.0e5f);
       f->all_simulated = f->h_pin[46] == 0;
       f->mass_span_pending = false;
     }

@@ -59,6 +59,9 @@ class Shard:
     cuts: np.ndarray = None           # the world-1 slab boundaries (x) of this partition
 
 
+_TEST_FAIL_BUILD_RANK = None   # test hook (tests/dist_worker.py sets it): the rank whose local build raises; never read from the environment
+
+
 CUT_BINS = 1 << 14   # histogram resolution of the device-side quantile cut: grid_lim / 16384 (1/64 cell at 256^3)
 
 
@@ -189,17 +192,37 @@ class ShardedSim:
     migrate_checked_at: int = 0
     migrate_warned: bool = False
     migrations: int = 0
+    mass_version: tuple = ()           # (data_ptr, version counter) of state.particle_mass when the ranks last agreed on the scene's mass span
 
 
-def global_p2g_tile(sc: Scene) -> str:
-    """The p2g accumulator every rank of a sharded run uses: "f64" when the masses of the simulated particles of the WHOLE scene span
-    more than 1e5 (the threshold of MPMHIP_P2G_TILE_AUTO, csrc/resort.hip), else "fixed"."""
-    m = np.asarray(sc.vol, np.float64) * float(sc.density)
-    if sc.selection is not None:
-        m = m[np.asarray(sc.selection) == 0]
-    m = m[m > 0]
-    span = float(m.max() / m.min()) if m.size else 1.0
-    return "f64" if span > 1.0e5 else "fixed"
+def sync_mass_span(ss: "ShardedSim") -> float:
+    """Collective: the smallest positive and the largest mass over the SIMULATED particles of all ranks, from the mass tensors as they
+    are bound now (after reset_density(update_mass=True), after a re-partition's carried masses), handed to every rank's context
+    (mpmhip_dist_set_mass_span).  MPMHIP_P2G_TILE_AUTO then switches to the fp64 tile on every rank together when the span of the
+    WHOLE scene exceeds 1e5 -- a rank deciding from its own shard could run other accumulator numerics than its neighbour on the halo
+    blocks they share, and a decision taken from the scene description would miss masses changed after the build.
+    Returns the span."""
+    import torch
+    import torch.distributed as dist
+    st, sv = ss.sim.state, ss.sim.solver
+    mt = st._raw("particle_mass")
+    m = mt.detach().float().reshape(-1)
+    ok = m > 0
+    sel = st._raw("particle_selection")
+    if sel is not None and sel.numel() == m.numel():
+        ok = ok & (sel.reshape(-1) == 0)
+    big = torch.finfo(torch.float32).max
+    lo = torch.where(ok, m, torch.full_like(m, big)).min() if m.numel() else torch.tensor(big, device=m.device)
+    hi = torch.where(ok, m, torch.zeros_like(m)).max() if m.numel() else torch.tensor(0.0, device=m.device)
+    t = torch.stack([-lo, hi]).to(torch.float32)      # one MAX all-reduce: max(-lo) = -min(lo)
+    t = t.cpu() if ss.backend == "gloo" else t
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    lo_g, hi_g = -float(t[0].item()), float(t[1].item())
+    if hi_g <= 0.0 or lo_g >= big:
+        lo_g, hi_g = 0.0, 0.0                           # no simulated particle anywhere
+    sv._call("mpmhip_dist_set_mass_span", float(lo_g), float(hi_g))
+    ss.mass_version = (mt.data_ptr(), mt._version)
+    return hi_g / lo_g if lo_g > 0 else 1.0
 
 
 def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int = 0, _carry: dict = None, _cuts=None) -> ShardedSim:
@@ -217,13 +240,12 @@ def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int 
     # undefined results on RCCL instead of the clean collective error repartition() promises).
     ss, err = None, None
     try:
-        if os.environ.get("MPMHIP_TEST_FAIL_BUILD_RANK") == str(rank):   # (tests: a rank whose local build fails)
-            raise MemoryError("injected failure of the local build (MPMHIP_TEST_FAIL_BUILD_RANK)")
+        if _TEST_FAIL_BUILD_RANK == rank:   # (set by tests/dist_worker.py only: a rank whose local build fails)
+            raise MemoryError("injected failure of the local build (tests)")
         shard = partition(sc, world, _cuts)[rank]
-        # MPMHIP_P2G_TILE_AUTO means "the SCENE's masses span more than 1e5" (include/mpmhip.h): a rank decides it from the particles it
-        # holds, so with slabs every rank would decide from its own shard and ranks could run different accumulator numerics on the
-        # halo blocks they share.  The global scene is on every rank here: decide once, the same everywhere.
-        sim = harness.build_solver(shard.scene, device, mode="fast", p2g_tile=global_p2g_tile(sc))
+        # MPMHIP_P2G_TILE_AUTO means "the SCENE's masses span more than 1e5" (include/mpmhip.h).  The context stays on AUTO; the span it
+        # decides from is made global right after the collective part below (sync_mass_span) and again whenever the masses change.
+        sim = harness.build_solver(shard.scene, device, mode="fast")
         sv = sim.solver
         if _carry is not None:
             _apply_carry(sim, shard, sc, _carry)
@@ -270,6 +292,7 @@ def build_sharded(sc: Scene, device, rank: int, world: int, rebin_interval: int 
         flag = torch.tensor([ok], dtype=torch.int32, device=dev if ss.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ss.transport = "rccl" if int(flag.item()) == 1 else "torch"
+    sync_mass_span(ss)
     return ss
 
 
@@ -596,6 +619,9 @@ def run(ss: ShardedSim, n_steps: int):
     import torch
     ss = maybe_repartition(ss)
     sim, sv, sc = ss.sim, ss.sim.solver, ss.sim.scene
+    mt = sim.state._raw("particle_mass")
+    if (mt.data_ptr(), mt._version) != ss.mass_version:   # masses rewritten since the ranks last agreed (reset_density(update_mass))
+        sync_mass_span(ss)                                    # (collective: every rank rewrites its masses through the same caller code)
     dp = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
     jv, jf = sim.joint_verts_v, sim.joint_faces_v
     dummy = sv._dummy_ptr()

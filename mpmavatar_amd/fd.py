@@ -49,23 +49,50 @@ def variant_slice(rank: int, world: int, n: int = len(DELTAS)) -> range:
     return range(lo, hi)
 
 
+_HWQ_SET_BY_US = None   # None: request_hw_queues() has not set the variable; else: whether its setting came in time
+
+
+def hip_runtime_started() -> bool:
+    """Has anything in this process initialised the HIP / HSA runtime yet?  The runtime opens /dev/kfd when it initialises -- at the first
+    HIP call of any kind, torch.cuda.is_available() and device_count() included, which torch.cuda.is_initialized() does not report
+     -- so an open descriptor on /dev/kfd is the test."""
+    import os
+    try:
+        for fd in os.listdir("/proc/self/fd"):
+            try:
+                if os.readlink(f"/proc/self/fd/{fd}") == "/dev/kfd":
+                    return True
+            except OSError:
+                continue
+    except OSError:
+        return True      # cannot tell (no /proc): do not claim the setting will work
+    return False
+
+
 def request_hw_queues(n: int = 8) -> bool:
     """One hardware queue per HIP stream for the concurrent FD step.  The ROCm runtime multiplexes all HIP streams of a process onto
     GPU_MAX_HW_QUEUES = 4 hardware queues; four solver contexts on four streams beside torch's own then share queues and take turns
     (36.0 k substeps/s at the S3 size with the default, 45.3 k with 8, nothing more with 16: profiles/HISTORY.md).  The runtime reads the
-    variable at its FIRST HIP call, so this only works before anything in the process touched the device: call it (or export the
-    variable) before the first torch.cuda / solver call.  A value the user set wins.  Returns True when the setting will take effect;
-    warns and returns False when the device is already initialised (the FD step still runs, on shared queues)."""
+    variable when it initialises, i.e. at the FIRST HIP call of the process -- torch.cuda.is_available() is one -- so this must run (or
+    the variable be exported) before anything touched the device.  A value the user exported wins.  Returns True when the setting
+    takes effect; when the runtime is already up (hip_runtime_started) it sets nothing, WARNS and returns False: the FD step still
+    runs, on shared queues, and the caller has been told -- no silent -20 %."""
     import os
     import warnings
+    global _HWQ_SET_BY_US
+    if _HWQ_SET_BY_US is not None:
+        return _HWQ_SET_BY_US            # an earlier call of this function decided
     if "GPU_MAX_HW_QUEUES" in os.environ:
-        return True                      # the user's (or an earlier call's) choice
-    if torch.cuda.is_initialized():
-        warnings.warn("mpmavatar_amd.fd: the HIP runtime is already initialised, GPU_MAX_HW_QUEUES cannot be raised any more; the "
-                      "concurrent finite-difference contexts will share hardware queues (about -20 % throughput).  Call "
+        return True                      # exported by the user (before the process started: in time by construction)
+    if hip_runtime_started():
+        warnings.warn("mpmavatar_amd.fd: the HIP runtime of this process is already initialised (/dev/kfd is open: some torch.cuda / HIP "
+                      "call ran, torch.cuda.is_available() counts), GPU_MAX_HW_QUEUES cannot be raised any more; the concurrent "
+                      "finite-difference contexts will share hardware queues (about -20 % throughput).  Call "
                       "mpmavatar_amd.fd.request_hw_queues() or export GPU_MAX_HW_QUEUES=8 before the first CUDA/HIP call.", stacklevel=2)
+        _HWQ_SET_BY_US = False
         return False
     os.environ["GPU_MAX_HW_QUEUES"] = str(int(n))
+    _HWQ_SET_BY_US = True
     return True
 
 
@@ -75,7 +102,7 @@ class MaterialFD:
 
     def __init__(self, scene: Scene, frames: Sequence[Frame], *, init=(1.0, 1.0, 1.0), ranges=((0.1, 10.0), (0.1, 10.0), (0.5, 1.5)),
                  lrs=(0.05, 0.05, 0.005), iterations=100, frame_dt=1.0 / 25, substeps=400, scale=1.0, shift=(0.0, 0.0, 0.0),
-                 device="cuda:0", concurrent=True, mode=None, variants: Optional[Sequence[int]] = None, build=True, batched=False):
+                 device="cuda:0", concurrent=True, mode=None, variants: Optional[Sequence[int]] = None, build=True):
         self.sc, self.frames = scene, list(frames)
         self.device = torch.device(device)
         self.iterations = int(iterations)
@@ -96,13 +123,12 @@ class MaterialFD:
         if not build:   # optimiser / bookkeeping only (host-side tests)
             self.concurrent, self.sims, self.pool = False, [], None
             return
-        # batched (round 5): the variants' contexts on ONE stream, stepped in lock step with one launch per phase for all of them
-        # (MPMWARP.p2g2p_n_multi -> mpmhip_steps_multi, csrc/batch.hip) instead of one stream + host thread per variant
-        self.batched = bool(batched) and len(self.variants) > 1
-        self.concurrent = bool(concurrent) and len(self.variants) > 1 and not self.batched
+        # concurrent: one context, HIP stream and host thread per variant (one batched launch per phase over the four contexts was built
+        # in round 5, bit-identical and slower -- 31.9 k against 46.2 k substeps/s -- and removed again: profiles/r05_experiments.md 7)
+        self.concurrent = bool(concurrent) and len(self.variants) > 1
         if self.concurrent:
             request_hw_queues()          # (opt-in by use: only the concurrent contexts want it; no import side effect)
-        n_ctx = len(self.variants) if (self.concurrent or self.batched) else 1
+        n_ctx = len(self.variants) if self.concurrent else 1
         self.streams = [torch.cuda.Stream(self.device) for _ in range(n_ctx)] if self.concurrent else [None] * n_ctx
         self.sims = []
         for s in self.streams:
@@ -144,42 +170,10 @@ class MaterialFD:
                 record.append(cloth.detach().cpu().numpy().copy())
         return float((loss / len(self._frames)).item())
 
-    def _prepare(self, sim, D: float, E: float, H: float):
-        """The per-simulation set-up of ``simulate`` (:584-609)."""
-        sc, dev = self.sc, self.device
-        st, md, sv = sim.state, sim.model, sim.solver
-        scaled = self._verts0 * np.array([[1.0, H, 1.0]], np.float32)
-        R_inv = torch.as_tensor(garment.compute_rest_dir_inv_from_vf(scaled, sc.faces), device=dev)
-        st.reset_state(sc.n_vertices, self._x0.clone(), self._d0.clone(), None, self._v0.clone(), tensor_R_inv=R_inv, device=dev,
-                       requires_grad=True)
-        st.set_require_grad(True)
-        ones = torch.ones(sc.n_particles, dtype=torch.float32, device=dev)
-        st.reset_density(ones * D, None, dev, update_mass=True)
-        sv.set_E_nu_from_torch(md, ones * (E * 100.0), ones * sc.nu, ones * sc.gamma, ones * sc.kappa, dev)
-        sv.prepare_mu_lam(md, st, dev)
-
-    def simulate_batched(self, jobs) -> List[float]:
-        """All variants frame by frame, every frame's substeps as ONE joint call for all of them."""
-        from .warp_mpm import MPMWARP
-        sc, dev, k = self.sc, self.device, len(jobs)
-        sims = self.sims[:k]
-        for sim, p in zip(sims, jobs):
-            self._prepare(sim, *p)
-        loss = [torch.zeros((), dtype=torch.float32, device=dev) for _ in range(k)]
-        for f in self._frames:
-            MPMWARP.p2g2p_n_multi([s.solver for s in sims], [s.model for s in sims], [s.state for s in sims], self.substep_size, self.substeps,
-                                  mesh_x=[f["mesh_x"]] * k, mesh_v=[f["mesh_v"]] * k, joint_verts_v=[f["jv"]] * k, joint_faces_v=[f["jf"]] * k)
-            for i, sim in enumerate(sims):
-                cloth = self.sim2wld(sim.state.particle_x[sc.n_elements:])
-                loss[i] = loss[i] + torch.nn.functional.mse_loss(cloth, f["target"])
-        return [float((l / len(self._frames)).item()) for l in loss]
-
     def losses(self, D: float, E: float, H: float) -> List[float]:
         """Losses of this process's variants at (D, E, H) + DELTAS[i]."""
         jobs = [(D + DELTAS[i][0], E + DELTAS[i][1], H + DELTAS[i][2]) for i in self.variants]
-        if self.batched:
-            out = self.simulate_batched(jobs)
-        elif not self.concurrent:
+        if not self.concurrent:
             out = [self.simulate(self.sims[0], *p) for p in jobs]
         else:
             def work(k):

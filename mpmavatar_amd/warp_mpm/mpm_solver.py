@@ -362,46 +362,7 @@ class MPMWARP(object):
         if self._read_snaps:
             self._refresh_held()
 
-    @staticmethod
-    def p2g2p_n_multi(solvers, models, states, dt, n, mesh_x=None, mesh_v=None, joint_traditional_v=None, joint_verts_v=None,
-                      joint_faces_v=None):
-        """``p2g2p_n`` for SEVERAL solvers in lock step (no reference counterpart; ``mpmhip_steps_multi``, csrc/batch.hip): the
-        independent simulations of the finite-difference training step (train_material_params.py:583-631) with ONE launch per phase
-        for all of them.  Every per-solver argument is a list with one entry per solver (or None); the solvers must have been created
-        on the same HIP stream.  Results are those of separate ``p2g2p_n`` calls, bit for bit."""
-        k = len(solvers)
-        lst = lambda a: list(a) if a is not None else [None] * k
-        mxs, mvs, jts, jvs, jfs = lst(mesh_x), lst(mesh_v), lst(joint_traditional_v), lst(joint_verts_v), lst(joint_faces_v)
-        ptrs = {name: (C.c_void_p * k)() for name in ("ctx", "mx", "mv", "jt", "jv", "jf")}
-        njt = (C.c_int32 * k)()
-        dp = lambda t: None if (t is None or t.numel() == 0) else t.data_ptr()
-        for i, sv in enumerate(solvers):
-            if dt != sv._host_dt:
-                sv._call("mpmhip_set_host_dt", float(dt))
-                sv._host_dt = dt
-            sv._push_if_modified()
-            sv._bind(models[i], states[i])
-            has_mesh = hasattr(sv, "mesh")
-            mx = sv._ptr(mxs[i], sv.num_mesh_v if has_mesh else None, "mesh_x")
-            mv = sv._ptr(mvs[i], sv.num_mesh_v if has_mesh else None, "mesh_v")
-            jt = sv._ptr(jts[i])
-            jv = sv._ptr(jvs[i], sv.num_joint_v, "joint_verts_v")
-            jf = sv._ptr(jfs[i], sv.num_joint_f, "joint_faces_v")
-            sv._keep = (mx, mv, jt, jv, jf)
-            ptrs["ctx"][i] = sv._ctx.value if hasattr(sv._ctx, "value") else sv._ctx
-            ptrs["mx"][i], ptrs["mv"][i], ptrs["jt"][i] = dp(mx), dp(mv), dp(jt)
-            ptrs["jv"][i] = dp(jv) if jv is None or jv.numel() else sv._dummy_ptr()
-            ptrs["jf"][i] = dp(jf) if jf is None or jf.numel() else sv._dummy_ptr()
-            njt[i] = 0 if jt is None else int(jt.shape[0])
-        sv0 = solvers[0]
-        rc = sv0._lib.mpmhip_steps_multi(ptrs["ctx"], k, float(dt), int(n), ptrs["mx"], ptrs["mv"], ptrs["jt"], njt, ptrs["jv"], ptrs["jf"])
-        if rc != L.OK:
-            msgs = [sv._lib.mpmhip_last_error(sv._ctx).decode() for sv in solvers]
-            raise L.MPMHipError(rc, next((m for m in msgs if m), "mpmhip_steps_multi failed"))
-        for sv in solvers:
-            sv._stale = True
-            if sv._read_snaps:
-                sv._refresh_held()
+
 
     def _dummy_ptr(self):
         if not hasattr(self, "_dummy"):

@@ -55,7 +55,11 @@ def _wide_sheet8():
     return scenes.sheet(n=128, n_grid=256, collider_subdiv=3, n_steps=100, name="sheet-128x128")
 
 
-SCENES = {"widesheet8": _wide_sheet8, "widesheet": _wide_sheet, "crossing": _crossing_cube, "sway": _sway_garment, "demohold": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=(10, 5, 64)),
+def _registry(name):
+    return lambda: scenes.REGISTRY[name]()
+
+
+SCENES = {"sheet-500k": _registry("sheet-500k"), "widesheet8": _wide_sheet8, "widesheet": _wide_sheet, "crossing": _crossing_cube, "sway": _sway_garment, "demohold": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=(10, 5, 64)),
           "garment": scenes.small_garment, "sheet": scenes.small_sheet, "cube": scenes.small_cube, "fastcube": _fast_cube,
           "demo": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=False)}
 
@@ -112,6 +116,7 @@ def main():
         dev = f"cuda:{rank}" if torch.cuda.device_count() >= world else "cuda:0"
         torch.cuda.set_device(dev)
         if os.environ.get("MPMHIP_TEST_FAIL_BUILD_RANK"):   # every rank must get the collective error, none may hang
+            mdist._TEST_FAIL_BUILD_RANK = int(os.environ["MPMHIP_TEST_FAIL_BUILD_RANK"])
             try:
                 mdist.build_sharded(sc, dev, rank, world)
                 print(f"dist rank {rank}: build_sharded did not raise", flush=True)
@@ -122,6 +127,22 @@ def main():
                 dist.destroy_process_group()
                 sys.exit(0)
         ss = mdist.build_sharded(sc, dev, rank, world, rebin_interval=int(os.environ.get("MPMHIP_TEST_REBIN", "8")))
+        if os.environ.get("MPMHIP_TEST_HEAVY_RANK"):
+            # masses changed AFTER the build, on ONE rank only (its own span stays 1, the scene's becomes 1e7): every rank
+            # must move to the fp64 tile together at its next import -- decided from the bound masses, all-reduced, not from the scene
+            assert ss.sim.solver.stats()["p2g_tile_in_use"] in (0, 1)
+            ones = torch.ones(ss.sim.scene.n_particles, dtype=torch.float32, device=dev)
+            heavy = 1.0e7 if rank == int(os.environ["MPMHIP_TEST_HEAVY_RANK"]) else 1.0
+            ss.sim.state.reset_density(ones * (sc.density * heavy), None, dev, update_mass=True)
+            span = mdist.sync_mass_span(ss)
+            mdist.run(ss, 4)
+            tile = ss.sim.solver.stats()["p2g_tile_in_use"]
+            print(f"dist[{scene_name}] rank {rank}: scene mass span {span:.1e}, p2g tile in use {tile}", flush=True)
+            fin = bool(torch.isfinite(ss.sim.state.particle_x).all())
+            flag = torch.tensor([1 if (tile == 2 and span > 1e6 and fin) else 0])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            dist.destroy_process_group()
+            sys.exit(0 if flag.item() == 1 else 1)
         ss.migrate_fraction = float(os.environ.get("MPMHIP_TEST_MIGRATE", "0"))
         chunk = int(os.environ.get("MPMHIP_TEST_RUN_CHUNK", str(steps)))
         ss.migrate_check_every = 1  # look at every run() call (production: every 512 substeps)
@@ -170,6 +191,21 @@ def main():
             scale = max(float(np.abs(x).max()), 1e-3)
             print(f"dist[{scene_name}] world={world} steps={steps} max rel dx vs single context = {err / scale:.3e}", flush=True)
             ok &= np.isfinite(err) and err / scale < 1e-5
+        if os.environ.get("MPMHIP_TEST_FULL"):
+            # BASELINE config 4's N > 1 leg at full size: x AND v of every particle, assembled from its owner,
+            # against the single context (<= 1e-6: the ranks compute the same substep, only the order of the halo sums differs) and
+            # against the OpenMP oracle (<= 1e-4, the north star's bound)
+            if rank == 0:
+                rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-3))
+                xs, vs = ref.state.particle_x.cpu().numpy(), ref.state.particle_v.cpu().numpy()
+                ex, ev = rel(glob["particle_x"], xs), rel(glob["particle_v"], vs)
+                from oracle.scene_adapter import omp_threads, oracle_from_scene, run_scene
+                o = oracle_from_scene(sc, omp=True, n_threads=omp_threads())
+                run_scene(o, sc, steps)
+                ox, ov = rel(glob["particle_x"], o.x), rel(glob["particle_v"], o.v)
+                print(f"dist[{scene_name}] FULL world={world} steps={steps} n_particles={sc.n_particles} n_grid={sc.n_grid}: vs single context "
+                      f"rel dx {ex:.2e} rel dv {ev:.2e}; vs oracle rel dx {ox:.2e} rel dv {ov:.2e}", flush=True)
+                ok &= ex < 1e-6 and ev < 1e-6 and ox < 1e-4 and ov < 1e-4
     flag = torch.tensor([1 if ok else 0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()

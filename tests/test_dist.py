@@ -211,6 +211,23 @@ def test_in_library_loop_with_four_and_eight_ranks(world, halo):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("halo", ["peer", "rccl"])
+def test_s4_sheet_500k_full_size_through_the_in_library_loop_two_ranks(halo, oracle_lib):
+    """BASELINE.json config 4, the N > 1 leg at FULL size (497,762 particles, 256^3) in the driver-run suite: two
+    ranks of `mpmhip_rccl_steps` -- the loop `bench.py --gpus 2` runs (reference loop: mpm_solver.py:229-536) -- over the RCCL stand-in
+    on the one GPU, 20 substeps; x and v of every particle, assembled from its owning rank, within 1e-6 of the single context and
+    within the north star's 1e-4 of the OpenMP oracle."""
+    import re
+    out = _launch(2, "gpu", "sheet-500k", 20, timeout=1200,
+                  extra_env=_mock_rccl_env(MPMHIP_TEST_REBIN=0, MPMHIP_DIST_HALO=halo, MPMHIP_VERBOSE=1, MPMHIP_TEST_FULL=1))
+    m = re.search(r"FULL world=2 steps=20 n_particles=(\d+) n_grid=(\d+): vs single context rel dx (\S+) rel dv (\S+); vs oracle rel dx (\S+) rel dv (\S+)", out)
+    assert m, out[-3000:]
+    print(m.group(0))
+    assert int(m.group(1)) == 497762 and int(m.group(2)) == 256
+    assert out.count("halos: peer-mapped" if halo == "peer" else "halos: send/recv") == 2, out[-2000:]
+
+
+@pytest.mark.gpu
 def test_peer_link_failure_on_one_rank_sends_every_rank_back_to_send_recv():
     """The decision for peer-mapped halos is collective: rank 1 reports that its links failed (MPMHIP_LINK_FAULT), and
     all three ranks keep their halos on the send/recv groups -- with the same result."""
@@ -236,6 +253,16 @@ def test_a_rank_whose_local_build_fails_takes_every_rank_out_cleanly(bad):
     out = _launch(3, "gpu", "sheet", 10, timeout=300, extra_env={"MPMHIP_TEST_FAIL_BUILD_RANK": str(bad)})
     assert out.count("collective build error") == 3, out[-2000:]
     assert out.count("on this rank") == 1 and out.count("another rank") == 2, out[-2000:]
+
+
+@pytest.mark.gpu
+def test_one_tile_decision_for_all_ranks_from_the_bound_masses():
+    """MPMHIP_P2G_TILE_AUTO in a sharded run.  Rank 1's particles are made 1e7 times heavier AFTER the build
+    (reset_density(update_mass=True)): rank 0's own masses still span a factor of one, the scene's 1e7.  Both ranks must run the fp64
+    tile from the next import on -- the span is measured on the bound mass tensors and all-reduced (mpmhip_dist_set_mass_span),
+    not read off the scene description, and AUTO is never forced to the fixed-point tile."""
+    out = _launch(2, "gpu", "cube", 4, extra_env={"MPMHIP_TEST_HEAVY_RANK": "1"})
+    assert out.count("p2g tile in use 2") == 2, out[-2000:]
 
 
 @pytest.mark.gpu

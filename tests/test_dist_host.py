@@ -115,19 +115,3 @@ def test_device_side_quantile_cuts_match_np_quantile_to_a_bin():
         assert sum(sizes) == px.size and max(sizes) - min(sizes) <= 0.1 * px.size / world + 48   # (lattice columns are 24 vertices)
         assert all(np.array_equal(s.cuts, cuts) for s in shards)
     assert md.cuts_from_histogram(np.zeros(md.CUT_BINS, np.int64), 4, 2.0).size == 0
-
-
-def test_one_tile_decision_for_all_ranks():
-    """MPMHIP_P2G_TILE_AUTO speaks about the SCENE's mass span; a sharded run decides once from the global scene."""
-    from mpmavatar_amd import dist as mdist, scenes
-    sc = scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8))
-    assert mdist.global_p2g_tile(sc) == "fixed"
-    heavy = scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8))
-    heavy.vol = heavy.vol.copy()
-    heavy.vol[heavy.n_elements:heavy.n_elements + heavy.n_traditional] *= 1e7      # sand 1e7 times heavier than the cloth
-    assert mdist.global_p2g_tile(heavy) == "f64"
-    frozen = scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8))
-    frozen.vol = heavy.vol
-    frozen.selection = np.zeros(frozen.n_particles, np.int32)
-    frozen.selection[frozen.n_elements:frozen.n_elements + frozen.n_traditional] = 1  # ... but not simulated: does not count
-    assert mdist.global_p2g_tile(frozen) == "fixed"

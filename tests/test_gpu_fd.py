@@ -10,11 +10,11 @@ from mpmavatar_amd import fd, scenes
 pytestmark = pytest.mark.gpu
 
 
-def _problem(concurrent, init=(1.0, 1.0, 1.0), batched=False):
+def _problem(concurrent, init=(1.0, 1.0, 1.0)):
     sc = scenes.garment_cylinder(n_theta=24, n_h=12, n_grid=48, aniso=True, collider_subdiv=2)
     frames = fd.synthetic_problem(sc, n_frames=3, frame_dt=30e-4)
     return fd.MaterialFD(sc, frames, init=init, lrs=(0.05, 0.05, 0.005), iterations=20, frame_dt=30e-4, substeps=30, scale=0.8,
-                         shift=(0.2, 0.1, 0.3), concurrent=concurrent, batched=batched)
+                         shift=(0.2, 0.1, 0.3), concurrent=concurrent)
 
 
 def test_concurrent_variants_match_the_sequential_order():
@@ -28,52 +28,6 @@ def test_concurrent_variants_match_the_sequential_order():
     assert len({round(x / la[0], 6) for x in la}) > 1      # the nudged parameters really changed the runs
     assert a.substeps_done == 4 * 3 * 30
     a.close(); b.close()
-
-
-def test_batched_variants_match_the_sequential_order():
-    """The four variants as four contexts on one stream, one launch per phase for all of them (mpmhip_steps_multi)."""
-    a, b = _problem(False, batched=True), _problem(False)
-    assert a.batched and len(a.sims) == 4
-    fd.capture(a, 1.0, 1.0, 1.0)
-    for f, g in zip(b._frames, a._frames):
-        f["target"] = g["target"].clone()
-    la, lb = a.losses(1.3, 0.8, 1.0), b.losses(1.3, 0.8, 1.0)
-    assert len(la) == 4 and all(np.isfinite(la)) and la[0] > 0
-    np.testing.assert_allclose(la, lb, rtol=2e-3)
-    assert len({round(x / la[0], 6) for x in la}) > 1
-    assert all(s.solver.stats()["batched_substeps"] == 3 * 30 for s in a.sims)     # every substep went through the batched launches
-    a.close(); b.close()
-
-
-def test_lock_step_call_equals_separate_calls(oracle_lib):
-    """MPMWARP.p2g2p_n_multi on three different scenes' solvers (cloth with collider + mover, a sheet over a sphere, a jelly cube: the
-    last one is not a form the batch covers and goes out by itself inside the joint loop) = three separate p2g2p_n calls = the oracle."""
-    from mpmavatar_amd import harness
-    from mpmavatar_amd.warp_mpm import MPMWARP
-    from oracle.scene_adapter import oracle_from_scene, run_scene
-    mk = [scenes.small_garment, scenes.small_sheet, scenes.small_cube]
-    multi, single = [harness.build_solver(f(), "cuda:0", mode="fast") for f in mk], [harness.build_solver(f(), "cuda:0", mode="fast") for f in mk]
-    t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a, np.float32), device="cuda:0").reshape(-1, 3)
-    for n in (1, 7, 40, 2):
-        args = {k: [] for k in ("mesh_x", "mesh_v", "joint_verts_v", "joint_faces_v")}
-        for sim in multi:
-            sc, k0 = sim.scene, sim.steps_done
-            args["mesh_x"].append(None if sim.mesh_x0 is None else sim.mesh_x0 + np.float32(sc.dt * k0) * sim.mesh_v)
-            args["mesh_v"].append(sim.mesh_v)
-            args["joint_verts_v"].append(sim.joint_verts_v)
-            args["joint_faces_v"].append(sim.joint_faces_v)
-            sim.steps_done += n
-        MPMWARP.p2g2p_n_multi([s.solver for s in multi], [s.model for s in multi], [s.state for s in multi], multi[0].scene.dt, n, **args)
-        for sim in single:
-            harness.run(sim, n, fused=True)
-    for a, b in zip(multi, single):
-        xa, xb = a.state.particle_x.cpu().numpy(), b.state.particle_x.cpu().numpy()
-        va, vb = a.state.particle_v.cpu().numpy(), b.state.particle_v.cpu().numpy()
-        assert np.abs(xa - xb).max() < 1e-6 and np.abs(va - vb).max() < 2e-3 * max(np.abs(vb).max(), 1e-3), a.scene.name
-        o = oracle_from_scene(a.scene)
-        run_scene(o, a.scene, 50)
-        assert np.abs(xa - o.x).max() / np.abs(o.x).max() < 1e-5, a.scene.name
-    assert multi[0].solver.stats()["batched_substeps"] == 50 and multi[1].solver.stats()["batched_substeps"] == 50
 
 
 def test_loss_vanishes_at_the_captured_parameters_and_training_reduces_it():

@@ -65,21 +65,21 @@ def test_s3_garment_120k_anisotropic_with_collider_50_substeps(oracle_lib):
 #       the reference's, whatever the dynamics do with rounding afterwards;
 #   (c) the free-running |dv| as a DISTRIBUTION against an ensemble: K = 5 oracle runs that differ only in the order of their atomic
 #       adds (thread counts T, T-1, ... of the OpenMP build) give 10 pairwise distance distributions; the HIP run's distance to each
-#       of the five must lie in the range those ten span, widened by ONE fixed margin (a factor of two), at the median, the 90th, 99th and 99.9th
-#       percentile and at the maximum.
+#       of the five (median over the five) must lie in the range those ten span, widened by ONE fixed margin (a factor of two), at the
+#       median, the 90th, 99th and 99.9th percentile and at the maximum.
 # And (d): the same scenes WITHOUT the shear term (gamma = 0: no discontinuity in mpm_utils.py:196-204, nothing to amplify) hold the
 # north star's 1e-4 on x AND v over the full 1000 substeps, strictly (test_*_gamma0_*).
 QUANTILES = (0.5, 0.9, 0.99, 0.999)
-# ONE fixed margin for every statistic: HIP within a factor of two of the range the ensemble's ten pairs span.  Why not tighter: the
-# statistics of the transition phase (substep 100 of S3: the top percent of the particles has reached the saturated level, the rest not
-# yet) are noisy in the ENSEMBLE ITSELF -- its ten pair values of p99 span 2.1e-5 .. 9.1e-5 in one run and 6.7e-5 .. 1.0e-4 in another --
-# and the HIP path enters that phase from a larger per-substep rounding difference (one-substep map 7e-7 of the top speed: FMA
-# contraction, fixed-point tile) than a re-ordering of the oracle's own sums (1e-7), so it gets there a few substeps earlier.  Observed
-# ratio HIP / ensemble maximum over the (checkpoint, statistic) values above the tolerance floor in five full runs: <= 1.60 (round 5
-# first used 1.5 and failed at 1.5006; profiles/r05_fullsize_margin_runs.txt).  Where the ensemble's own ten values span more than a
-# factor of two the margin is that span (capped at four): the tolerance follows the ensemble's own noise.
-Q_MARGIN = 2.0
-MAX_MARGIN = 2.0
+# ONE fixed margin for every statistic and every checkpoint: the median over the five oracle members of HIP's statistic lies within a
+# factor of two of the range the ensemble's ten pairs span.  Why not tighter: the statistics of the transition phase (substep 100 of
+# S3: the top percent of the particles has reached the saturated level, the rest not yet) are noisy in the ENSEMBLE ITSELF -- its ten
+# pair values of p99 span 2.1e-5 .. 9.1e-5 in one run and 6.7e-5 .. 1.0e-4 in another -- and the HIP path enters that phase from a
+# larger per-substep rounding difference (one-substep map 7e-7 of the top speed: FMA contraction, fixed-point tile) than a
+# re-ordering of the oracle's own sums (1e-7), so it gets there a few substeps earlier.  Observed ratio HIP / ensemble maximum over the
+# (checkpoint, statistic) values above the tolerance floor in five full runs: <= 1.60 (profiles/r05_fullsize_margin_runs.txt).  The
+# factor is NOT adapted to the run (round 5 widened it to the ensemble's own span, up to four): the span is printed,
+# the bound is the constant.
+MARGIN = 2.0
 K_ORACLES = 5
 
 
@@ -149,7 +149,8 @@ def _check(rows, what):
     for r in rows:
         cp = r["substep"]
         hip, pairs = np.array(r["hip"]), np.array(r["pairs"])
-        line = ", ".join(f"{n} {np.median(hip[:, i]):.1e} [{pairs[:, i].min():.1e}..{pairs[:, i].max():.1e}]" for i, n in enumerate(names))
+        line = ", ".join(f"{n} {np.median(hip[:, i]):.1e} [{pairs[:, i].min():.1e}..{pairs[:, i].max():.1e}, span x{pairs[:, i].max() / max(pairs[:, i].min(), 1e-30):.1f}]"
+                         for i, n in enumerate(names))
         print(f"{what} substep {cp}: x {r['dx']:.1e}; |dv| HIP-vs-oracle (median of {len(hip)}) [oracle-vs-oracle range of {len(pairs)} pairs]: "
               f"{line}; top speed {r['vmax']:.2f}; one-substep map {r['one_step']}")
         assert r["dx"] < 1e-4 and r["ppx"] < 1e-4, f"{what} substep {cp}: x {r['dx']:.2e} (per particle {r['ppx']:.2e})"
@@ -160,9 +161,7 @@ def _check(rows, what):
         for i, n in enumerate(names):
             h = float(np.median(hip[:, i]))
             lo, hi = float(pairs[:, i].min()), float(pairs[:, i].max())
-            # the fixed factor of two -- or, where the ensemble's OWN ten values of this statistic span more than that (transition
-            # phases: some pairs have reached the saturated level, others not yet), the factor they span, at most four
-            margin = min(max(MAX_MARGIN if n == "max" else Q_MARGIN, hi / max(lo, 1e-30)), 4.0)
+            margin = MARGIN
             assert h <= max(margin * hi, floor), f"{what} substep {cp}: {n} of |dv| {h:.2e} m/s above {margin} x the ensemble's {hi:.2e}"
             # ... and not BELOW the ensemble either (a HIP run that stayed implausibly close to one oracle order would not be running the
             # same dynamics): only meaningful where the ensemble has spread at all
@@ -185,6 +184,17 @@ def test_s4_sheet_500k_1000_substeps_north_star_protocol(oracle_lib):
     sc, rows = _follow("sheet-500k", [100, 300, 600, 1000])
     assert sc.n_particles == 497762 and sc.n_grid == 256 and sc.gamma > 0
     _check(rows, "S4")
+
+
+def test_demo_250_full_size_1000_substeps(oracle_lib):
+    """BASELINE.json config 5's solver part at FULL size in the driver-run suite: the run_demo.py stand-in --
+    200 x 200 garment sheet + 100,000 sand particles (Drucker-Prager) on a 250^3 grid, floor, body collider, staged release of the
+    held sand through joint_traditional_v (run_demo.py:142,219-379,514-530) -- 1000 substeps against the five-member OpenMP oracle
+    ensemble: (a) x strict 1e-4 at substeps 100 / 400 / 1000, per particle too; (b) the one-substep map from identical inputs at each
+    of them, x and v strict 1e-4; (c) the free-running |dv| distribution within the fixed margin of the ensemble's own."""
+    sc, rows = _follow("demo-250", [100, 400, 1000])
+    assert sc.n_grid == 250 and sc.n_traditional == 100000 and sc.n_elements > 0 and sc.joint_t_hold > 0
+    _check(rows, "demo-250")
 
 
 @pytest.mark.parametrize("name,n_p", [("garment-120k-aniso", 119600), ("sheet-500k", 497762)])

@@ -13,8 +13,8 @@ n_theta, n_h, n_grid, n_frames, substeps = (a + [200, 200, 128, 2, 400][len(a):]
 sc = scenes.garment_cylinder(n_theta=n_theta, n_h=n_h, n_grid=n_grid, aniso=True)
 frames = fd.synthetic_problem(sc, n_frames=n_frames, frame_dt=substeps * 1e-4)
 out = {"scene": sc.name, "n_particles": sc.n_particles, "n_grid": n_grid, "frames": n_frames, "substeps_per_frame": substeps}
-for label, conc, bat in (("sequential", False, False), ("concurrent", True, False), ("batched", False, True)):
-    m = fd.MaterialFD(sc, frames, frame_dt=substeps * 1e-4, substeps=substeps, concurrent=conc, batched=bat)
+for label, conc in (("sequential", False), ("concurrent", True)):
+    m = fd.MaterialFD(sc, frames, frame_dt=substeps * 1e-4, substeps=substeps, concurrent=conc)
     fd.capture(m, 1.0, 1.0, 1.0)
     m.losses(1.2, 1.0, 1.0)   # warm-up: first sorts, allocations
     torch.cuda.synchronize(); t0 = time.perf_counter(); n0 = m.substeps_done
@@ -25,7 +25,6 @@ for label, conc, bat in (("sequential", False, False), ("concurrent", True, Fals
     print(label, out[label], flush=True)
     m.close(); del m
 out["speedup"] = out["concurrent"]["substeps_per_s"] / out["sequential"]["substeps_per_s"]
-out["speedup_batched"] = out["batched"]["substeps_per_s"] / out["sequential"]["substeps_per_s"]
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/fd_bench.json", "w"), indent=1)
 print(json.dumps(out))
