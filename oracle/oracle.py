@@ -85,11 +85,11 @@ def build(force: bool = False) -> None:
 _libs: dict = {}
 
 
-def _load(omp: bool):
-    key = "omp" if omp else "serial"
+def _load(omp: bool, fma: bool = False):
+    key = ("omp_fma" if fma else "omp") if omp else "serial"
     if key in _libs:
         return _libs[key]
-    path = os.path.join(_BUILD, "liboracle_omp.so" if omp else "liboracle.so")
+    path = os.path.join(_BUILD, {"serial": "liboracle.so", "omp": "liboracle_omp.so", "omp_fma": "liboracle_omp_fma.so"}[key])
     src = os.path.join(_HERE, "mpm_oracle.c")
     if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
         build()
@@ -180,8 +180,8 @@ class OracleMPM:
     """
 
     def __init__(self, n_particles, n_elements, n_vertices, n_grid=100, grid_lim=1.0, mesh_vertices=None,
-                 mesh_faces=None, num_joint_t=0, num_joint_v=0, num_joint_f=0, omp=False, n_threads=1):
-        self.lib = _load(omp)
+                 mesh_faces=None, num_joint_t=0, num_joint_v=0, num_joint_f=0, omp=False, n_threads=1, fma=False):
+        self.lib = _load(omp, fma and omp)   # fma: the FMA-contracted OpenMP build (ensemble member, see oracle/Makefile)
         self.n_particles, self.n_elements, self.n_vertices = n_particles, n_elements, n_vertices
         self.n_nv = n_nv = n_particles - n_vertices
         self.n_grid, self.grid_lim = n_grid, grid_lim

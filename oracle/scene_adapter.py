@@ -26,10 +26,10 @@ def omp_threads() -> int:
     return max(1, min(16, avail))
 
 
-def oracle_from_scene(sc, omp=False, n_threads=1) -> OracleMPM:
+def oracle_from_scene(sc, omp=False, n_threads=1, fma=False) -> OracleMPM:
     o = OracleMPM(sc.n_particles, sc.n_elements, sc.n_vertices, n_grid=sc.n_grid, grid_lim=sc.grid_lim,
                   mesh_vertices=sc.mesh_vertices, mesh_faces=sc.mesh_faces, num_joint_v=sc.num_joint_v,
-                  num_joint_f=sc.num_joint_f, omp=omp, n_threads=n_threads)
+                  num_joint_f=sc.num_joint_f, omp=omp, n_threads=n_threads, fma=fma)
     o.x[:] = sc.x
     o.v[:] = sc.v
     o.vol[:] = sc.vol

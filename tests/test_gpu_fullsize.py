@@ -63,8 +63,9 @@ def test_s3_garment_120k_anisotropic_with_collider_50_substeps(oracle_lib):
 #   (b) the ONE-SUBSTEP MAP at every checkpoint, i.e. in the draped states too: the oracle is set to the HIP state, both advance one
 #       substep, x and v of ALL particles agree to 1e-4 (strict; measured ~1e-6) -- what the implementation computes per substep is
 #       the reference's, whatever the dynamics do with rounding afterwards;
-#   (c) the free-running |dv| as a DISTRIBUTION against an ensemble: K = 5 oracle runs that differ only in the order of their atomic
-#       adds (thread counts T, T-1, ... of the OpenMP build) give 10 pairwise distance distributions; the HIP run's distance to each
+#   (c) the free-running |dv| as a DISTRIBUTION against an ensemble: K = 5 oracle runs -- three that differ only in the order of their
+#       atomic adds (thread counts of the OpenMP build) and two of the FMA-contracted build of the same source (round 6) -- give 10
+#       pairwise distance distributions; the HIP run's distance to each
 #       of the five (median over the five) must lie in the range those ten span, widened by ONE fixed margin (a factor of two), at the
 #       median, the 90th, 99th and 99.9th percentile and at the maximum.
 # And (d): the same scenes WITHOUT the shear term (gamma = 0: no discontinuity in mpm_utils.py:196-204, nothing to amplify) hold the
@@ -108,7 +109,14 @@ def _follow(name, checkpoints, gamma0=False, k_oracles=K_ORACLES):
     threads = [max(T // k_oracles + (1 if k < T % k_oracles else 0), 2) for k in range(k_oracles)] if k_oracles > 1 else [T]
     tmp = tempfile.mkdtemp(prefix="oracle_ensemble_")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, name, "1" if gamma0 else "0", str(t), os.path.join(tmp, f"o{k}.npz")]
+    # Members 3 and 4 of a five-member ensemble are the FMA-CONTRACTED build of the same restatement (oracle/Makefile): the strict members
+    # differ from each other only in the order of their atomic adds (~1e-7 of the top speed per substep), the HIP build also in where a
+    # product and a sum are fused (-ffp-contract=fast-honor-pragmas: ~7e-7 per substep, the one-substep map below) -- and so does a
+    # contracted member.  While a scene is still AMPLIFYING rounding (sand: no saturated level within 1000 substeps) the distance
+    # between two trajectories is proportional to what they were perturbed by, and an ensemble of re-orderings alone is a factor 4-7
+    # closer to itself than any other legitimate fp32 evaluation is to it (round 6: demo-250 p90 at substep 400, 4.1e-5 against 1.0e-5).
+    fma_members = {3, 4} if k_oracles >= 5 else set()
+    procs = [subprocess.Popen([sys.executable, worker, name, "1" if gamma0 else "0", str(t) + ("f" if k in fma_members else ""), os.path.join(tmp, f"o{k}.npz")]
                               + [str(c) for c in checkpoints], stdout=subprocess.DEVNULL) for k, t in enumerate(threads)]
     try:
         probe = oracle_from_scene(sc, omp=True, n_threads=max(T // 4, 2) if k_oracles > 1 else T)
