@@ -359,9 +359,8 @@ def _main(out_stream):
                 "g2p_v": pb["g2p_v"] + 28 * n_act + 40 * n_col + 16 * n_mov,                            # + grid stage
             }
             fused_bytes["g2p2g"] = fused_bytes["p2g"] + fused_bytes["g2p_v"]   # (traditional-only scenes: one launch does both)
-            fused_bytes["p2g_g2p"] = fused_bytes["p2g"] + fused_bytes["g2p_v"]  # (cloth scenes, round 6: p2g and g2p as one launch behind a phase gate)
             fused_kernel = {"compute_stress_from_F_trial": "k_stress_elem<true>", "p2g": "k_p2g", "g2p_v": "k_g2p",
-                            "rebin": "re-sort", "g2p2g": "k_g2p2g", "p2g_g2p": "k_p2g_g2p"}
+                            "rebin": "re-sort", "g2p2g": "k_g2p2g"}
             med = lambda v: sorted(v)[len(v) // 2] if v else 0.0
 
             def stamped_pass(n_prof):
@@ -394,10 +393,8 @@ def _main(out_stream):
                         k["frac_of_measured_copy"] = k["GBps"] / copy_bw["hbm_2x1GiB_GBps"]
                         if k["GBps"] > COPY_CEILING_GBS:
                             k["exceeds_copy_ceiling"] = True   # read `traffic_frac`, not `frac`, for this launch
-                        phases_of = ["p2g", "g2p_v"] if name == "p2g_g2p" else [name]
-                        trs = [pmc_traffic(ph, args.scene, only=fused_kernel.get(ph) if ph == "g2p_v" else None) for ph in phases_of]
-                        if all(t[0] for t in trs):
-                            tr, src = sum(t[0] for t in trs), trs[0][1]
+                        tr, src = pmc_traffic(name, args.scene, only=fused_kernel.get(name) if name == "g2p_v" else None)
+                        if tr:
                             k["traffic"], k["traffic_GBps"], k["traffic_source"] = tr, tr / (ms * 1e-3) / 1e9, src
                             k["traffic_frac"] = k["traffic_GBps"] / HBM_PEAK_GBS
                     ks_out.append(k)
@@ -405,12 +402,6 @@ def _main(out_stream):
                 return ks_out
             n_prof = max(args.steps, 100)  # (untimed pass: enough samples per launch even with the driver's short windows)
             kernels = stamped_pass(n_prof)
-            # The same loop with p2g and g2p as the two launches of rounds 1-5 (host-side switch, results unchanged): their own durations
-            # -- the north star quotes the g2p gather alone -- beside the merged launch the timed loop runs
-            if any(k["phase"] == "p2g_g2p" for k in kernels):
-                sv._call("mpmhip_set_debug_flags", 32)
-                out["kernels_unmerged"] = [k for k in stamped_pass(n_prof) if k["phase"] in ("p2g", "g2p_v", "compute_stress_from_F_trial")]
-                sv._call("mpmhip_set_debug_flags", 0)
             out["kernels"], out["kernels_mode"], out["kernels_note"] = kernels, "fused-loop", FUSED_BYTES_NOTE
             # the whole substep against the roofline: algorithmic bytes of all phases / wall time of the timed loop, and the same
             # with the PMC traffic of the three launches (the ~0.2 GB working set sits in the 256 MiB Infinity Cache: "fraction of

@@ -115,7 +115,6 @@ typedef struct {
                                    with an interval too long for their speed) and the results are not valid */
   int64_t g2p2g_launches;       /* fast mode, scenes of traditional particles only: substep boundaries that ran as ONE launch
                                    (g2p of substep n + stress and p2g of substep n + 1, csrc/g2p.hip k_g2p2g) */
-  int64_t merged_launches;      /* fast mode, cloth scenes: substeps whose p2g and g2p ran as ONE launch (k_p2g_g2p, csrc/p2g.hip) */
   int32_t p2g_tile_in_use;      /* fast mode: the accumulator p2g's chunk tile runs on NOW -- MPMHIP_P2G_TILE_FIXED or MPMHIP_P2G_TILE_F64
                                    (what MPMHIP_P2G_TILE_AUTO resolved to at the last import; 0 in baseline mode) */
   int32_t reserved_;

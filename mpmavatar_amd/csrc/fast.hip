@@ -194,7 +194,6 @@ int fast_init(mpmhip_ctx *c) {
   if (const char *e = getenv("MPMHIP_P2G_TILE")) { f->p2g_fixed = std::string(e) != "f64"; f->p2g_fixed_forced = std::string(e) == "fx"; }
   f->p2g_fixed_now = f->p2g_fixed;
   if (const char *e = getenv("MPMHIP_G2P2G")) f->g2p2g = atoi(e) != 0;
-  if (const char *e = getenv("MPMHIP_MERGE_PG")) f->merge_pg = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_SPLIT_SPLAT")) f->split_splat = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_SPLIT_SPLAT_MAX")) f->split_splat_max_chunks = atoi(e);
   if (const char *e = getenv("MPMHIP_G2P2G_MAX")) f->g2p2g_max_chunks = atoi(e);
@@ -226,7 +225,6 @@ int fast_init(mpmhip_ctx *c) {
   if ((rc = dalloc(c, &f->g.vout, f->nblocks * GCH_VOUT * 64))) return rc;
   if ((rc = dalloc(c, &f->g.counters, CNT_N))) return rc;
   if ((rc = dalloc(c, &f->pack_done, (size_t)DONE_SHARDS * DONE_STRIDE))) return rc;
-  if ((rc = dalloc(c, &f->gate_mem, (size_t)GATE_WORDS))) return rc;
   // one allocation, one memset per re-sort: [particle-block flags | active-block flags | device counts]
   static_assert(RC_N <= 64, "device counts of a re-sort");
   f->fc_tiles = (int)((f->nblocks + FC_TILE - 1) / FC_TILE);
@@ -240,7 +238,7 @@ int fast_init(mpmhip_ctx *c) {
   if ((rc = dalloc(c, &f->pb_index, f->nblocks))) return rc;
   if ((rc = dalloc(c, &f->ab_index, f->nblocks))) return rc;
   f->g.ab_flag = f->ab_flag;
-  if (const char *e = getenv("MPMHIP_DBG")) f->g.dbg = MPMHIP_DEBUG ? (int)strtoul(e, nullptr, 0) : ((int)strtoul(e, nullptr, 0) & (64 | 32));
+  if (const char *e = getenv("MPMHIP_DBG")) f->g.dbg = MPMHIP_DEBUG ? (int)strtoul(e, nullptr, 0) : ((int)strtoul(e, nullptr, 0) & 64);
   if (const char *e = getenv("MPMHIP_FUSE_GRID")) f->fuse_grid = atoi(e) != 0;
   f->g2p_two_pass = cfg.n_particles - cfg.n_elements - cfg.n_vertices == 0;
   if (const char *e = getenv("MPMHIP_G2P_TWO_PASS")) f->g2p_two_pass = atoi(e) != 0;
@@ -574,20 +572,6 @@ int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     launch_g2p2g(c, grid, dt, rd, sa, tp, f->pend_gp, f->pend_bcl);
     f->g2p_pending = false;
     f->n_g2p2g += 1;
-  } else if (f->merge_pg && f->fuse_grid && !c->profiling && !f->dist && !f->g.halo.slot && !f->g2p_mflag && f->g2p_two_pass && d.n_e > 0 && d.n_v > 0 &&
-             d.n_t == 0 && !trad_fused && !jt_tile && !sa.pack.n_wg && f->n_chunks > 0 && f->n_chunks_g > 0 && !(f->g.dbg & 32) && !(MPMHIP_DEBUG && (f->g.dbg || f->g.trace))) {
-    // cloth scenes of the production loop: this substep's g2p rides in the p2g launch behind the phase gate (PhaseGate, fast_device.hpp).
-    // Its grid-stage parameters are those step_phase_b would compute (nothing between the two changes what they are taken from).
-    GridParams gp;
-    BCList bcl;
-    grid_stage_params(c, a, gp, bcl);
-    const int p_end = sa.n_extra + (int)xcd_grid(f->n_chunks);   // a multiple of GATE_SHARDS: n_extra of 8, xcd_grid of 128
-    sa.z_first = 1 << 30;                                        // (the clearing workgroups follow the gather workgroups in this launch)
-    sa.gate = PhaseGate{f->gate_mem, f->gate_shard += (unsigned)(p_end / GATE_SHARDS), f->gate_master += (unsigned)GATE_SHARDS, ++f->gate_epoch, 1};
-    ScopedPhase ph(c, "p2g_g2p");
-    launch_p2g_g2p(c, f->n_chunks, dt, sa, tp, gp, bcl);
-    f->g2p_merged = true;
-    f->n_merged += 1;
   } else {
     ScopedPhase ph(c, "p2g");
     if (f->n_chunks || sa.n_extra || sa.z.n_wg || sa.pack.n_wg)
@@ -631,8 +615,6 @@ int step_phase_b(mpmhip_ctx *c, const StepArgs &a) {
   if (fused && g2p2g_ok(c)) {  // G2P2G: the next substep's launch does this g2p in front of its p2g (or flush_g2p does)
     f->g2p_pending = true;
     f->pend_gp = gp; f->pend_bcl = bcl; f->pend_dt = dt;
-  } else if (f->g2p_merged) {
-    f->g2p_merged = false;   // (went out with the p2g launch of this substep: step_phase_a)
   } else {
     ScopedPhase ph(c, "g2p_v");
     if (f->n_chunks_g) launch_g2p(c, fused, f->g2p_two_pass, dt, gp, bcl);
@@ -700,9 +682,8 @@ int fast_export_grid(mpmhip_ctx *c, float *m, float *v_in, float *v_out) {
 }
 
 int fast_set_debug_flags(mpmhip_ctx *c, int flags) {
-  // bit 64 (stand-alone element finalize every substep) and bit 32 (p2g and g2p as two launches instead of k_p2g_g2p) are host-side
-  // switches, exist in every build and leave the results right
-  if (!MPMHIP_DEBUG && (flags & ~(64 | 32)))
+  // bit 64 (stand-alone element finalize every substep; results stay right) is a host-side switch and exists in every build
+  if (!MPMHIP_DEBUG && (flags & ~64))
     return fail(c, MPMHIP_ERR_INVALID, "set_debug_flags: this build carries no kernel ablation switches (build a variant with "
                                        "-DMPMHIP_DEBUG=1, tools/build_variants.py, and select it with MPMHIP_LIB)");
   c->fast->g.dbg = flags;
@@ -743,7 +724,6 @@ int fast_stats(mpmhip_ctx *c, mpmhip_stats *out) {
   flush_g2p(c);  // (a pending g2p counts its out-of-margin particles too)
   out->rebins = f->rebins;
   out->g2p2g_launches = f->n_g2p2g;
-  out->merged_launches = f->n_merged;
   out->p2g_tile_in_use = f->p2g_fixed_now ? MPMHIP_P2G_TILE_FIXED : MPMHIP_P2G_TILE_F64;
   out->n_active_blocks = f->n_A;
   int *dcnt = f->g.counters + 4;

@@ -321,26 +321,12 @@ __device__ __forceinline__ void raise_face(int *counters, int step_id) {
   counters[CNT_PAR0 + 2 * (step_id & 1)] = 1;
 }
 
-// a grid value produced during THIS launch (INL) or before it
-template <bool INL>
-__device__ __forceinline__ float grid_ld(const float *p) {
-#ifdef PG_PLAIN
-  return *p;
-#else
-  return INL ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-#endif
-}
-template <bool INL>
-__device__ __forceinline__ int grid_ldi(const int *p) {
-  return INL ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-
 // One node of the grid stage.  ZERO = true consumes the accumulators (re-zeroes what it read); ZERO = false only reads
 // them (g2p evaluates nodes on the fly while it stages its tile, k_zero_blocks / the zeroing workgroups of the next
 // stress launch clear them afterwards).  Returns the node's v_out; m_out = accumulated mass.
 // (the four accumulator values come in as arguments so that a caller can have issued their loads earlier: g2p does,
 // together with its particle loads, to take one dependent memory level out of the head of every workgroup)
-template <bool ZERO, bool INL = false>
+template <bool ZERO>
 __device__ __forceinline__ V3 node_finish(int blk, int l, float m, float px, float py, float pz, const Dims &d, const GridPtrs &g,
                                           const GridParams &gp, const BCList &bcl, int &ncol, int &nmov, bool use_col,
                                           unsigned bc_mask, const float *rem_mov = nullptr) {
@@ -352,10 +338,9 @@ __device__ __forceinline__ V3 node_finish(int blk, int l, float m, float px, flo
   if (gp.damping < 1.0f) v = v - (1.0f - gp.damping) * v;
   if (gp.has_col && use_col) {  // normalize_grid + collide, mpm_solver.py:882-917
     float *pc = g.col + ((size_t)blk * GCH_COL) * 64 + l;
-    float wc = grid_ld<INL>(pc);
+    float wc = pc[0];
     if (wc != 0.0f) {
-      V3 vin = v3(grid_ld<INL>(pc + 64), grid_ld<INL>(pc + 128), grid_ld<INL>(pc + 192)),
-         nrm = v3(grid_ld<INL>(pc + 256), grid_ld<INL>(pc + 320), grid_ld<INL>(pc + 384));
+      V3 vin = v3(pc[64], pc[128], pc[192]), nrm = v3(pc[256], pc[320], pc[384]);
       if (wc > 1e-15f) {
         V3 vm = (1.0f / wc) * vin;
         v = collide_node(v, vm, nrm, gp.col_friction);
@@ -367,10 +352,10 @@ __device__ __forceinline__ V3 node_finish(int blk, int l, float m, float px, flo
   }
   if (gp.has_mov && gp.mov_on) {
     float *pv = g.mov + ((size_t)blk * GCH_MOV) * 64 + l;
-    float wv = grid_ld<INL>(pv), mx = 0.0f, my = 0.0f, mz = 0.0f;
+    float wv = pv[0], mx = 0.0f, my = 0.0f, mz = 0.0f;
     if (rem_mov) { wv += rem_mov[0]; mx = rem_mov[64]; my = rem_mov[128]; mz = rem_mov[192]; }  // the neighbour rank's share
     if (wv != 0.0f) {
-      if (wv > 1e-15f) { v = (1.0f / wv) * v3(grid_ld<INL>(pv + 64) + mx, grid_ld<INL>(pv + 128) + my, grid_ld<INL>(pv + 192) + mz); nmov = 1; }
+      if (wv > 1e-15f) { v = (1.0f / wv) * v3(pv[64] + mx, pv[128] + my, pv[192] + mz); nmov = 1; }
       if (ZERO) { pv[0] = 0.0f; pv[64] = 0.0f; pv[128] = 0.0f; pv[192] = 0.0f; }
     }
   }
@@ -652,52 +637,6 @@ __device__ __forceinline__ void pack_wait(const PackArgs &pk, int *err) {
     }
   }
   __syncthreads();
-}
-// ---- phase gate: p2g and g2p of a substep in ONE launch (round 6) -------------------------------------------------------------------
-// The g2p chunk workgroups ride in the p2g launch, behind the scattering workgroups.  Workgroups of one launch are dispatched in order
-// of their id (per XCD: id % 8), so when a g2p workgroup gets a slot every scattering workgroup of its XCD has been dispatched -- is
-// resident or done -- and waiting for them cannot deadlock (the argument of PackArgs above).  What this buys: the kernel boundary
-// between the two (the cheapest grid-wide synchronisation there is: 2.9-4.1 us) becomes a flag, and the tail of the scatter -- the last
-// of 2.1 rounds of workgroups, a quarter of the slots busy for 5 us (profiles/r03_wg_timeline.md) -- is filled with the heads of the
-// gather workgroups (chunk record -> positions: 2.5 us of latency they would otherwise pay after the boundary).
-// Producer (every workgroup in front of the gather ones): its atomics acknowledged (s_waitcnt vmcnt(0); the accumulators are only
-// ever touched by device-scope atomics, performed at the memory side), then one returning add on one of GATE_SHARDS counters; the
-// workgroup that completes a shard bumps the master count, the one that completes the master count stores the epoch into the flag.
-// Consumer: every wavefront reads the flag word WITH its chunk record (one request, one address).  Already at the epoch -- the rule
-// from the second round of gather workgroups on -- and nothing changes: accumulators and positions are requested together, no
-// dependent memory level is added.  Not yet: positions first, then the wavefront polls, then the accumulators.  Accumulators, collider
-// and mover channels and the collider flags are read with agent-scope loads in this form (nothing may come from this XCD's L2: the
-// values were produced at the memory side during this launch).
-constexpr int GATE_SHARDS = 8, GATE_STRIDE = 16, GATE_MASTER = GATE_SHARDS * GATE_STRIDE, GATE_FLAG = GATE_MASTER + GATE_STRIDE,
-              GATE_WORDS = GATE_FLAG + GATE_STRIDE;
-struct PhaseGate {
-  unsigned *mem;                  // [GATE_WORDS]: shard counters, master counter, flag (64 bytes apart)
-  unsigned shard_target, master_target, epoch;
-  int on;
-};
-__device__ __forceinline__ void gate_arrive(const PhaseGate &pg) {
-  if (!pg.on) return;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned old = __hip_atomic_fetch_add(pg.mem + (blockIdx.x & (GATE_SHARDS - 1)) * GATE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1u == pg.shard_target) {
-      unsigned m = __hip_atomic_fetch_add(pg.mem + GATE_MASTER, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (m + 1u == pg.master_target) __hip_atomic_store(pg.mem + GATE_FLAG, pg.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-__device__ __forceinline__ unsigned gate_peek(const PhaseGate &pg) {  // (issued with the chunk record; the value decides later)
-  return __hip_atomic_load(pg.mem + GATE_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool gate_open(const PhaseGate &pg, unsigned flag) { return (int)(flag - pg.epoch) >= 0; }
-__device__ __forceinline__ void gate_wait(const PhaseGate &pg, int *err) {  // per wavefront; wall-clock bound like the peer links
-  long long t0 = wall_clock64();
-  while (!gate_open(pg, __hip_atomic_load(pg.mem + GATE_FLAG, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT))) {
-    __builtin_amdgcn_s_sleep(8);
-    if (wall_clock64() - t0 > LINK_TIMEOUT_TICKS) { *err = 1; break; }
-  }
-  asm volatile("" ::: "memory");
 }
 // one lane waits for a peer's flag (g2p's out-of-margin path; the tile path waits per workgroup, link_wait)
 __device__ __forceinline__ void link_wait_lane(const int *flag, int seq, int *err) {

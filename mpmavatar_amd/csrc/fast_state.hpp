@@ -211,11 +211,6 @@ struct FastState {
   int par = 0, nbuf = 2;
   // G2P2G: the g2p of the last substep has not been launched yet -- the next substep's launch does it in front of its own p2g
   // (k_g2p2g), or flush_g2p() does with a plain k_g2p when anything else needs the particles first
-  // p2g + g2p of a cloth substep as ONE launch behind a phase gate (round 6; PhaseGate in fast_device.hpp, k_p2g_g2p in p2g.hip)
-  bool merge_pg = true;        // MPMHIP_MERGE_PG=0: the two launches of rounds 1-5
-  bool g2p_merged = false;     // this substep's g2p went out with its p2g launch (step_phase_b has no launch then)
-  unsigned *gate_mem = nullptr, gate_shard = 0, gate_master = 0, gate_epoch = 0;
-  int64_t n_merged = 0;        // substeps that ran the merged launch (statistics)
   bool g2p2g = true;           // MPMHIP_G2P2G=0: two launches per substep for traditional-only scenes as before
   int g2p2g_max_chunks = 512;  // MPMHIP_G2P2G_MAX
   int stagger_auto = 2;        // p2g first-round stagger units for chunk lists of at least two rounds; -1: forced by MPMHIP_P2G_STAGGER
@@ -257,15 +252,7 @@ inline void kstamp_launch(mpmhip_ctx *c, K kernel, unsigned grid, unsigned block
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, c->stream, args...);
   }
 }
-template <class K, class... A>
-inline void kstamp_launch_lds(mpmhip_ctx *c, K kernel, unsigned grid, unsigned block, unsigned lds_bytes, A &&...args) {  // ... with dynamic shared memory
-  if (c->prof_fused) {
-    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds_bytes, c->stream, c->kev0, c->kev1, 0, args...);
-    c->kev_pending = true;
-  } else {
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds_bytes, c->stream, args...);
-  }
-}
+
 
 // ---- functions shared by the translation units of the fast back end ------------------------------------------------------
 // resort.hip
@@ -288,7 +275,6 @@ int step_phase_b(mpmhip_ctx *c, const StepArgs &a);
 int step_phase_c(mpmhip_ctx *c, const StepArgs &a);
 // p2g.hip / g2p.hip: the only places that name the template instantiations of the substep's kernels
 void launch_p2g(mpmhip_ctx *c, bool trad, bool jt, unsigned grid, int n_chunks, float dt, const SplatArgs &sa, const TradParams &tp);
-void launch_p2g_g2p(mpmhip_ctx *c, int n_chunks, float dt, const SplatArgs &sa, const TradParams &tp, const GridParams &gp, const BCList &bcl);
 void launch_stress_elem(mpmhip_ctx *c, int mode, const SplatArgs &sa);
 void launch_stress_trad(mpmhip_ctx *c, float dt);
 void launch_g2p(mpmhip_ctx *c, bool fused, bool two, float dt, const GridParams &gp, const BCList &bcl);

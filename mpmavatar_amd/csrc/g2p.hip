@@ -74,14 +74,3 @@ void launch_g2p2g(mpmhip_ctx *c, unsigned grid, float dt, const GridRead &rd, co
 }
 
 }  // namespace mpm
-#ifdef PG_PROBE
-namespace mpm { namespace {
-template <bool INL>
-__global__ __launch_bounds__(PT) void k_probe(const ChunkRec *recs, int n_chunks, Bufs b, Dims d, float dt, GridPtrs g, GridParams gp, BCList bcl, PhaseGate pg) {
-  __shared__ float4 tile[TILE_PAD];
-  g2p_body<true, true, false, false, false, INL>(recs, n_chunks, b, d, dt, g, gp, bcl, tile, (int)blockIdx.x, pg);
-}
-template __global__ void k_probe<true>(const ChunkRec *, int, Bufs, Dims, float, GridPtrs, GridParams, BCList, PhaseGate);
-template __global__ void k_probe<false>(const ChunkRec *, int, Bufs, Dims, float, GridPtrs, GridParams, BCList, PhaseGate);
-} }
-#endif

@@ -178,7 +178,7 @@ __device__ __forceinline__ V3 g2p_gather_grad_d3(const float4 *tile, int ox, int
 
 // same sums for a particle that drifted out of its tile margin: rolled loop over the global grid (zero outside
 // active blocks); kept small so that it does not set the kernel's register budget
-template <bool FUSED, bool HALO = false, bool INL = false>
+template <bool FUSED, bool HALO = false>
 __device__ __forceinline__ G2PResult g2p_gather_global(V3 x, const Dims &d, const GridPtrs &g, const GridParams &gp,
                                                        const BCList &bcl) {
   Stencil s = make_stencil(x, d.inv_dx);
@@ -205,11 +205,6 @@ __device__ __forceinline__ G2PResult g2p_gather_global(V3 x, const Dims &d, cons
             rem_mov = halo_add_node(g.halo, hs, l_, m, px, py, pz);
           }
           u = node_finish<false>(blk, l_, m, px, py, pz, d, g, gp, bcl, nc, nm, true, 0xffffffffu, rem_mov);
-        } else if (FUSED && INL) {
-          int nc = 0, nm = 0, l_ = loc_of(x_, y_, z_);
-          const float *pm = g.mv + ((size_t)blk * GCH_MV) * 64 + l_;
-          float m = grid_ld<true>(pm), px = grid_ld<true>(pm + 64), py = grid_ld<true>(pm + 128), pz = grid_ld<true>(pm + 192);
-          u = node_finish<false, true>(blk, l_, m, px, py, pz, d, g, gp, bcl, nc, nm, true, 0xffffffffu);
         } else if (FUSED) {
           float m;
           int nc = 0, nm = 0;
@@ -274,13 +269,9 @@ __device__ __forceinline__ void g2p_write(const Bufs &b, int cls, int s, V3 x, V
 // level less at the head of every workgroup for more L2 traffic; node values are identical (an unflagged block holds zeros).
 // HALO = true (multi-GPU, needs MFLAG = false): blocks shared with a neighbour rank get its contribution added on the way
 // (HaloIn), after the workgroup has seen the neighbour's flag for this substep.
-// INL = true (needs FUSED, MFLAG = false, no HALO): the workgroup runs in the SAME launch as the scatter of this substep, behind its
-// phase gate (PhaseGate, fast_device.hpp).
-template <bool FUSED, bool TWO_PASS, bool MFLAG, bool HALO = false, bool B128 = false, bool INL = false>
+template <bool FUSED, bool TWO_PASS, bool MFLAG, bool HALO = false, bool B128 = false>
 __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, const Bufs &b, const Dims &d, float dt, const GridPtrs &g,
-                                         const GridParams &gp, const BCList &bcl, float4 *tile, int wg,
-                                         const PhaseGate &gate = PhaseGate{nullptr, 0u, 0u, 0u, 0}) {
-  static_assert(!INL || (FUSED && !MFLAG && !HALO), "the in-launch gather is the fused, flag-free, single-GPU form");
+                                         const GridParams &gp, const BCList &bcl, float4 *tile, int wg) {
   WGT(g, 1, 0);
   // The front of a g2p workgroup is a chain of memory latencies (record -> positions + accumulators -> grid stage): few
   // instructions, long waits.  Its wavefronts get issue priority over wavefronts that are in the VALU / LDS-bound sweeps of another
@@ -290,8 +281,6 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
   __builtin_amdgcn_s_setprio(3);
   int w = xcd_slice(wg, n_chunks);
   if (w < 0) return;
-  unsigned gate_flag = 0;
-  if (INL) gate_flag = gate_peek(gate);  // (one request beside the chunk record's: is the scatter of this substep complete?)
   const ChunkRec cm = recs[w];
   // (the whole record with the first request: LLVM sinks the load of a field into the branch of map() that uses it, and e0 -- the
   // common case -- arrived one dependent memory level after the rest; the empty asm uses the three range starts here)
@@ -311,14 +300,6 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
     x = ld3(b.all, A_X, sx_);
     d3 = v3(b.el.at(E_D + 2, se), b.el.at(E_D + 5, se), b.el.at(E_D + 8, se));
   }
-  if (INL) {
-    // the scatter still running (first round of gather workgroups only): wait here, with the positions on their way; otherwise -- the
-    // flag arrived with the chunk record -- fall through and request the accumulators in the same burst as the positions
-    gate_flag = (unsigned)__builtin_amdgcn_readfirstlane((int)gate_flag);
-#ifndef PG_NOWAIT
-    if (!gate_open(gate, gate_flag)) gate_wait(gate, g.counters + 1);
-#endif  // (a wait that ran into its bound counts as a dropped contribution: results invalid)
-  }
   constexpr int NPT = TILE3 / PT;  // tile nodes per thread
   int nbk[NPT], nlk[NPT], hsl[NPT];
   float am[NPT], apx[NPT], apy[NPT], apz[NPT];
@@ -334,7 +315,7 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
     if (FUSED && !MFLAG) {  // (all 27 overlapped blocks of a particle block are on the active list: cleared or loaded;
                             // a node outside the grid reads this block's instead -- no branch around the loads -- and drops it)
       const float *pm = g.mv + ((size_t)(in ? nbk[u] : blk) * GCH_MV) * 64 + nlk[u];
-      float a0 = grid_ld<INL>(pm), a1 = grid_ld<INL>(pm + 64), a2 = grid_ld<INL>(pm + 128), a3 = grid_ld<INL>(pm + 192);
+      float a0 = pm[0], a1 = pm[64], a2 = pm[128], a3 = pm[192];
       am[u] = in ? a0 : 0.0f; apx[u] = in ? a1 : 0.0f; apy[u] = in ? a2 : 0.0f; apz[u] = in ? a3 : 0.0f;
     }
     hsl[u] = -1;
@@ -350,7 +331,7 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
       int nx = bx + l / 9 - 1, ny = by + (l / 3) % 3 - 1, nz = bz + l % 3 - 1;
       if ((unsigned)nx < (unsigned)d.NB && (unsigned)ny < (unsigned)d.NB && (unsigned)nz < (unsigned)d.NB) {
         if (MFLAG) fm = g.m_flag[(nx * d.NB + ny) * d.NB + nz];
-        if (gp.has_col) fl = grid_ldi<INL>(g.col_flag + (nx * d.NB + ny) * d.NB + nz);
+        if (gp.has_col) fl = g.col_flag[(nx * d.NB + ny) * d.NB + nz];
       }
     }
     if (gp.has_col) col_mask = __ballot(fl != 0);
@@ -388,7 +369,7 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
         if (!MFLAG) {
           const float *rem_mov = nullptr;
           if (HALO && hsl[u] >= 0) rem_mov = halo_add_node(g.halo, hsl[u], nl, am[u], apx[u], apy[u], apz[u]);
-          v = node_finish<false, INL>(nb, nl, am[u], apx[u], apy[u], apz[u], d, g, gp, bcl, nc, nm, uc, bc_mask, rem_mov);
+          v = node_finish<false>(nb, nl, am[u], apx[u], apy[u], apz[u], d, g, gp, bcl, nc, nm, uc, bc_mask, rem_mov);
         } else if ((m_mask >> nidx) & 1ull) {
           float m;
           v = node_update<false>(nb, nl, d, g, gp, bcl, m, nc, nm, uc, bc_mask);
@@ -444,7 +425,7 @@ __device__ __forceinline__ void g2p_body(const ChunkRec *recs, int n_chunks, con
   if (__any(escaped)) {
     asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(s), "+v"(cls), "+v"(d3.x), "+v"(d3.y), "+v"(d3.z));
     if (escaped) {
-      G2PResult r = g2p_gather_global<FUSED, HALO, INL>(x, d, g, gp, bcl);
+      G2PResult r = g2p_gather_global<FUSED, HALO>(x, d, g, gp, bcl);
       g2p_write(b, cls, s, x, d3, r, ox, oy, oz, d, dt, g);
       atomicAdd(g.counters + 0, 1);
     }

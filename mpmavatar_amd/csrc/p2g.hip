@@ -53,67 +53,6 @@ __global__ __launch_bounds__(PT) void k_p2g(const ChunkRec *recs, int n_chunks, 
   __shared__ float red[8];
   p2g_body<STEPS, TRAD, JT, FX>(recs, n_chunks, b, va, d, rpic, dt, g, sa, tp, tile, esc, esc_n, red, (int)blockIdx.x);
 }
-
-// p2g AND g2p of a cloth substep in one launch (PhaseGate, fast_device.hpp): workgroups [0, p_end) are k_p2g's splat and chunk
-// workgroups, [p_end, p_end + g_grid) the gather workgroups of k_g2p<true, true, false> behind the gate, the rest clear the other
-// accumulator buffer (they fill the gather's tail as they filled the scatter's).
-constexpr unsigned PG_LDS_BYTES = P2G_TILE_DOUBLES * sizeof(double) + CHUNK * sizeof(int) + 8 * sizeof(float) + 16;
-struct G2PTail {
-  const ChunkRec *recs;   // the g2p chunk list (== the p2g list on one GPU)
-  int n_chunks, p_end, g_grid;
-};
-// The kernel's arguments as ONE record: the scatter half is a function of its own (noinline: register allocation and the
-// scheduler's occupancy target are per FUNCTION, and inlined beside the gather half -- 96 VGPRs by itself -- the pair compiles to
-// 126-129, four wavefronts per SIMD) and reads what it needs through the kernel-argument segment pointer.
-struct PGArgs {
-  const ChunkRec *recs;
-  int n_chunks;
-  Bufs b;
-  VAdj va;
-  Dims d;
-  float rpic, dt;
-  GridPtrs g;
-  SplatArgs sa;
-  TradParams tp;
-  GridParams gp;
-  BCList bcl;
-  G2PTail gt;
-};
-template <int STEPS, bool FX, bool B128>
-__device__ __forceinline__ void pg_kernel_body() {
-  // The arguments are read THROUGH THE KERNEL-ARGUMENT SEGMENT POINTER, where they are used, instead of as by-value parameters: those
-  // are all loaded into SGPRs at the kernel's entry, for both halves at once, and ~110 of them end up spilled into VGPR lanes.  A
-  // scalar that is read from constant memory can be loaded again instead of being kept (6 spilled SGPRs).
-  const PGArgs &A = *reinterpret_cast<const PGArgs *>(__builtin_amdgcn_kernarg_segment_ptr());
-  // DYNAMIC shared memory (PG_LDS_BYTES at the launch): with the 31 KB declared statically hipcc takes the launch for LDS-bound at low
-  // occupancy and schedules the gather half for 120-126 VGPRs -- the same code under a 12 KB tile compiles to 96
-  extern __shared__ __attribute__((aligned(16))) double pg_lds[];
-  const int bid = (int)blockIdx.x;
-  if (bid < A.gt.p_end) {
-    double *tile = pg_lds;
-    int *esc = reinterpret_cast<int *>(pg_lds + P2G_TILE_DOUBLES);
-    float *red = reinterpret_cast<float *>(esc + CHUNK);
-    int &esc_n = *reinterpret_cast<int *>(red + 8);
-    p2g_body<STEPS, false, false, FX, false>(A.recs, A.n_chunks, A.b, A.va, A.d, A.rpic, A.dt, A.g, A.sa, A.tp, tile, esc, esc_n, red, bid);
-  } else if (bid < A.gt.p_end + A.gt.g_grid) {
-    g2p_body<true, true, false, false, B128, true>(A.gt.recs, A.gt.n_chunks, A.b, A.d, A.dt, A.g, A.gp, A.bcl, reinterpret_cast<float4 *>(pg_lds), bid - A.gt.p_end, A.sa.gate);
-  } else {
-    zero_blocks_wg(A.sa.z, bid - (A.gt.p_end + A.gt.g_grid));
-  }
-}
-// Two halves that compile to 89 and 95 VGPRs by themselves come out at 125 together: the scheduler's occupancy target is per function,
-// drops to four wavefronts per SIMD while it works on the scatter nest and is not raised again for the gather sweeps.  The attribute
-// pins it at five: the two hot regions are instruction for instruction those of k_p2g / k_g2p (tools/isa_mix.py), ten dwords of the
-// small-bin splat's face data go through scratch.
-#ifndef PG_WAVES
-#define PG_WAVES __attribute__((amdgpu_waves_per_eu(5, 5)))
-#endif
-template <int STEPS, bool FX>
-__global__ __launch_bounds__(PT) PG_WAVES void k_p2g_g2p(PGArgs by_value) { pg_kernel_body<STEPS, FX, false>(); }
-// chunk lists of at most one round of workgroups: the gather reads its tile with ds_read_b128 (see launch_g2p) and occupancy is not
-// what bounds the launch -- no pin
-template <int STEPS, bool FX>
-__global__ __launch_bounds__(PT) void k_p2g_g2p_wide(PGArgs by_value) { pg_kernel_body<STEPS, FX, true>(); }
 }  // namespace
 
 // ---- launchers of the substep's kernels (the only places that name their template instantiations) -------------------------
@@ -133,22 +72,6 @@ void launch_p2g(mpmhip_ctx *c, bool trad, bool jt, unsigned grid, int n_chunks, 
   else if (trad) kstamp_launch(c, k_p2g<P2G_STEPS, true, false, true>, P2G_ARGS);
   else kstamp_launch(c, k_p2g<P2G_STEPS, false, false, true>, P2G_ARGS);
 #undef P2G_ARGS
-}
-// the cloth form of p2g + the fused two-sweep g2p as ONE launch; sa.z_first must be out of range (the clearing workgroups come last here)
-void launch_p2g_g2p(mpmhip_ctx *c, int n_chunks, float dt, const SplatArgs &sa, const TradParams &tp, const GridParams &gp, const BCList &bcl) {
-  FastState *f = c->fast;
-  const Dims &d = f->d;
-  const Bufs &b = f->buf[f->cur];
-  const float rpic = c->sc.rpic_damping;
-  G2PTail gt{f->chunks_g, f->n_chunks_g, sa.n_extra + (int)xcd_grid(n_chunks), (int)xcd_grid(f->n_chunks_g)};
-  const unsigned grid = (unsigned)(gt.p_end + gt.g_grid + sa.z.n_wg);
-  const bool wide = f->n_chunks_g <= 1280;  // (ds_read_b128 in the sweeps where a launch is at most one round: see launch_g2p)
-  const PGArgs A{f->chunks, n_chunks, b, f->va(), d, rpic, dt, f->g, sa, tp, gp, bcl, gt};
-  if (!f->p2g_fixed_now) {
-    if (wide) kstamp_launch_lds(c, k_p2g_g2p_wide<3, false>, grid, PT, PG_LDS_BYTES, A);
-    else kstamp_launch_lds(c, k_p2g_g2p<3, false>, grid, PT, PG_LDS_BYTES, A);
-  } else if (wide) kstamp_launch_lds(c, k_p2g_g2p_wide<P2G_STEPS, true>, grid, PT, PG_LDS_BYTES, A);
-  else kstamp_launch_lds(c, k_p2g_g2p<P2G_STEPS, true>, grid, PT, PG_LDS_BYTES, A);
 }
 // compute_stress_from_F_trial of the elements: mode 0 = from the stored directors (first substep after an import), 1 = with the
 // element finalize of the substep before fused in, 2 = the same with the collider splat's first pass in front (sa.n_fbins workgroups)

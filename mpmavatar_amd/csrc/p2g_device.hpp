@@ -87,7 +87,6 @@ struct SplatArgs {
   ZeroArgs z;              // workgroups [z_first, z_first + z.n_wg), after the chunk workgroups: clear the other
   int z_first;             // accumulator buffer
   PackArgs pack;           // workgroups [pack.first, ...) after those: multi-GPU halo pack (see PackArgs)
-  PhaseGate gate;          // p2g + g2p in one launch: every workgroup in front of z_first arrives here when its atomics are out
 };
 
 // PASS 0: weight + weight*velocity (collider channels 0..3), PASS 1: weight*normal (channels 4..6); both passes use
@@ -854,9 +853,7 @@ __device__ __forceinline__ void col_splat_wg(double *tile, const SplatArgs &sa, 
 // JT = true: the mover holds MANY traditional particles (run_demo.py keeps 100k sand particles frozen for the first
 // frames); their joint splat (weight, weight * joint velocity into the mover channels, mpm_solver.py:677-704) is a
 // second pass through the same LDS tile by the chunk that owns them instead of 27 x 4 scattered global atomics each.
-// TAIL = false (k_p2g_g2p): the launch's clearing workgroups are not this function's business and there is no halo pack: neither the
-// branch nor its arguments (PackArgs: 75 SGPRs of tables) exist in the kernel
-template <int STEPS, bool TRAD, bool JT, bool FX, bool TAIL = true>
+template <int STEPS, bool TRAD, bool JT, bool FX>
 __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, const Bufs &b, const VAdj &va, const Dims &d, float rpic,
                                          float dt, const GridPtrs &g, const SplatArgs &sa, const TradParams &tp, double *tile, int *esc,
                                          int &esc_n, float *red, int bid) {
@@ -888,10 +885,10 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
     }
     else if (e < sa.n_fbins + sa.n_mov_wg) { if (!DBG(g, 16384)) mover_splat_wg(b, sa.js, e - sa.n_fbins, d, g); }
     WGT(g, 0, 6);
-    if (TAIL) wg_done(sa.pack); gate_arrive(sa.gate);
+    wg_done(sa.pack);
     return;
   }
-  if (TAIL && bid >= sa.z_first) {  // ... and the clearing workgroups last: they fill the tail of the launch
+  if (bid >= sa.z_first) {  // ... and the clearing workgroups last: they fill the tail of the launch
     if (sa.pack.n_wg && bid >= sa.pack.first) {  // (multi-GPU) halo pack, once everything in front has scattered
       pack_wait(sa.pack, g.counters + 10);
       halo_pack_wg<true>(sa.pack.tb, g, bid - sa.pack.first);
@@ -902,7 +899,7 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
     return;
   }
   int w = xcd_slice(bid - (sa.e0 == 0 ? sa.n_extra : 0), n_chunks);
-  if (w < 0) { if (TAIL) wg_done(sa.pack); gate_arrive(sa.gate); return; }
+  if (w < 0) { wg_done(sa.pack); return; }
   if (g.stagger > 0 && bid < g.stagger_first) {
     // The workgroups of the first round all start within a microsecond, load together and then scatter together: memory
     // system and VALU / LDS pipelines take turns idling, and a first-round workgroup lives 12.4 us against 9.0 us for one
@@ -995,7 +992,7 @@ __device__ __forceinline__ void p2g_body(const ChunkRec *recs, int n_chunks, con
       p2g_flush<false, true, false>(tile, ox, oy, oz, d, g, FxScale{1.0f, 1.0f, 1.0f, 1.0f});
     }
   }
-  if (TAIL) wg_done(sa.pack); gate_arrive(sa.gate);
+  wg_done(sa.pack);
 }
 }  // namespace fk
 }  // namespace mpm

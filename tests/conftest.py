@@ -15,7 +15,7 @@ def pytest_configure(config):
 # Order of the suite under `-x`: what proves parity with the reference runs FIRST -- the fixtures generated from
 # the imported reference, then the oracle comparisons, then the full-size statements -- and what measures (bench contract, soak)
 # runs LAST, so that nothing about timing or the box can keep a parity test from being reached.
-_ORDER = ["test_gpu_ref_golden", "test_gpu_parity", "test_gpu_golden", "test_gpu_merged", "test_gpu_edges", "test_gpu_api", "test_gpu_sort",
+_ORDER = ["test_gpu_ref_golden", "test_gpu_parity", "test_gpu_golden", "test_gpu_edges", "test_gpu_api", "test_gpu_sort",
           "test_gpu_g2p2g", "test_gpu_branch_flips", "test_gpu_mass_ratio", "test_gpu_fuzz", "test_frames", "test_render_inputs",
           "test_io_formats", "test_gpu_fd", "test_dist", "test_gpu_fullsize"]
 _LAST = ["test_c_abi_demo", "test_gpu_soak", "test_bench_contract"]
