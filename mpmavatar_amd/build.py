@@ -59,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-def build_variant(name: str, flags, every: bool = False) -> str:
+def build_variant(name: str, flags, every: bool = False, only=None) -> str:
     """Another build of the same sources with extra compiler flags, in lib/variants/libmpmhip_<name>.so (selected at run time with
     MPMHIP_LIB=<path>; the default library is untouched).  every = False compiles only the fast back end (FAST_SOURCES) with the flags.  Used for the
     contraction-free witness build (tests/test_gpu_ref_golden.py) and for kernel A/B experiments (tools/build_variants.py)."""
@@ -69,7 +69,7 @@ def build_variant(name: str, flags, every: bool = False) -> str:
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     for src in SOURCES:
-        if src not in FAST_SOURCES and not every:
+        if (src not in FAST_SOURCES and not every) or (only is not None and src not in only):   # only: the flags go to these sources alone
             objs.append(os.path.join(OBJDIR, src.replace(".hip", ".o")))
             continue
         obj = os.path.join(vdir, f"{src[:-4]}_{name}.o")

@@ -21,7 +21,8 @@ def one(spec):
     name, _, defs = spec.partition(":")
     defs = [d for d in defs.split(",") if d]
     every = "ALL" in defs  # name:ALL,-flag,...  compiles every source with the flags (later flags override build.py's)
-    return B.build_variant(name, [d for d in defs if d != "ALL"], every)
+    only = [d[5:] for d in defs if d.startswith("ONLY=")] or None   # name:ONLY=p2g.hip,-flag  the flags go to that source alone
+    return B.build_variant(name, [d for d in defs if d != "ALL" and not d.startswith("ONLY=")], every, only)
 
 
 if __name__ == "__main__":
