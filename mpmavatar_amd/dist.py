@@ -5,10 +5,12 @@ Decomposition
   * ownership: vertices and traditional particles are assigned to ranks by the quantile slab of their x coordinate at
     the last (re-)partition, an element to the owner of its first vertex.  Between re-partitions ownership is fixed (the
     ghost lists below are built once per partition; particles that wander into a neighbour's slab only widen the halo).
-    MIGRATION: ``maybe_repartition`` (called at the start of every ``run``) counts the owned particles that have left
-    their slab and, when more than ``migrate_fraction`` of them have, gathers the state of all ranks, cuts new slabs at the
-    current positions and rebuilds every rank's shard -- a stop-the-world step that costs about as much as the
-    initial build and is needed every few thousand substeps at most.
+    MIGRATION: ownership is a matter of performance, not of correctness -- any two ranks exchange whatever blocks they share -- and a
+    body that only MOVES (a garment walking across the slabs) keeps its halo.  ``maybe_repartition`` (called at the start of every
+    ``run``) therefore asks first whether the halo has GROWN since the partition was cut (``migrate_halo_factor``, one all-reduce) and
+    only then whether more than ``migrate_fraction`` of the owned particles have left their slab; if both, it gathers the state of all
+    ranks, cuts new slabs at the current positions and rebuilds every rank's shard -- a stop-the-world step that costs about as much
+    as the initial build and is needed only when material mixes across a cut (poured sand).
   * ghosts: a rank also holds (a) every element that touches one of its vertices (so vertex forces are complete
     without an exchange) and (b) every vertex of its local elements.  Ghost copies carry particle_selection == 2:
     stress / element finalise run on them, p2g / g2p do not.
@@ -187,7 +189,13 @@ class ShardedSim:
     keep: list = field(default_factory=list)
     static: dict = field(default_factory=dict)
     global_scene: Scene = None         # the unsharded scene this shard was cut from (positions as of the last partition)
-    migrate_fraction: float = 0.10     # re-partition when more than this fraction of the particles left their slab (0: never)
+    migrate_fraction: float = 0.10     # re-partition when more than this fraction of the particles left their slab (0: never) ...
+    migrate_halo_factor: float = 1.5   # ... AND the halo -- the bytes a rank sends per substep -- has grown by this factor since the
+                                       # partition was cut (0: do not ask).  A body that MOVES keeps its halo: a garment walking across
+                                       # the slabs, a cube thrown along x leave "their" slabs entirely without a single block more to
+                                       # exchange, and ownership is a matter of performance only (any two ranks exchange whatever blocks
+                                       # they share); only material that MIXES across the cut (poured sand) makes the halo grow
+    halo_ref: int = 0                  # max over the ranks of the halo bytes per substep right after the partition's first re-sort
     migrate_check_every: int = 512     # ... looked at every this many substeps (one device-side count + one all-reduce)
     migrate_checked_at: int = 0
     migrate_warned: bool = False
@@ -411,6 +419,22 @@ def slab_leavers(ss: "ShardedSim") -> float:
     return float(t[0] / max(float(t[1]), 1.0))
 
 
+def halo_bytes_max(ss: "ShardedSim") -> int:
+    """Collective: max over the ranks of the bytes a rank sends per substep in the halo exchange (shared blocks x channels x 256 B),
+    as of the last collective re-sort."""
+    import torch
+    import torch.distributed as dist
+    if ss.transport == "rccl":
+        hb = C.c_int64(0)
+        ss.sim.solver._call("mpmhip_dist_halo_bytes", C.byref(hb))
+        mine = int(hb.value)
+    else:
+        mine = 4 * sum(int(p["n_halo"]) for p in ss.peers)
+    t = torch.tensor([mine], dtype=torch.int64, device="cpu" if ss.backend == "gloo" else ss.sim.solver.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
 def repartition(ss: "ShardedSim") -> "ShardedSim":
     """Collective: new slabs at the particles' CURRENT positions; every rank rebuilds its shard and continues the same run
     (state, solver time and substep count carried over).  The ShardedSim is updated IN PLACE (and returned): a caller that
@@ -426,6 +450,7 @@ def repartition(ss: "ShardedSim") -> "ShardedSim":
     new_sc = replace(sc, x=carry["particle_x"], v=carry["particle_v"], d=carry["particle_d"])
     dev = str(ss.sim.solver.device)
     keep = dict(steps_done=ss.steps_done, resorts=ss.resorts, migrate_fraction=ss.migrate_fraction, migrations=ss.migrations + 1,
+                migrate_halo_factor=ss.migrate_halo_factor, halo_ref=0,
                 migrate_check_every=ss.migrate_check_every, migrate_checked_at=ss.migrate_checked_at)
     rank, world, rebin_interval = ss.shard.rank, ss.shard.world, ss.rebin_interval
     old = ss.sim
@@ -472,10 +497,21 @@ def maybe_repartition(ss: "ShardedSim") -> "ShardedSim":
                   "the start)", file=sys.stderr, flush=True)
         ss.migrate_warned = True
         return ss
+    # (1) has the halo grown?  One int64 all-reduce; the reference value is taken at the first look after a (re-)partition
+    halo = halo_bytes_max(ss)
+    if ss.halo_ref <= 0:
+        ss.halo_ref = max(halo, 1)
+    grown = ss.migrate_halo_factor <= 0 or halo > ss.migrate_halo_factor * ss.halo_ref
+    if not grown:
+        if os.environ.get("MPMHIP_VERBOSE"):
+            print(f"[mpmavatar_amd.dist] rank {ss.shard.rank}: substep {ss.steps_done}: halo {halo} B per substep (x{halo / ss.halo_ref:.2f} of "
+                  f"the partition's {ss.halo_ref} B): slabs stay", flush=True)
+        return ss
+    # (2) ... and is it because particles left their slabs (new cuts at the current positions would help)?
     frac = slab_leavers(ss)
     if os.environ.get("MPMHIP_VERBOSE"):
-        print(f"[mpmavatar_amd.dist] rank {ss.shard.rank}: substep {ss.steps_done}: {100 * frac:.1f} % of the particles are outside "
-              f"their owner's slab" + (" -> re-partition" if frac > ss.migrate_fraction else ""), flush=True)
+        print(f"[mpmavatar_amd.dist] rank {ss.shard.rank}: substep {ss.steps_done}: halo x{halo / ss.halo_ref:.2f}, {100 * frac:.1f} % of the "
+              f"particles are outside their owner's slab" + (" -> re-partition" if frac > ss.migrate_fraction else ""), flush=True)
     return repartition(ss) if frac > ss.migrate_fraction else ss
 
 

@@ -144,6 +144,7 @@ def main():
             dist.destroy_process_group()
             sys.exit(0 if flag.item() == 1 else 1)
         ss.migrate_fraction = float(os.environ.get("MPMHIP_TEST_MIGRATE", "0"))
+        ss.migrate_halo_factor = float(os.environ.get("MPMHIP_TEST_HALO_FACTOR", "0"))   # 0: the slab criterion alone (forces the re-partition path)
         chunk = int(os.environ.get("MPMHIP_TEST_RUN_CHUNK", str(steps)))
         ss.migrate_check_every = 1  # look at every run() call (production: every 512 substeps)
         held = ss
@@ -153,7 +154,8 @@ def main():
         if os.environ.get("MPMHIP_DIST_TRANSPORT") == "rccl" and (torch.cuda.device_count() >= world or os.environ.get("MPMHIP_RCCL_LIB")):
             ok &= ss.transport == "rccl"   # the test asked for the in-library loop: falling back silently is a failure
         if float(os.environ.get("MPMHIP_TEST_MIGRATE", "0")) > 0:
-            print(f"dist[{scene_name}] rank {rank}: {ss.migrations} re-partitions", flush=True)
+            print(f"dist[{scene_name}] rank {rank}: {ss.migrations} re-partitions, {100 * mdist.slab_leavers(ss):.0f} % outside their slab, "
+                  f"halo x{mdist.halo_bytes_max(ss) / max(ss.halo_ref, 1):.2f}", flush=True)
         # every collective of the driver once more, whatever the world size: with the NCCL backend a tensor on the wrong
         # device fails here, on the one-GPU box, and not first on a multi-GPU node
         frac = mdist.slab_leavers(ss)

@@ -245,6 +245,25 @@ def test_in_library_loop_migration_over_the_stand_in():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["torch", "rccl"])
+def test_a_body_that_only_moves_is_not_re_partitioned(transport):
+    """the reference's drivers move the body -- and the garment with it -- for hundreds of frames, and round 5
+    re-partitioned (stop-the-world, ~1 s) whenever 10 % of the particles had left the x-slab they were cut by.  Ownership is a matter
+    of performance only; what costs is the halo, and a cube thrown along x carries its cut with it: with the production criterion
+    (halo grown by 1.5 x AND 10 % of the particles outside their slab) it crosses the slab boundary entirely -- most of its particles
+    outside "their" slab -- without one re-partition, without one more byte of halo, on the single context's trajectory."""
+    import re
+    env = {"MPMHIP_TEST_MIGRATE": "0.1", "MPMHIP_TEST_HALO_FACTOR": "1.5", "MPMHIP_TEST_RUN_CHUNK": "30"}
+    if transport == "rccl":
+        env.update(_mock_rccl_env())
+    out = _launch(2, "gpu", "crossing", 150, extra_env=env)
+    assert "max rel dx" in out
+    m = re.findall(r"rank \d+: (\d+) re-partitions, (\d+) % outside their slab, halo x([0-9.]+)", out)
+    assert len(m) == 2, out[-2000:]
+    assert all(int(n) == 0 for n, _, _ in m) and all(int(fr) >= 10 for _, fr, _ in m) and all(float(h) < 1.5 for _, _, h in m), m
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("bad", [0, 2])
 def test_a_rank_whose_local_build_fails_takes_every_rank_out_cleanly(bad):
     """ADVICE r4: build_sharded votes on the local part of the build BEFORE its first collective.  Rank `bad` fails there (injected);
