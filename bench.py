@@ -442,7 +442,7 @@ def _main(out_stream):
         n_act = st["n_active_nodes"]
         ne_o = int(owned[:lsc.n_elements].sum()) if owned is not None else lsc.n_elements
         nv_o = int(owned[lsc.n_elements + lsc.n_traditional:].sum()) if owned is not None else lsc.n_vertices
-        nt_o = lsc.n_traditional
+        nt_o = int(ss.shard.own_t.size)          # (the local traditional class also holds the free rows of the migration slack)
         rank_bytes = {"compute_stress_from_F_trial": (188 + 60) * lsc.n_elements + 12 * lsc.n_vertices,   # ghosts run the stress update too
                       "p2g": 100 * ne_o + 76 * nv_o + 220 * nt_o + 16 * n_act,
                       "g2p_v": 168 * lsc.n_elements + 72 * lsc.n_vertices + 144 * nt_o + 40 * n_act}       # ghosts gather for themselves
@@ -482,7 +482,8 @@ def _main(out_stream):
         out["exchange"] = {"transport": box["ss"].transport, "halo": halo, "halo_bytes_per_substep_sent_by_rank0": halo_bytes,
                            "channels_per_node": ch, "peers_of_rank0": len(box["ss"].static) - 1,
                            "halo_exchange_us": next((k["ms"] * 1e3 for k in kernels if k["phase"] == "halo_exchange"), None),
-                           "re_partitions": box["ss"].migrations}
+                           "re_partitions": box["ss"].migrations, "on_device_migrations": box["ss"].trad_migrations,
+                           "particles_migrated_on_device": box["ss"].trad_migrated}
     mark("kernel events")
     if sharded and world > 1 and not args.no_shard_floor:
         # What this N can reach at best: rank 0 runs ITS shard (owned particles + ghost copies) as an ordinary single-GPU scene, no

@@ -59,9 +59,16 @@ class Shard:
     send_p_gid: Dict[int, np.ndarray] = field(default_factory=dict)  # the same lists as global ids (tests)
     recv_p_gid: Dict[int, np.ndarray] = field(default_factory=dict)
     cuts: np.ndarray = None           # the world-1 slab boundaries (x) of this partition
+    t_gid: np.ndarray = None          # local traditional row -> global traditional id, -1 = free row (slack for on-device migration);
+                                      # free rows first, owned rows behind them in ascending id order (own_t = t_gid[t_gid >= 0])
 
 
 _TEST_FAIL_BUILD_RANK = None   # test hook (tests/dist_worker.py sets it): the rank whose local build raises; never read from the environment
+
+
+# Free rows a rank's traditional class is built with (fraction of its owned particles, at least TRAD_SLACK_MIN): what on-device
+# migration moves particles INTO.  Free rows carry particle_selection = 1 (never simulated, sorted behind everything, no chunk).
+TRAD_SLACK, TRAD_SLACK_MIN = 0.25, 256
 
 
 CUT_BINS = 1 << 14   # histogram resolution of the device-side quantile cut: grid_lim / 16384 (1/64 cell at 256^3)
@@ -89,15 +96,26 @@ def device_cuts(ss: "ShardedSim") -> np.ndarray:
     import torch
     import torch.distributed as dist
     sh = ss.shard
-    x = ss.sim.state.particle_x.detach()[:, 0]
-    ne_l = sh.own_e.size + sh.ghost_e.size
-    xs = x[ne_l:ne_l + sh.own_t.size + sh.own_v.size].float()
+    xs = _owned_movable_x(ss).float()
     lim = float(ss.global_scene.grid_lim)
     h = torch.histc(xs, bins=CUT_BINS, min=0.0, max=lim) if xs.numel() else torch.zeros(CUT_BINS, device=x.device)
     h = h.to(torch.int64)
     h = h.cpu() if ss.backend == "gloo" else h
     dist.all_reduce(h)
     return cuts_from_histogram(h.cpu().numpy(), sh.world, lim)
+
+
+def _owned_movable_x(ss: "ShardedSim"):
+    """x of the traditional particles and vertices this rank OWNS (device tensor): traditional rows by their global-id table (free
+    rows of the migration slack excluded), then the owned vertices (the first own_v rows of the vertex class)."""
+    import torch
+    sh = ss.shard
+    x = ss.sim.state.particle_x.detach()[:, 0]
+    ne_l = sh.own_e.size + sh.ghost_e.size
+    nt_l = sh.t_gid.size
+    own_rows = torch.as_tensor(np.nonzero(sh.t_gid >= 0)[0], device=x.device, dtype=torch.int64)
+    xt = x[ne_l:ne_l + nt_l][own_rows] if nt_l else x[:0]
+    return torch.cat([xt, x[ne_l + nt_l:ne_l + nt_l + sh.own_v.size]])
 
 
 def _owners(sc: Scene, world: int, cuts=None):
@@ -112,9 +130,10 @@ def _owners(sc: Scene, world: int, cuts=None):
     return owner_e, owner_t, owner_v, np.asarray(cuts, np.float64)
 
 
-def partition(sc: Scene, world: int, cuts=None) -> List[Shard]:
+def partition(sc: Scene, world: int, cuts=None, slack: bool = True) -> List[Shard]:
     """Deterministic: every rank computes the full partition from the same Scene, no communication.  cuts: slab boundaries to use
-    (re-partition: device_cuts()); None = the world-quantiles of the vertices' and traditional particles' x."""
+    (re-partition: device_cuts()); None = the world-quantiles of the vertices' and traditional particles' x.  slack: scenes with
+    traditional particles get free rows in every rank's traditional class (TRAD_SLACK) for on-device migration."""
     n_e, n_t, n_v = sc.n_elements, sc.n_traditional, sc.n_vertices
     owner_e, owner_t, owner_v, cuts = _owners(sc, world, cuts)
     faces = sc.faces.astype(np.int64)
@@ -129,29 +148,35 @@ def partition(sc: Scene, world: int, cuts=None) -> List[Shard]:
         ghost_v = need_v[owner_v[need_v] != r]
         vl = np.concatenate([own_v, ghost_v])
         own_t = np.nonzero(owner_t == r)[0]
+        n_free = (int(TRAD_SLACK * own_t.size) + TRAD_SLACK_MIN) if (slack and world > 1 and n_t > 0 and sc.joint_t_hold >= 0) else 0
+        # local traditional rows: free rows first (a copy of some valid particle, never simulated), the owned ones behind them in
+        # ascending id order -- the mover's "last n traditional particles" (run_demo.py:524) stays a suffix of the owned ones
+        t_src = np.concatenate([np.full(n_free, own_t[0] if own_t.size else 0, np.int64), own_t])
+        t_gid = np.concatenate([np.full(n_free, -1, np.int64), own_t.astype(np.int64)])
         g2l = np.full(n_v, -1, np.int64)
         g2l[vl] = np.arange(vl.size)
         f_loc = g2l[faces[el]].astype(np.int32) if el.size else np.zeros((0, 3), np.int32)
         assert (f_loc >= 0).all()
-        x = np.concatenate([sc.x[el], sc.x[n_e + own_t], sc.x[n_e + n_t + vl]], 0)
-        v = np.concatenate([sc.v[el], sc.v[n_e + own_t], sc.v[n_e + n_t + vl]], 0)
-        vol = np.concatenate([sc.vol[el], sc.vol[n_e + own_t], sc.vol[n_e + n_t + vl]], 0)
+        x = np.concatenate([sc.x[el], sc.x[n_e + t_src], sc.x[n_e + n_t + vl]], 0)
+        v = np.concatenate([sc.v[el], sc.v[n_e + t_src], sc.v[n_e + n_t + vl]], 0)
+        vol = np.concatenate([sc.vol[el], sc.vol[n_e + t_src], sc.vol[n_e + n_t + vl]], 0)
         sel = np.zeros(x.shape[0], np.int32)
         sel[own_e.size:el.size] = 2
-        sel[el.size + own_t.size + own_v.size:] = 2
+        sel[el.size:el.size + n_free] = 1
+        sel[el.size + t_src.size + own_v.size:] = 2
         njv = int((own_v < sc.num_joint_v).sum())
         njf = int((own_e < sc.num_joint_f).sum())
         jv = None if sc.joint_verts_v is None else sc.joint_verts_v[own_v[:njv]]
         jf = None if sc.joint_faces_v is None else sc.joint_faces_v[own_e[:njf]]
-        local = replace(sc, name=f"{sc.name}[{r}/{world}]", n_elements=int(el.size), n_traditional=int(own_t.size),
+        local = replace(sc, name=f"{sc.name}[{r}/{world}]", n_elements=int(el.size), n_traditional=int(t_src.size),
                         n_vertices=int(vl.size), x=np.ascontiguousarray(x, np.float32), v=np.ascontiguousarray(v, np.float32),
                         vol=np.ascontiguousarray(vol, np.float32), faces=f_loc, d=sc.d[el], R_inv=sc.R_inv[el],
                         num_joint_v=njv, num_joint_f=njf, joint_verts_v=jv, joint_faces_v=jf, selection=sel, joint_t_hold=0,
                         has_mover=(sc.num_joint_v > 0 or sc.num_joint_f > 0) if sc.has_mover is None else sc.has_mover)
-        shards.append(Shard(r, world, local, own_e, ghost_e, own_t, own_v, ghost_v, cuts=cuts))
+        shards.append(Shard(r, world, local, own_e, ghost_e, own_t, own_v, ghost_v, cuts=cuts, t_gid=t_gid))
     # ghost exchange lists, ordered by global id on both sides
     for r, sh in enumerate(shards):
-        off_v = sh.scene.n_elements + sh.scene.n_traditional
+        off_v = sh.scene.n_elements + sh.scene.n_traditional   # (traditional class incl. its free rows)
         lv = {g: i for i, g in enumerate(np.concatenate([sh.own_v, sh.ghost_v]))}
         le = {g: i for i, g in enumerate(np.concatenate([sh.own_e, sh.ghost_e]))}
         for q, other in enumerate(shards):
@@ -200,6 +225,10 @@ class ShardedSim:
     migrate_checked_at: int = 0
     migrate_warned: bool = False
     migrations: int = 0
+    migrate_trad_fraction: float = 0.01   # on-device migration of traditional particles when at least this fraction of them lies in
+                                          # another rank's slab of the CURRENT quantile cuts (0: at every check; < 0: never)
+    trad_migrations: int = 0              # on-device migration events / particles moved by them
+    trad_migrated: int = 0
     mass_version: tuple = ()           # (data_ptr, version counter) of state.particle_mass when the ranks last agreed on the scene's mass span
 
 
@@ -319,14 +348,15 @@ def local_to_global_rows(shard: Shard, sc: Scene):
     all-particle arrays (x, v, C, model arrays) and for the element+traditional ones (F, F_trial, stress)."""
     ne_g, nt_g = sc.n_elements, sc.n_traditional
     ne_l = shard.own_e.size + shard.ghost_e.size
-    nt_l = shard.own_t.size
+    nt_l = shard.t_gid.size                                  # local traditional rows incl. free ones
+    t_loc = np.nonzero(shard.t_gid >= 0)[0]                  # ... the owned ones among them
     rows_e = np.arange(shard.own_e.size)
-    rows_t = ne_l + np.arange(nt_l)
+    rows_t = ne_l + t_loc
     rows_v = ne_l + nt_l + np.arange(shard.own_v.size)
     all_rows = np.concatenate([rows_e, rows_t, rows_v])
-    all_ids = np.concatenate([shard.own_e, ne_g + shard.own_t, ne_g + nt_g + shard.own_v])
+    all_ids = np.concatenate([shard.own_e, ne_g + shard.t_gid[t_loc], ne_g + nt_g + shard.own_v])
     nv_rows = np.concatenate([rows_e, rows_t])
-    nv_ids = np.concatenate([shard.own_e, ne_g + shard.own_t])
+    nv_ids = np.concatenate([shard.own_e, ne_g + shard.t_gid[t_loc]])
     return all_rows, all_ids, nv_rows, nv_ids
 
 
@@ -384,8 +414,9 @@ def _apply_carry(sim, shard: Shard, sc: Scene, carry: dict):
     ne_g, nt_g = sc.n_elements, sc.n_traditional
     el = np.concatenate([shard.own_e, shard.ghost_e])
     vl = np.concatenate([shard.own_v, shard.ghost_v])
-    all_ids = np.concatenate([el, ne_g + shard.own_t, ne_g + nt_g + vl])
-    nv_ids = np.concatenate([el, ne_g + shard.own_t])
+    t_ids = np.where(shard.t_gid >= 0, shard.t_gid, shard.own_t[0] if shard.own_t.size else 0)   # (free rows: any valid particle's state)
+    all_ids = np.concatenate([el, ne_g + t_ids, ne_g + nt_g + vl])
+    nv_ids = np.concatenate([el, ne_g + t_ids])
     dev = st.particle_x.device
     put = lambda dst, a: dst.copy_(torch.as_tensor(np.ascontiguousarray(a, np.float32), device=dev).reshape(dst.shape)) if dst.numel() else None
     for f in ("particle_C", "particle_mass"):
@@ -403,10 +434,8 @@ def slab_leavers(ss: "ShardedSim") -> float:
     import torch
     import torch.distributed as dist
     sh = ss.shard
-    x = ss.sim.state.particle_x.detach()[:, 0]
-    ne_l = sh.own_e.size + sh.ghost_e.size
-    n_own = sh.own_t.size + sh.own_v.size            # owned traditional particles, then owned vertices, contiguous rows
-    xs = x[ne_l:ne_l + n_own]
+    xs = _owned_movable_x(ss)
+    n_own = sh.own_t.size + sh.own_v.size
     lo = -np.inf if sh.rank == 0 else float(sh.cuts[sh.rank - 1])
     hi = np.inf if sh.rank == sh.world - 1 else float(sh.cuts[sh.rank])
     out = ((xs < lo) | (xs >= hi)).sum().to(torch.float64)
@@ -435,6 +464,117 @@ def halo_bytes_max(ss: "ShardedSim") -> int:
     return int(t.item())
 
 
+# --------------------------------------------------------------------------------------------- on-device migration (traditional particles)
+_MIG_STATE = (("particle_x", 3), ("particle_v", 3), ("particle_C", 9), ("particle_F", 9), ("particle_F_trial", 9), ("particle_stress", 9),
+              ("particle_vol", 1), ("particle_mass", 1), ("particle_density", 1))
+_MIG_MODEL = ("E", "nu", "mu", "lam", "gamma", "kappa", "yield_stress")
+MIG_RECORD_FLOATS = sum(w for _, w in _MIG_STATE) + len(_MIG_MODEL)   # 52 floats = 208 B per migrating particle (+ its 8-byte global id)
+
+
+def _mig_tensors(ss: "ShardedSim"):
+    """The per-particle float tensors a traditional particle's record is made of, each as a [local traditional rows, width] VIEW of the
+    caller-order tensor the solver is bound to."""
+    st, md, sh = ss.sim.state, ss.sim.model, ss.shard
+    ne_l, nt_l = sh.own_e.size + sh.ghost_e.size, sh.t_gid.size
+    out = []
+    for name, w in _MIG_STATE:
+        out.append(st._raw(name).detach().reshape(-1, w)[ne_l:ne_l + nt_l])
+    for name in _MIG_MODEL:
+        out.append(md._raw(name).detach().reshape(-1, 1)[ne_l:ne_l + nt_l])
+    return out
+
+
+def migrate_traditional(ss: "ShardedSim", min_fraction: float = 0.0) -> int:
+    """Collective, ON THE DEVICE: new slab boundaries at the current positions (device_cuts: quantiles of a histogram summed over the
+    ranks, so a body that only moves takes its cuts with it and nothing migrates), and every owned traditional particle that now lies in
+    another rank's slab goes there -- its record (52 floats + global id) through ONE all-to-all of device tensors, into a free row of the
+    destination's traditional class (TRAD_SLACK) -- and leaves a free row behind.  No state goes through the host, no context is
+    rebuilt; what the host learns is one histogram, a world x world table of counts and the new id table of its own rows.  The
+    traditional block is left sorted (free rows first, owned rows by ascending global id): the mover's "last n particles" rule
+    (run_demo.py:524) keeps holding per rank.  Elements and vertices are not touched (cloth ownership follows the mesh, not the slab;
+    see maybe_repartition).
+    Returns the number of particles that changed rank (all ranks: the same number); 0 when fewer than min_fraction of the traditional
+    particles would move; -1 when some rank has too few free rows (nothing is changed then: the caller falls back to repartition())."""
+    import torch
+    import torch.distributed as dist
+    sh, sim = ss.shard, ss.sim
+    sc = ss.global_scene
+    world, rank = sh.world, sh.rank
+    if world == 1 or sc.n_traditional == 0 or sh.t_gid is None:
+        return 0
+    sv, st = sim.solver, sim.state
+    dev = st._raw("particle_x").device
+    host = ss.backend == "gloo"
+    sv._call("mpmhip_pull_state")                       # the caller-order tensors are the solver's state now (one export kernel)
+    cuts_np = device_cuts(ss)                           # (collective) quantile cuts of the owned vertices + traditional particles
+    cuts = torch.as_tensor(cuts_np, dtype=torch.float32, device=dev)
+    gid = torch.as_tensor(sh.t_gid, dtype=torch.int64, device=dev)
+    owned = gid >= 0
+    fields = _mig_tensors(ss)
+    x = fields[0][:, 0]
+    dest = torch.bucketize(x.contiguous(), cuts, right=True)       # = np.searchsorted(cuts, x, side="right"), the rule of _owners()
+    move = owned & (dest != rank)
+    out_counts = torch.bincount(dest[move], minlength=world).to(torch.int64)
+    table = [torch.zeros(world, dtype=torch.int64, device="cpu" if host else dev) for _ in range(world)]
+    dist.all_gather(table, out_counts.cpu() if host else out_counts)
+    table = torch.stack(table).cpu().numpy()            # table[src][dst]
+    n_moving = int(table.sum())
+    n_in = int(table[:, rank].sum())
+    n_free = int((~owned).sum().item())
+    ok = torch.tensor([1 if n_in <= n_free + int(table[rank].sum()) else 0], dtype=torch.int32, device="cpu" if host else dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if n_moving == 0 or n_moving < min_fraction * sc.n_traditional:
+        return 0
+    if int(ok.item()) != 1:
+        return -1
+    # records of the leavers, grouped by destination (stable: ascending row inside a group)
+    idx = torch.nonzero(move).reshape(-1)
+    idx = idx[torch.sort(dest[idx], stable=True).indices]
+    rec = torch.cat([f[idx] for f in fields], dim=1).contiguous()
+    rec_id = gid[idx].contiguous()
+    out_split = [int(c) for c in table[rank]]
+    in_split = [int(c) for c in table[:, rank]]
+    rec_in = torch.empty((n_in, MIG_RECORD_FLOATS), dtype=torch.float32, device=dev)
+    id_in = torch.empty(n_in, dtype=torch.int64, device=dev)
+    if host:   # gloo: staged through host memory like every other exchange of the test backend
+        ro, io = list(rec.cpu().split(out_split)), list(rec_id.cpu().split(out_split))
+        ri, ii = [torch.empty((c, MIG_RECORD_FLOATS)) for c in in_split], [torch.empty(c, dtype=torch.int64) for c in in_split]
+        dist.all_to_all(ri, ro)
+        dist.all_to_all(ii, io)
+        rec_in, id_in = torch.cat(ri).to(dev), torch.cat(ii).to(dev)
+    else:
+        dist.all_to_all_single(rec_in, rec, in_split, out_split)
+        dist.all_to_all_single(id_in, rec_id, in_split, out_split)
+    # leavers free their rows, arrivals take free rows (the leavers' included)
+    gid[idx] = -1
+    free_rows = torch.nonzero(gid < 0).reshape(-1)[:n_in]
+    off = 0
+    for f in fields:
+        w = f.shape[1]
+        f[free_rows] = rec_in[:, off:off + w]
+        off += w
+    gid[free_rows] = id_in
+    # sorted layout: free rows first, owned rows by ascending global id
+    order = torch.sort(gid, stable=True).indices
+    for f in fields:
+        f.copy_(f[order])
+    gid = gid[order]
+    ne_l = sh.own_e.size + sh.ghost_e.size
+    sel = st._raw("particle_selection")
+    sel[ne_l:ne_l + gid.numel()] = (gid < 0).to(sel.dtype)      # 1: free row (never simulated), 0: owned
+    sh.t_gid = gid.cpu().numpy()
+    sh.own_t = sh.t_gid[sh.t_gid >= 0]
+    sh.cuts = np.asarray(cuts_np, np.float64)
+    st._touch()
+    sim.model._touch()
+    sv._call("mpmhip_push_state")                       # the caller-order tensors are newer than the solver's sorted copy: re-import at the
+    ss.sorted_once = False                              # collective re-sort that the next substep starts with
+    ss.mass_version = ()                                # (masses moved with their particles: the ranks agree on the span again)
+    ss.trad_migrated += n_moving
+    ss.trad_migrations += 1
+    return n_moving
+
+
 def repartition(ss: "ShardedSim") -> "ShardedSim":
     """Collective: new slabs at the particles' CURRENT positions; every rank rebuilds its shard and continues the same run
     (state, solver time and substep count carried over).  The ShardedSim is updated IN PLACE (and returned): a caller that
@@ -450,7 +590,8 @@ def repartition(ss: "ShardedSim") -> "ShardedSim":
     new_sc = replace(sc, x=carry["particle_x"], v=carry["particle_v"], d=carry["particle_d"])
     dev = str(ss.sim.solver.device)
     keep = dict(steps_done=ss.steps_done, resorts=ss.resorts, migrate_fraction=ss.migrate_fraction, migrations=ss.migrations + 1,
-                migrate_halo_factor=ss.migrate_halo_factor, halo_ref=0,
+                migrate_halo_factor=ss.migrate_halo_factor, halo_ref=0, migrate_trad_fraction=ss.migrate_trad_fraction,
+                trad_migrations=ss.trad_migrations, trad_migrated=ss.trad_migrated,
                 migrate_check_every=ss.migrate_check_every, migrate_checked_at=ss.migrate_checked_at)
     rank, world, rebin_interval = ss.shard.rank, ss.shard.world, ss.rebin_interval
     old = ss.sim
@@ -485,7 +626,7 @@ def repartition(ss: "ShardedSim") -> "ShardedSim":
 def maybe_repartition(ss: "ShardedSim") -> "ShardedSim":
     import os
     import sys
-    if ss.migrate_fraction <= 0 or ss.shard.world == 1 or ss.steps_done == 0:
+    if (ss.migrate_fraction <= 0 and ss.migrate_trad_fraction < 0) or ss.shard.world == 1 or ss.steps_done == 0:
         return ss
     if ss.steps_done - ss.migrate_checked_at < ss.migrate_check_every:
         return ss
@@ -496,6 +637,18 @@ def maybe_repartition(ss: "ShardedSim") -> "ShardedSim":
             print("[mpmavatar_amd.dist] scene has a moving velocity cuboid: particle migration is skipped (slabs stay as cut at "
                   "the start)", file=sys.stderr, flush=True)
         ss.migrate_warned = True
+        return ss
+    # (0) traditional particles that have mixed across the cuts change rank ON THE DEVICE (migrate_traditional): cheap enough to do at
+    # every look, and what it does not fix (too few free rows; cloth folded across a cut) is left to the halo criterion below
+    if ss.migrate_trad_fraction >= 0 and ss.global_scene.n_traditional > 0:
+        moved = migrate_traditional(ss, ss.migrate_trad_fraction)
+        if os.environ.get("MPMHIP_VERBOSE"):
+            print(f"[mpmavatar_amd.dist] rank {ss.shard.rank}: substep {ss.steps_done}: on-device migration of traditional particles: "
+                  + ("too few free rows on some rank" if moved < 0 else f"{moved} changed rank"), flush=True)
+        if moved > 0:
+            ss.halo_ref = 0          # (new slabs: the halo reference is taken again at the next look)
+            return ss
+    if ss.migrate_fraction <= 0:
         return ss
     # (1) has the halo grown?  One int64 all-reduce; the reference value is taken at the first look after a (re-)partition
     halo = halo_bytes_max(ss)
@@ -697,7 +850,7 @@ def run(ss: ShardedSim, n_steps: int):
         return min(n, f0 + spf - step)
     jt_buf = None
     if ss.global_scene.joint_t_hold > 0:
-        jt_buf = torch.zeros((max(ss.shard.own_t.size, 1), 3), dtype=torch.float32, device=sv.device)
+        jt_buf = torch.zeros((max(ss.shard.t_gid.size, 1), 3), dtype=torch.float32, device=sv.device)
         ss.keep_jt = jt_buf
     if ss.transport == "rccl":
         jvp = None if jv is None else (dp(jv) or dummy)
@@ -755,5 +908,6 @@ def gather_positions(ss: ShardedSim):
     st, sh, sc = ss.sim.state, ss.shard, ss.sim.scene
     x = st.particle_x.detach().cpu().numpy()
     ne, nt = sc.n_elements, sc.n_traditional
-    return dict(e_id=sh.own_e, e_x=x[:sh.own_e.size], t_id=sh.own_t, t_x=x[ne:ne + sh.own_t.size],
+    t_loc = np.nonzero(sh.t_gid >= 0)[0]
+    return dict(e_id=sh.own_e, e_x=x[:sh.own_e.size], t_id=sh.t_gid[t_loc], t_x=x[ne + t_loc],
                 v_id=sh.own_v, v_x=x[ne + nt:ne + nt + sh.own_v.size])

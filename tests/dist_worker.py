@@ -36,6 +36,17 @@ def _crossing_cube():
     return sc
 
 
+def _shear_cube():
+    """A cube sheared along x (top +12 m/s, bottom -12 m/s): material MIXES across the cut between the slabs -- what on-device migration
+    of traditional particles is for (a cube that only moves takes its quantile cuts with it and nothing migrates)."""
+    sc = scenes.small_cube()
+    nt0 = sc.n_elements
+    y = sc.x[nt0:nt0 + sc.n_traditional, 1]
+    sc.v = sc.v.copy()
+    sc.v[nt0:nt0 + sc.n_traditional, 0] += (12.0 * (y - y.mean()) / (y.max() - y.min())).astype(np.float32)
+    return sc
+
+
 def _sway_garment():
     """The small garment on a body that is posed anew every 20 substeps (Scene.mesh_sway: a new velocity per frame, joints
     riding on it), like the captured motion of train_material_params.py:617-622."""
@@ -59,7 +70,7 @@ def _registry(name):
     return lambda: scenes.REGISTRY[name]()
 
 
-SCENES = {"sheet-500k": _registry("sheet-500k"), "widesheet8": _wide_sheet8, "widesheet": _wide_sheet, "crossing": _crossing_cube, "sway": _sway_garment, "demohold": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=(10, 5, 64)),
+SCENES = {"shear": _shear_cube, "sheet-500k": _registry("sheet-500k"), "widesheet8": _wide_sheet8, "widesheet": _wide_sheet, "crossing": _crossing_cube, "sway": _sway_garment, "demohold": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=(10, 5, 64)),
           "garment": scenes.small_garment, "sheet": scenes.small_sheet, "cube": scenes.small_cube, "fastcube": _fast_cube,
           "demo": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=False)}
 
@@ -145,6 +156,7 @@ def main():
             sys.exit(0 if flag.item() == 1 else 1)
         ss.migrate_fraction = float(os.environ.get("MPMHIP_TEST_MIGRATE", "0"))
         ss.migrate_halo_factor = float(os.environ.get("MPMHIP_TEST_HALO_FACTOR", "0"))   # 0: the slab criterion alone (forces the re-partition path)
+        ss.migrate_trad_fraction = float(os.environ.get("MPMHIP_TEST_TRAD_MIG", "-1"))     # on-device migration: off unless the test asks (0: at every look)
         chunk = int(os.environ.get("MPMHIP_TEST_RUN_CHUNK", str(steps)))
         ss.migrate_check_every = 1  # look at every run() call (production: every 512 substeps)
         held = ss
@@ -153,6 +165,9 @@ def main():
         ok &= ss is held                # a re-partition updates the ShardedSim in place: a caller that never rebinds is fine
         if os.environ.get("MPMHIP_DIST_TRANSPORT") == "rccl" and (torch.cuda.device_count() >= world or os.environ.get("MPMHIP_RCCL_LIB")):
             ok &= ss.transport == "rccl"   # the test asked for the in-library loop: falling back silently is a failure
+        if float(os.environ.get("MPMHIP_TEST_TRAD_MIG", "-1")) >= 0:
+            print(f"dist[{scene_name}] rank {rank}: {ss.trad_migrations} on-device migrations moved {ss.trad_migrated} particles, {ss.migrations} re-partitions, "
+                  f"owns {ss.shard.own_t.size} of {sc.n_traditional}, {int((ss.shard.t_gid < 0).sum())} free rows", flush=True)
         if float(os.environ.get("MPMHIP_TEST_MIGRATE", "0")) > 0:
             print(f"dist[{scene_name}] rank {rank}: {ss.migrations} re-partitions, {100 * mdist.slab_leavers(ss):.0f} % outside their slab, "
                   f"halo x{mdist.halo_bytes_max(ss) / max(ss.halo_ref, 1):.2f}", flush=True)

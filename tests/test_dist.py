@@ -8,6 +8,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -242,6 +243,28 @@ def test_in_library_loop_migration_over_the_stand_in():
     assert "max rel dx" in out and "(rccl, halos: peer-mapped" in out
     n = [int(x) for x in re.findall(r"rank \d+: (\d+) re-partitions", out)]
     assert len(n) == 2 and n[0] == n[1] and n[0] >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,transport", [(2, "torch"), (2, "rccl"), (3, "rccl"), (4, "rccl")])
+def test_on_device_migration_of_traditional_particles(world, transport):
+    """material that MIXES across the slab cuts changes rank on the device (mpmavatar_amd.dist.migrate_traditional):
+    new quantile cuts from a histogram summed over the ranks, the leavers' records (52 floats + id) through one all-to-all of device
+    tensors into free rows of the destination's traditional class, no context rebuilt, no state through the host, no
+    all_gather_object.  A sheared cube on 2 / 3 / 4 ranks, a look every 30 substeps: several migration events, no stop-the-world
+    re-partition, ownership stays a partition of the particles, and the run stays on the single context's trajectory."""
+    import re
+    env = {"MPMHIP_TEST_TRAD_MIG": "0", "MPMHIP_TEST_RUN_CHUNK": "30"}
+    if transport == "rccl":
+        env.update(_mock_rccl_env())
+    out = _launch(world, "gpu", "shear", 150, extra_env=env)
+    assert "max rel dx" in out
+    m = re.findall(r"rank \d+: (\d+) on-device migrations moved (\d+) particles, (\d+) re-partitions, owns (\d+) of (\d+), (\d+) free rows", out)
+    assert len(m) == world, out[-3000:]
+    ev, moved, rep, owns, total, free = (np.array([int(r[k]) for r in m]) for k in range(6))
+    assert (ev >= 2).all() and len(set(ev)) == 1 and (moved > 0).all() and len(set(moved)) == 1 and (rep == 0).all(), m
+    assert owns.sum() == total[0] and (free > 0).all(), m                       # still a partition; nobody ran out of rows
+    assert owns.max() - owns.min() <= 0.1 * total[0] / world + 8, m             # ... and a balanced one (quantile cuts)
 
 
 @pytest.mark.gpu

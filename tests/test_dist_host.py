@@ -21,8 +21,9 @@ def _local_view(g, sh, sc):
     ne, nt = sc.n_elements, sc.n_traditional
     el = np.concatenate([sh.own_e, sh.ghost_e])
     vl = np.concatenate([sh.own_v, sh.ghost_v])
-    all_ids = np.concatenate([el, ne + sh.own_t, ne + nt + vl])
-    nv_ids = np.concatenate([el, ne + sh.own_t])
+    t_ids = np.where(sh.t_gid >= 0, sh.t_gid, 0)       # (free rows of the migration slack hold some particle's values; never read back)
+    all_ids = np.concatenate([el, ne + t_ids, ne + nt + vl])
+    nv_ids = np.concatenate([el, ne + t_ids])
     out = {}
     for f, a in g.items():
         out[f] = a[el] if f == "particle_d" else (a[all_ids] if a.shape[0] == sc.n_particles else a[nv_ids])
