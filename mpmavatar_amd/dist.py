@@ -227,8 +227,9 @@ class ShardedSim:
     migrations: int = 0
     migrate_trad_fraction: float = 0.01   # on-device migration of traditional particles when at least this fraction of them lies in
                                           # another rank's slab of the CURRENT quantile cuts (0: at every check; < 0: never)
-    trad_migrations: int = 0              # on-device migration events / particles moved by them
+    trad_migrations: int = 0              # on-device migration events / particles moved by them / wall time spent in them
     trad_migrated: int = 0
+    trad_migration_ms: list = field(default_factory=list)   # wall time of every event (the first pays torch's one-time kernel loads)
     mass_version: tuple = ()           # (data_ptr, version counter) of state.particle_mass when the ranks last agreed on the scene's mass span
 
 
@@ -505,8 +506,19 @@ def migrate_traditional(ss: "ShardedSim", min_fraction: float = 0.0) -> int:
     sv, st = sim.solver, sim.state
     dev = st._raw("particle_x").device
     host = ss.backend == "gloo"
+    import os
+    import time
+    marks = []
+
+    def mark(what):   # MPMHIP_VERBOSE=2: where a migration event's time goes (synchronises the device at every mark)
+        if os.environ.get("MPMHIP_VERBOSE") == "2":
+            torch.cuda.synchronize()
+            marks.append((what, time.perf_counter()))
+    mark("start")
     sv._call("mpmhip_pull_state")                       # the caller-order tensors are the solver's state now (one export kernel)
+    mark("pull")
     cuts_np = device_cuts(ss)                           # (collective) quantile cuts of the owned vertices + traditional particles
+    mark("cuts")
     cuts = torch.as_tensor(cuts_np, dtype=torch.float32, device=dev)
     gid = torch.as_tensor(sh.t_gid, dtype=torch.int64, device=dev)
     owned = gid >= 0
@@ -523,6 +535,7 @@ def migrate_traditional(ss: "ShardedSim", min_fraction: float = 0.0) -> int:
     n_free = int((~owned).sum().item())
     ok = torch.tensor([1 if n_in <= n_free + int(table[rank].sum()) else 0], dtype=torch.int32, device="cpu" if host else dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    mark("counts")
     if n_moving == 0 or n_moving < min_fraction * sc.n_traditional:
         return 0
     if int(ok.item()) != 1:
@@ -539,12 +552,23 @@ def migrate_traditional(ss: "ShardedSim", min_fraction: float = 0.0) -> int:
     if host:   # gloo: staged through host memory like every other exchange of the test backend
         ro, io = list(rec.cpu().split(out_split)), list(rec_id.cpu().split(out_split))
         ri, ii = [torch.empty((c, MIG_RECORD_FLOATS)) for c in in_split], [torch.empty(c, dtype=torch.int64) for c in in_split]
-        dist.all_to_all(ri, ro)
-        dist.all_to_all(ii, io)
+        ops = []   # (gloo has no all-to-all: point-to-point, batched)
+        for q in range(world):
+            if q == rank:
+                continue
+            for src, dst in ((ro, ri), (io, ii)):
+                if src[q].numel():
+                    ops.append(dist.P2POp(dist.isend, src[q].contiguous(), q))
+                if dst[q].numel():
+                    ops.append(dist.P2POp(dist.irecv, dst[q], q))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
         rec_in, id_in = torch.cat(ri).to(dev), torch.cat(ii).to(dev)
     else:
         dist.all_to_all_single(rec_in, rec, in_split, out_split)
         dist.all_to_all_single(id_in, rec_id, in_split, out_split)
+    mark("exchange")
     # leavers free their rows, arrivals take free rows (the leavers' included)
     gid[idx] = -1
     free_rows = torch.nonzero(gid < 0).reshape(-1)[:n_in]
@@ -554,6 +578,7 @@ def migrate_traditional(ss: "ShardedSim", min_fraction: float = 0.0) -> int:
         f[free_rows] = rec_in[:, off:off + w]
         off += w
     gid[free_rows] = id_in
+    mark("insert")
     # sorted layout: free rows first, owned rows by ascending global id
     order = torch.sort(gid, stable=True).indices
     for f in fields:
@@ -562,6 +587,7 @@ def migrate_traditional(ss: "ShardedSim", min_fraction: float = 0.0) -> int:
     ne_l = sh.own_e.size + sh.ghost_e.size
     sel = st._raw("particle_selection")
     sel[ne_l:ne_l + gid.numel()] = (gid < 0).to(sel.dtype)      # 1: free row (never simulated), 0: owned
+    mark("sort rows")
     sh.t_gid = gid.cpu().numpy()
     sh.own_t = sh.t_gid[sh.t_gid >= 0]
     sh.cuts = np.asarray(cuts_np, np.float64)
@@ -572,6 +598,9 @@ def migrate_traditional(ss: "ShardedSim", min_fraction: float = 0.0) -> int:
     ss.mass_version = ()                                # (masses moved with their particles: the ranks agree on the span again)
     ss.trad_migrated += n_moving
     ss.trad_migrations += 1
+    mark("bookkeeping")
+    if marks and rank == 0:
+        print("[mpmavatar_amd.dist] migration event: " + ", ".join(f"{b[0]} {1e3 * (b[1] - a[1]):.2f} ms" for a, b in zip(marks, marks[1:])), flush=True)
     return n_moving
 
 
@@ -591,7 +620,7 @@ def repartition(ss: "ShardedSim") -> "ShardedSim":
     dev = str(ss.sim.solver.device)
     keep = dict(steps_done=ss.steps_done, resorts=ss.resorts, migrate_fraction=ss.migrate_fraction, migrations=ss.migrations + 1,
                 migrate_halo_factor=ss.migrate_halo_factor, halo_ref=0, migrate_trad_fraction=ss.migrate_trad_fraction,
-                trad_migrations=ss.trad_migrations, trad_migrated=ss.trad_migrated,
+                trad_migrations=ss.trad_migrations, trad_migrated=ss.trad_migrated, trad_migration_ms=ss.trad_migration_ms,
                 migrate_check_every=ss.migrate_check_every, migrate_checked_at=ss.migrate_checked_at)
     rank, world, rebin_interval = ss.shard.rank, ss.shard.world, ss.rebin_interval
     old = ss.sim
@@ -641,7 +670,14 @@ def maybe_repartition(ss: "ShardedSim") -> "ShardedSim":
     # (0) traditional particles that have mixed across the cuts change rank ON THE DEVICE (migrate_traditional): cheap enough to do at
     # every look, and what it does not fix (too few free rows; cloth folded across a cut) is left to the halo criterion below
     if ss.migrate_trad_fraction >= 0 and ss.global_scene.n_traditional > 0:
+        import time
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         moved = migrate_traditional(ss, ss.migrate_trad_fraction)
+        torch.cuda.synchronize()
+        if moved > 0:
+            ss.trad_migration_ms.append(1e3 * (time.perf_counter() - t0))
         if os.environ.get("MPMHIP_VERBOSE"):
             print(f"[mpmavatar_amd.dist] rank {ss.shard.rank}: substep {ss.steps_done}: on-device migration of traditional particles: "
                   + ("too few free rows on some rank" if moved < 0 else f"{moved} changed rank"), flush=True)

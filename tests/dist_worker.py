@@ -70,7 +70,16 @@ def _registry(name):
     return lambda: scenes.REGISTRY[name]()
 
 
-SCENES = {"shear": _shear_cube, "sheet-500k": _registry("sheet-500k"), "widesheet8": _wide_sheet8, "widesheet": _wide_sheet, "crossing": _crossing_cube, "sway": _sway_garment, "demohold": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=(10, 5, 64)),
+def _shear_block():
+    """The same at 512,000 particles (block-512k of the registry, sheared): what a migration event costs at the headline size."""
+    sc = scenes.REGISTRY["block-512k"]()
+    y = sc.x[:, 1]
+    sc.v = sc.v.copy()
+    sc.v[:, 0] += (6.0 * (y - y.mean()) / (y.max() - y.min())).astype(np.float32)
+    return sc
+
+
+SCENES = {"shear": _shear_cube, "shear512k": _shear_block, "sheet-500k": _registry("sheet-500k"), "widesheet8": _wide_sheet8, "widesheet": _wide_sheet, "crossing": _crossing_cube, "sway": _sway_garment, "demohold": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=(10, 5, 64)),
           "garment": scenes.small_garment, "sheet": scenes.small_sheet, "cube": scenes.small_cube, "fastcube": _fast_cube,
           "demo": lambda: scenes.demo_mix(n_grid=48, n_sheet=16, sand=(16, 3, 8), hold=False)}
 
@@ -167,7 +176,7 @@ def main():
             ok &= ss.transport == "rccl"   # the test asked for the in-library loop: falling back silently is a failure
         if float(os.environ.get("MPMHIP_TEST_TRAD_MIG", "-1")) >= 0:
             print(f"dist[{scene_name}] rank {rank}: {ss.trad_migrations} on-device migrations moved {ss.trad_migrated} particles, {ss.migrations} re-partitions, "
-                  f"owns {ss.shard.own_t.size} of {sc.n_traditional}, {int((ss.shard.t_gid < 0).sum())} free rows", flush=True)
+                  f"owns {ss.shard.own_t.size} of {sc.n_traditional}, {int((ss.shard.t_gid < 0).sum())} free rows; ms per event {[round(t, 2) for t in ss.trad_migration_ms]}", flush=True)
         if float(os.environ.get("MPMHIP_TEST_MIGRATE", "0")) > 0:
             print(f"dist[{scene_name}] rank {rank}: {ss.migrations} re-partitions, {100 * mdist.slab_leavers(ss):.0f} % outside their slab, "
                   f"halo x{mdist.halo_bytes_max(ss) / max(ss.halo_ref, 1):.2f}", flush=True)
