@@ -117,7 +117,9 @@ typedef struct {
                                    (g2p of substep n + stress and p2g of substep n + 1, csrc/g2p.hip k_g2p2g) */
   int32_t p2g_tile_in_use;      /* fast mode: the accumulator p2g's chunk tile runs on NOW -- MPMHIP_P2G_TILE_FIXED or MPMHIP_P2G_TILE_F64
                                    (what MPMHIP_P2G_TILE_AUTO resolved to at the last import; 0 in baseline mode) */
-  int32_t reserved_;
+  int32_t kept_collider_substeps; /* fast mode: substeps of mpmhip_steps calls whose body was at rest (mesh_v == 0 for every vertex) that
+                                     ran WITHOUT body-face splat workgroups: the collider field is splatted once per accumulator buffer
+                                     and kept until the particle order changes or the call ends (csrc/fast.hip fast_body_at_rest_begin) */
 } mpmhip_stats;
 
 /* ---- lifetime ----------------------------------------------------------------- */

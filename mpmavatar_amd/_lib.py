@@ -54,7 +54,7 @@ class ModelScalars(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("substeps", C.c_int64), ("rebins", C.c_int64), ("n_active_blocks", C.c_int32),
                 ("n_active_nodes", C.c_int32), ("n_collider_nodes", C.c_int32), ("n_mover_nodes", C.c_int32),
-                ("n_fallback_particles", C.c_int32), ("n_dropped", C.c_int32), ("g2p2g_launches", C.c_int64), ("p2g_tile_in_use", C.c_int32), ("reserved_", C.c_int32)]
+                ("n_fallback_particles", C.c_int32), ("n_dropped", C.c_int32), ("g2p2g_launches", C.c_int64), ("p2g_tile_in_use", C.c_int32), ("kept_collider_substeps", C.c_int32)]
 
 
 class DistPeer(C.Structure):

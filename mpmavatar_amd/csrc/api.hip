@@ -381,6 +381,13 @@ int mpmhip_steps(mpmhip_ctx *c, float dt, int32_t n, const float *mesh_x, const 
                  const float *joint_faces_v) {
   CHECK_CTX(c);
   if (n < 0) return fail(c, MPMHIP_ERR_INVALID, "steps: n < 0");
+  const bool fast = fast_mode(c) && c->fast && c->st_bound && c->md_bound && (!(mesh_x || mesh_v) || c->mesh_points);
+  if (fast) {   // a body that does not move during this call is splatted once, not n times (fast_body_at_rest_begin, fast.hip)
+    c->cur_vel = mesh_v ? mesh_v : c->mesh_vel;
+    int rc = fast_body_at_rest_begin(c, n);
+    if (rc) return rc;
+  }
+  struct AtRestEnd { mpmhip_ctx *c; bool on; ~AtRestEnd() { if (on) fast_body_at_rest_end(c); } } at_rest_end{c, fast};
   for (int k = 0; k < n; ++k) {
     // mesh_x + substep_size*substep_local*mesh_v, train_material_params.py:623, evaluated inside the kernels
     StepArgs a{dt, mesh_x, mesh_v, (float)((double)dt * (double)k), k == n - 1, joint_traditional_v,

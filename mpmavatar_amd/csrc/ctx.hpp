@@ -181,6 +181,8 @@ int baseline_add_mover_storage(mpmhip_ctx *ctx, Mover &mv);
 int fast_init(mpmhip_ctx *ctx);
 void fast_destroy(mpmhip_ctx *ctx);
 int fast_step(mpmhip_ctx *ctx, const StepArgs &a);
+int fast_body_at_rest_begin(mpmhip_ctx *ctx, int n_substeps);   // head / tail of every mpmhip_steps call (fast.hip)
+void fast_body_at_rest_end(mpmhip_ctx *ctx);
 int fast_pull(mpmhip_ctx *ctx);
 int fast_export_grid(mpmhip_ctx *ctx, float *m, float *v_in, float *v_out);
 int fast_stats(mpmhip_ctx *ctx, mpmhip_stats *out);

@@ -148,11 +148,53 @@ int flush_elements(mpmhip_ctx *c) {
 
 // what has to be cleared after the last fused substep (the buffer g points at), marking it clean
 ZeroArgs take_zero(FastState *f) {
-  ZeroArgs z{f->alist, f->n_A, 0, f->dirty_col, f->dirty_mov, f->g.mv, f->g.col, f->g.mov, f->g.m_flag, f->g.col_flag};
+  // (a buffer that holds the collider field of a body at rest keeps it: col_state 2)
+  const int has_col = (f->dirty_col && f->col_state[f->par] != 2) ? 1 : 0;
+  ZeroArgs z{f->alist, f->n_A, 0, has_col, f->dirty_mov, f->g.mv, f->g.col, f->g.mov, f->g.m_flag, f->g.col_flag};
   if (f->grid_dirty && f->n_A) z.n_wg = (f->n_A + PT / 64 - 1) / (PT / 64);
+  if (f->grid_dirty && f->col_state[f->par] == 1) f->col_state[f->par] = 0;   // (cleared by the workgroups these arguments go to)
   f->grid_dirty = false;
   return z;
 }
+// collider fields kept for a body at rest: clear them now, over the active list as it stands (before it changes; before a body that
+// moves splats into the buffers again)
+void drop_kept_collider_fields(mpmhip_ctx *c) {
+  FastState *f = c->fast;
+  for (int k = 0; k < f->nbuf; ++k) {
+    if (f->col_state[k] != 2) continue;
+    if (f->n_A && f->col2[k]) {
+      // col-only pass: an all-zero flag array stands in for the mass flags (m_flag of the buffer may be live)
+      ZeroArgs z{f->alist, f->n_A, (f->n_A + PT / 64 - 1) / (PT / 64), 1, 0, f->mv2[k], f->col2[k], f->mov2[k], f->zero_flags, f->cflag2[k]};
+      hipLaunchKernelGGL(k_zero_blocks, (unsigned)z.n_wg, PT, 0, c->stream, z);
+    }
+    f->col_state[k] = 0;
+  }
+}
+__global__ void k_any_nonzero(const float *v, size_t n, int *flag) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool nz = i < n && v[i] != 0.0f;
+  if (__any(nz) && (threadIdx.x & 63) == 0) *flag = 1;
+}
+// Head of an mpmhip_steps call: does the body move during the call?  One small kernel over the vertex velocities and one host wait per
+// CALL (calls of >= 16 substeps only; a 400-substep frame pays ~20 us for it).  Whatever was kept from the call before is dropped:
+// the pose may have changed between calls.
+int fast_body_at_rest_begin(mpmhip_ctx *c, int n_substeps) {
+  FastState *f = c->fast;
+  f->col_at_rest = false;
+  drop_kept_collider_fields(c);
+  const bool eligible = f->col_keep && n_substeps >= 16 && !c->colliders.empty() && c->num_mesh_f && c->num_mesh_v && f->nbuf == 2 && f->fuse_grid &&
+                        !c->profiling && !f->dist && c->cur_vel && !(MPMHIP_DEBUG && f->g.dbg);
+  if (!eligible) return MPMHIP_OK;
+  int *flag = f->g.counters + 13;
+  MPM_HIP_CHECK(c, hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+  const size_t nm = (size_t)c->num_mesh_v * 3;
+  hipLaunchKernelGGL(k_any_nonzero, (unsigned)((nm + 255) / 256), 256, 0, c->stream, c->cur_vel, nm, flag);
+  MPM_HIP_CHECK(c, hipMemcpyAsync(f->h_pin + 31, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MPM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  f->col_at_rest = f->h_pin[31] == 0;
+  return MPMHIP_OK;
+}
+void fast_body_at_rest_end(mpmhip_ctx *c) { c->fast->col_at_rest = false; }   // (kept fields are dropped by whoever steps next)
 void select_buffer(FastState *f, int par) {
   f->par = par;
   f->g.mv = f->mv2[par]; f->g.col = f->col2[par]; f->g.mov = f->mov2[par];
@@ -194,6 +236,7 @@ int fast_init(mpmhip_ctx *c) {
   if (const char *e = getenv("MPMHIP_P2G_TILE")) { f->p2g_fixed = std::string(e) != "f64"; f->p2g_fixed_forced = std::string(e) == "fx"; }
   f->p2g_fixed_now = f->p2g_fixed;
   if (const char *e = getenv("MPMHIP_G2P2G")) f->g2p2g = atoi(e) != 0;
+  if (const char *e = getenv("MPMHIP_COL_KEEP")) f->col_keep = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_SPLIT_SPLAT")) f->split_splat = atoi(e) != 0;
   if (const char *e = getenv("MPMHIP_SPLIT_SPLAT_MAX")) f->split_splat_max_chunks = atoi(e);
   if (const char *e = getenv("MPMHIP_G2P2G_MAX")) f->g2p2g_max_chunks = atoi(e);
@@ -225,6 +268,7 @@ int fast_init(mpmhip_ctx *c) {
   if ((rc = dalloc(c, &f->g.vout, f->nblocks * GCH_VOUT * 64))) return rc;
   if ((rc = dalloc(c, &f->g.counters, CNT_N))) return rc;
   if ((rc = dalloc(c, &f->pack_done, (size_t)DONE_SHARDS * DONE_STRIDE))) return rc;
+  if ((rc = dalloc(c, &f->zero_flags, f->nblocks))) return rc;
   // one allocation, one memset per re-sort: [particle-block flags | active-block flags | device counts]
   static_assert(RC_N <= 64, "device counts of a re-sort");
   f->fc_tiles = (int)((f->nblocks + FC_TILE - 1) / FC_TILE);
@@ -414,6 +458,7 @@ int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     if ((rc = do_import(c))) return rc;
   }
   const float dt = a.dt;
+  if (!f->col_at_rest) drop_kept_collider_fields(c);   // (fields kept by an mpmhip_steps call whose body was at rest: this body may move)
   // pre-p2g particle operations, mpm_solver.py:260-279 (impulses first, then velocity modifiers)
   if (f->g2p_pending && (!g2p2g_ok(c) || !c->pre.empty() || dt != f->pend_dt)) flush_g2p(c);
   if (!c->pre.empty() && d.n_p) {
@@ -501,6 +546,13 @@ int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
       select_buffer(f, (f->par + 1) % f->nbuf);
     }
   }
+  // a body at rest whose collider field this buffer already holds (col_state 2): no splat workgroups in this substep
+  bool col_kept = false;
+  if (has_col && f->col_at_rest && f->nbuf == 2 && !c->profiling && f->col_state[f->par] == 2) {
+    sa.n_fbins = 0;
+    col_kept = true;
+    f->n_col_kept += 1;
+  }
   // cloth scenes of the production loop: the splat's first pass rides in front of the stress launch (col_splat_wg)
   // ... where the p2g launch is at most one round of workgroups, i.e. as long as a workgroup's life is the launch's length
   // (garment-120k-aniso: stress 9.7 -> 12.0 us, p2g 20.0 -> 16.4 us, 24.7 k -> 25.6 k substeps/s; with several rounds of chunk
@@ -577,6 +629,7 @@ int step_phase_a(mpmhip_ctx *c, const StepArgs &a) {
     if (f->n_chunks || sa.n_extra || sa.z.n_wg || sa.pack.n_wg)
       launch_p2g(c, trad_fused, jt_tile, xcd_grid(f->n_chunks) + (unsigned)(sa.n_extra + sa.z.n_wg + sa.pack.n_wg), f->n_chunks, dt, sa, tp);
   }
+  if (has_col && !col_kept && f->nbuf == 2) f->col_state[f->par] = (f->col_at_rest && !c->profiling) ? 2 : 1;
   return MPMHIP_OK;
 }
 
@@ -725,6 +778,7 @@ int fast_stats(mpmhip_ctx *c, mpmhip_stats *out) {
   out->rebins = f->rebins;
   out->g2p2g_launches = f->n_g2p2g;
   out->p2g_tile_in_use = f->p2g_fixed_now ? MPMHIP_P2G_TILE_FIXED : MPMHIP_P2G_TILE_F64;
+  out->kept_collider_substeps = (int32_t)std::min<int64_t>(f->n_col_kept, 0x7fffffff);
   out->n_active_blocks = f->n_A;
   int *dcnt = f->g.counters + 4;
   if (f->grid_dirty) {  // fused substeps do not count collider / mover nodes: count the last substep now

@@ -204,6 +204,14 @@ struct FastState {
   // they are cleared by the next substep's stress launch (ZeroArgs) or, before a re-sort, by k_zero_blocks
   bool fuse_grid = true, grid_dirty = false, fuse_trad = true;
   int dirty_col = 0, dirty_mov = 0;
+  // A body AT REST inside one mpmhip_steps call (mesh_v == 0 for every vertex: checked once per call, fast_body_at_rest): its collider
+  // field -- weight, weight * velocity, weight * normal per node -- is the same in every substep, so it is splatted ONCE into each of
+  // the two accumulator buffers and then kept: no splat workgroups, no clearing of the collider channels, until the particle order
+  // (the face bins, the active list) changes or the call ends.  col_state[buffer]: 0 clean, 1 holds this substep's splat (cleared by
+  // the next launch's clearing workgroups, as ever), 2 holds the field of the body at rest (kept).
+  bool col_at_rest = false;      // this mpmhip_steps call's body does not move
+  int col_state[3] = {0, 0, 0};
+  int64_t n_col_kept = 0;        // substeps that ran without splat workgroups because the field was kept (statistics)
   // accumulator double buffer: g.{mv,col,mov,m_flag,col_flag} point at buffer `par`
   // (three for scenes that can run the fused g2p -> p2g launch, k_g2p2g: read / write / clear)
   float *mv2[3] = {nullptr, nullptr, nullptr}, *col2[3] = {nullptr, nullptr, nullptr}, *mov2[3] = {nullptr, nullptr, nullptr};
@@ -211,6 +219,8 @@ struct FastState {
   int par = 0, nbuf = 2;
   // G2P2G: the g2p of the last substep has not been launched yet -- the next substep's launch does it in front of its own p2g
   // (k_g2p2g), or flush_g2p() does with a plain k_g2p when anything else needs the particles first
+  bool col_keep = true;        // MPMHIP_COL_KEEP=0: splat the body every substep whether it moves or not (A/B)
+  int *zero_flags = nullptr;   // [blocks] zeros (drop_kept_collider_fields)
   bool g2p2g = true;           // MPMHIP_G2P2G=0: two launches per substep for traditional-only scenes as before
   int g2p2g_max_chunks = 512;  // MPMHIP_G2P2G_MAX
   int stagger_auto = 2;        // p2g first-round stagger units for chunk lists of at least two rounds; -1: forced by MPMHIP_P2G_STAGGER
@@ -270,6 +280,7 @@ ZeroArgs take_zero(FastState *f);
 void select_buffer(FastState *f, int par);
 void flush_grid(mpmhip_ctx *c);
 void materialize_grid(mpmhip_ctx *c, bool count);
+void drop_kept_collider_fields(mpmhip_ctx *c);
 int step_phase_a(mpmhip_ctx *c, const StepArgs &a);
 int step_phase_b(mpmhip_ctx *c, const StepArgs &a);
 int step_phase_c(mpmhip_ctx *c, const StepArgs &a);

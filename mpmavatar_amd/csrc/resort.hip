@@ -694,6 +694,7 @@ int rebin(mpmhip_ctx *c) {
   int rc;
   if (d.n_p == 0) { flush_grid(c); f->n_P = f->n_A = f->n_chunks = f->n_chunks_g = 0; f->steps_since_rebin = 0; return MPMHIP_OK; }
   flush_elements(c);
+  drop_kept_collider_fields(c);   // (a body at rest: its kept collider fields live on the OLD active list and in the old face bins)
   // k_keys: the keys (written where the sort wants its input, so that the sorted keys end up in keys[1] and the order in f->order),
   // the sort's first histogram, the zeroing of the block flags / counts, and -- as extra workgroups -- the clearing of the grid
   // accumulators of the old active list (flush_grid)
