@@ -249,7 +249,7 @@ __global__ void k_g2p_v(mpmhip_state_ptrs st, const float *grid_v_out, GridDesc 
   store_v3(st.particle_x + 3 * (size_t)q, nx);
   store_m3(st.particle_C + 9 * (size_t)q, nC);
   if (q < n_nv) {
-    M3 Fn = (m3_identity() + dt * nF) * load_m3(st.particle_F + 9 * (size_t)q);
+    M3 Fn = deform_update(nF, dt, load_m3(st.particle_F + 9 * (size_t)q));
     store_m3(st.particle_F_trial + 9 * (size_t)q, Fn);
   }
 }

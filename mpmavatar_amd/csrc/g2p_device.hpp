@@ -231,7 +231,7 @@ __device__ __forceinline__ void g2p_write_grad(const Bufs &b, int cls, int s, V3
     V3 d3n = (m3_identity() + dt * F) * d3;
     b.el.at(E_D + 2, s) = d3n.x; b.el.at(E_D + 5, s) = d3n.y; b.el.at(E_D + 8, s) = d3n.z;
   } else if (cls == 1) {
-    st9(b.tr, T_FT, s - d.n_e, (m3_identity() + dt * F) * ld9(b.tr, T_F, s - d.n_e));
+    st9(b.tr, T_FT, s - d.n_e, deform_update(F, dt, ld9(b.tr, T_F, s - d.n_e)));
   }
 }
 template <bool NO_GRAD = false>
@@ -547,7 +547,7 @@ __device__ __forceinline__ void g2p2g_body(const ChunkRec *recs, int n_chunks, c
     V3 xg = fit ? x : v3((float)(ox + 2) * d.dx, (float)(oy + 2) * d.dx, (float)(oz + 2) * d.dx);
     G2PResult r = g2p_gather<false>(vt, ox, oy, oz, xg, d);
     nv = r.v; nC = r.C;
-    Ft = (m3_identity() + dt * r.F) * ld9(b.tr, T_F, tx);   // g2p_v :780-786
+    Ft = deform_update(r.F, dt, ld9(b.tr, T_F, tx));   // g2p_v :780-786
     float a_min = (1.0f / d.inv_dx) * 2.0f, a_max = d.grid_lim - (1.0f / d.inv_dx) * 2.0f;
     nx = x + dt * nv;
     nx = v3(fminf(fmaxf(nx.x, a_min), a_max), fminf(fmaxf(nx.y, a_min), a_max), fminf(fmaxf(nx.z, a_min), a_max));

@@ -61,6 +61,22 @@ __device__ __forceinline__ M3 operator*(const M3 &a, const M3 &b) {
             a.a20 * b.a00 + a.a21 * b.a10 + a.a22 * b.a20, a.a20 * b.a01 + a.a21 * b.a11 + a.a22 * b.a21,
             a.a20 * b.a02 + a.a21 * b.a12 + a.a22 * b.a22};
 }
+// F_trial = (I + dt grad_v) F of a traditional particle (g2p_v, mpm_utils.py:780-786) with every product and every sum rounded on its
+// own, as the reference's mat33 arithmetic is in the fixtures that pin this code.  Everywhere else hipcc may contract a * b + c into one
+// FMA (-ffp-contract=fast-honor-pragmas); here it may not: F stays within ~1e-3 of a rotation, 1 + dt g rounds at 6e-8, and whether the
+// product dt g is rounded before that sum decides the last bit of F -- which the elastic stress multiplies by E.  This one expression
+// is what kept the spinning jelly cube of the reference's sequence fixture from the per-particle 1e-4 (2.2e-4 / 4.4e-4 with the
+// contraction, 5.3e-5 / 4.1e-5 without; every other contraction of the library switched off on top of it: 5.3e-5;
+// profiles/r06_experiments.md 2).  27 multiplies + 21 adds instead of 27 FMAs + 3 adds per traditional particle and substep.
+__device__ __forceinline__ M3 deform_update(const M3 &G, float dt, const M3 &F) {
+#pragma clang fp contract(off)
+  float g00 = 1.0f + dt * G.a00, g01 = dt * G.a01, g02 = dt * G.a02;
+  float g10 = dt * G.a10, g11 = 1.0f + dt * G.a11, g12 = dt * G.a12;
+  float g20 = dt * G.a20, g21 = dt * G.a21, g22 = 1.0f + dt * G.a22;
+  return M3{g00 * F.a00 + g01 * F.a10 + g02 * F.a20, g00 * F.a01 + g01 * F.a11 + g02 * F.a21, g00 * F.a02 + g01 * F.a12 + g02 * F.a22,
+            g10 * F.a00 + g11 * F.a10 + g12 * F.a20, g10 * F.a01 + g11 * F.a11 + g12 * F.a21, g10 * F.a02 + g11 * F.a12 + g12 * F.a22,
+            g20 * F.a00 + g21 * F.a10 + g22 * F.a20, g20 * F.a01 + g21 * F.a11 + g22 * F.a21, g20 * F.a02 + g21 * F.a12 + g22 * F.a22};
+}
 __device__ __forceinline__ V3 operator*(const M3 &a, V3 v) {
   return V3{a.a00 * v.x + a.a01 * v.y + a.a02 * v.z, a.a10 * v.x + a.a11 * v.y + a.a12 * v.z,
             a.a20 * v.x + a.a21 * v.y + a.a22 * v.z};
