@@ -5,7 +5,8 @@
  * (/root/reference/warp_mpm/mpm_solver.py:229-536) and the kernels it launches
  * (warp_mpm/mpm_utils.py).  Every function cites the reference lines it follows.
  * Kernel = serial `for tid` loop in reference thread order; inner stencil loops in
- * reference order (i outer, j, k inner).  PARITY UNPINNED (Warp not runnable here).
+ * reference order (i outer, j, k inner).  Pinned by fixtures the reference's own kernel
+ * bodies produced over a NumPy stand-in of the warp module (mpm_oracle.h, PINNING).
  *
  * Compile:  gcc -O2 -ffp-contract=off -fPIC -shared  (serial oracle)
  *           gcc -O2 -fopenmp -DORC_OMP ...           (multi-core CPU baseline)
@@ -424,12 +425,63 @@ static inline void add3(float *dst, const float *a) {
   dst[2] += a[2];
 }
 
+/* The nodes a grid-wide pass visits: the whole grid, or the active box of this substep (mpm_oracle.h, ACTIVE BOX). */
+typedef struct { int lo[3], hi[3]; } orc_box;
+static orc_box box_of(const orc_sim *s) {
+  orc_box b;
+  for (int a = 0; a < 3; ++a) {
+    b.lo[a] = s->box_mode ? s->box_lo[a] : 0;
+    b.hi[a] = s->box_mode ? s->box_hi[a] : s->n_grid - 1;
+  }
+  return b;
+}
+static inline int in_box(const orc_box *b, int ix, int iy, int iz) {
+  return ix >= b->lo[0] && ix <= b->hi[0] && iy >= b->lo[1] && iy <= b->hi[1] && iz >= b->lo[2] && iz <= b->hi[2];
+}
+/* for every node g of the box, rows along z: ORC_BOX_FOR(s, bx) { ... g ... } ORC_BOX_END */
+#define ORC_BOX_FOR(s, bx)                                                              \
+  ORC_PARALLEL_FOR                                                                      \
+  for (int ix_ = (bx).lo[0]; ix_ <= (bx).hi[0]; ++ix_)                                  \
+    for (int iy_ = (bx).lo[1]; iy_ <= (bx).hi[1]; ++iy_) {                              \
+      size_t g0_ = gidx((s), ix_, iy_, (bx).lo[2]), g1_ = gidx((s), ix_, iy_, (bx).hi[2]); \
+      for (size_t g = g0_; g <= g1_; ++g)
+#define ORC_BOX_END }
+static void box_clear(const orc_sim *s, const orc_box *b, float *a, int comps) {
+  if (b->lo[0] == 0 && b->lo[1] == 0 && b->lo[2] == 0 && b->hi[0] == s->n_grid - 1 && b->hi[1] == s->n_grid - 1 && b->hi[2] == s->n_grid - 1) {
+    memset(a, 0, (size_t)s->n_grid * s->n_grid * s->n_grid * comps * sizeof(float));
+    return;
+  }
+  size_t len = (size_t)(b->hi[2] - b->lo[2] + 1) * comps * sizeof(float);
+  ORC_PARALLEL_FOR
+  for (int ix = b->lo[0]; ix <= b->hi[0]; ++ix)
+    for (int iy = b->lo[1]; iy <= b->hi[1]; ++iy) memset(a + gidx(s, ix, iy, b->lo[2]) * comps, 0, len);
+}
+/* bounding box of every particle's stencil (base .. base + 2 per axis, orc_stencil), clamped to the grid */
+static void box_from_particles(orc_sim *s) {
+  int lo0 = s->n_grid, lo1 = s->n_grid, lo2 = s->n_grid, hi0 = -1, hi1 = -1, hi2 = -1;
+  for (int p = 0; p < s->n_particles; ++p) {
+    int b0 = (int)(s->x[p * 3] * s->inv_dx - 0.5f), b1 = (int)(s->x[p * 3 + 1] * s->inv_dx - 0.5f), b2 = (int)(s->x[p * 3 + 2] * s->inv_dx - 0.5f);
+    if (b0 < lo0) lo0 = b0;
+    if (b1 < lo1) lo1 = b1;
+    if (b2 < lo2) lo2 = b2;
+    if (b0 > hi0) hi0 = b0;
+    if (b1 > hi1) hi1 = b1;
+    if (b2 > hi2) hi2 = b2;
+  }
+  int lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0 + 2, hi1 + 2, hi2 + 2};
+  for (int a = 0; a < 3; ++a) {
+    s->box_lo[a] = lo[a] < 0 ? 0 : lo[a];
+    s->box_hi[a] = hi[a] > s->n_grid - 1 ? s->n_grid - 1 : hi[a];
+    if (s->n_particles == 0) { s->box_lo[a] = 0; s->box_hi[a] = 0; }
+  }
+}
+
 /* zero_grid, mpm_utils.py:411-417 */
 void orc_zero_grid(orc_sim *s) {
-  size_t n = (size_t)s->n_grid * s->n_grid * s->n_grid;
-  memset(s->grid_m, 0, n * sizeof(float));
-  memset(s->grid_v_in, 0, 3 * n * sizeof(float));
-  memset(s->grid_v_out, 0, 3 * n * sizeof(float));
+  orc_box bx = box_of(s);
+  box_clear(s, &bx, s->grid_m, 1);
+  box_clear(s, &bx, s->grid_v_in, 3);
+  box_clear(s, &bx, s->grid_v_out, 3);
 }
 
 /* Test hooks (tests/test_hip_math_on_host.py): when set, the per-particle constitutive update is taken from the caller
@@ -548,22 +600,24 @@ void orc_p2g(orc_sim *s, float dt) {
 
 /* grid_normalization_and_gravity, mpm_utils.py:561-572 */
 void orc_grid_normalization_and_gravity(orc_sim *s, float dt) {
-  size_t n = (size_t)s->n_grid * s->n_grid * s->n_grid;
-  ORC_PARALLEL_FOR
-  for (size_t g = 0; g < n; ++g) {
+  orc_box bx = box_of(s);
+  ORC_BOX_FOR(s, bx) {
     if (s->grid_m[g] > 1e-15f) {
       float inv = 1.0f / s->grid_m[g];
       for (int a = 0; a < 3; ++a)
         s->grid_v_out[g * 3 + a] = s->grid_v_in[g * 3 + a] * inv + dt * s->g[a];
     }
   }
+  ORC_BOX_END
 }
 
 /* add_damping_via_grid, mpm_utils.py:1162-1174 */
 void orc_add_damping_via_grid(orc_sim *s, float scale) {
-  size_t n = (size_t)s->n_grid * s->n_grid * s->n_grid * 3;
-  ORC_PARALLEL_FOR
-  for (size_t g = 0; g < n; ++g) s->grid_v_out[g] -= (1.0f - scale) * s->grid_v_out[g];
+  orc_box bx = box_of(s);
+  ORC_BOX_FOR(s, bx) {
+    for (int a = 0; a < 3; ++a) s->grid_v_out[g * 3 + a] -= (1.0f - scale) * s->grid_v_out[g * 3 + a];
+  }
+  ORC_BOX_END
 }
 
 static int in_splat_bounds(const orc_sim *s, const int *b) { /* mpm_solver.py:692,730,767,858 */
@@ -574,11 +628,11 @@ static int in_splat_bounds(const orc_sim *s, const int *b) { /* mpm_solver.py:69
 /* mesh collider k: zero_grid, compute_mesh, normalize_grid, collide; mpm_solver.py:819-917 */
 void orc_mesh_collide(orc_sim *s, int k) {
   orc_mesh_collider *mc = &s->mesh_colliders[k];
-  size_t n = (size_t)s->n_grid * s->n_grid * s->n_grid;
-  memset(mc->weight, 0, n * sizeof(float));
-  memset(mc->v_in, 0, 3 * n * sizeof(float));
-  memset(mc->v_out, 0, 3 * n * sizeof(float));
-  memset(mc->normal, 0, 3 * n * sizeof(float));
+  orc_box bx = box_of(s);
+  box_clear(s, &bx, mc->weight, 1);
+  box_clear(s, &bx, mc->v_in, 3);
+  box_clear(s, &bx, mc->v_out, 3);
+  box_clear(s, &bx, mc->normal, 3);
   ORC_PARALLEL_FOR
   for (int p = 0; p < s->num_mesh_f; ++p) { /* compute_mesh :829-880 */
     int i0 = s->mesh_indices[3 * p], i1 = s->mesh_indices[3 * p + 1], i2 = s->mesh_indices[3 * p + 2];
@@ -602,6 +656,7 @@ void orc_mesh_collide(orc_sim *s, int k) {
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j)
         for (int kk = 0; kk < 3; ++kk) {
+          if (!in_box(&bx, base[0] + i, base[1] + j, base[2] + kk)) continue; /* (never taken with box_mode = 0) */
           float weight = w[i] * w[3 + j] * w[6 + kk];
           size_t g = gidx(s, base[0] + i, base[1] + j, base[2] + kk);
           float a3[3] = {weight * fv[0], weight * fv[1], weight * fv[2]};
@@ -612,15 +667,14 @@ void orc_mesh_collide(orc_sim *s, int k) {
           mc->weight[g] += weight;
         }
   }
-  ORC_PARALLEL_FOR
-  for (size_t g = 0; g < n; ++g) { /* normalize_grid :882-890 */
+  ORC_BOX_FOR(s, bx) { /* normalize_grid :882-890 */
     if (mc->weight[g] > 1e-15f) {
       float inv_w = 1.0f / mc->weight[g];
       for (int a = 0; a < 3; ++a) mc->v_out[g * 3 + a] = mc->v_in[g * 3 + a] * inv_w;
     }
   }
-  ORC_PARALLEL_FOR
-  for (size_t g = 0; g < n; ++g) { /* collide :892-917 */
+  ORC_BOX_END
+  ORC_BOX_FOR(s, bx) { /* collide :892-917 */
     float *v = &s->grid_v_out[g * 3];
     if (mc->weight[g] > 1e-15f) {
       float vrel[3], nn[3], vproj[3], vfric[3];
@@ -640,6 +694,7 @@ void orc_mesh_collide(orc_sim *s, int k) {
       for (int a = 0; a < 3; ++a) v[a] = vfric[a] + mc->v_out[g * 3 + a];
     }
   }
+  ORC_BOX_END
 }
 
 /* splat of a prescribed velocity at particle q, mpm_solver.py:677-788 */
@@ -648,9 +703,11 @@ static void mover_splat(orc_sim *s, orc_mover *mv, int q, const float *vel) {
   float w[9];
   orc_stencil(&s->x[q * 3], s->inv_dx, base, w, NULL);
   if (!in_splat_bounds(s, base)) return;
+  orc_box bx = box_of(s);
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j)
       for (int k = 0; k < 3; ++k) {
+        if (!in_box(&bx, base[0] + i, base[1] + j, base[2] + k)) continue; /* (a particle's stencil lies inside the box by construction) */
         float weight = w[i] * w[3 + j] * w[6 + k];
         size_t g = gidx(s, base[0] + i, base[1] + j, base[2] + k);
         float a3[3] = {weight * vel[0], weight * vel[1], weight * vel[2]};
@@ -664,10 +721,10 @@ static void mover_splat(orc_sim *s, orc_mover *mv, int q, const float *vel) {
 void orc_particle_move(orc_sim *s, int k, const float *joint_t_v, int n_joint_t,
                        const float *joint_v_v, const float *joint_f_v) {
   orc_mover *mv = &s->movers[k];
-  size_t n = (size_t)s->n_grid * s->n_grid * s->n_grid;
+  orc_box bx = box_of(s);
   int n_nv = s->n_particles - s->n_vertices;
-  memset(mv->weight, 0, n * sizeof(float));
-  memset(mv->velocity, 0, 3 * n * sizeof(float));
+  box_clear(s, &bx, mv->weight, 1);
+  box_clear(s, &bx, mv->velocity, 3);
   if (joint_t_v) { /* :437-449, offset n_particles - n_vertices - joint_num */
     int off = n_nv - n_joint_t;
     ORC_PARALLEL_FOR
@@ -677,13 +734,13 @@ void orc_particle_move(orc_sim *s, int k, const float *joint_t_v, int n_joint_t,
   for (int p = 0; p < s->num_joint_v; ++p) mover_splat(s, mv, p + n_nv, &joint_v_v[p * 3]);
   ORC_PARALLEL_FOR
   for (int p = 0; p < s->num_joint_f; ++p) mover_splat(s, mv, p, &joint_f_v[p * 3]);
-  ORC_PARALLEL_FOR
-  for (size_t g = 0; g < n; ++g) { /* normalize_grid :790-799: overwrite */
+  ORC_BOX_FOR(s, bx) { /* normalize_grid :790-799: overwrite */
     if (mv->weight[g] > 1e-15f) {
       float inv_w = 1.0f / mv->weight[g];
       for (int a = 0; a < 3; ++a) s->grid_v_out[g * 3 + a] = mv->velocity[g * 3 + a] * inv_w;
     }
   }
+  ORC_BOX_END
 }
 
 /* grid BC k, mpm_solver.py:600-655 / 950-981 / 993-1050 / 1341-1352 */
@@ -691,10 +748,11 @@ void orc_apply_bc(orc_sim *s, int k, float dt) {
   orc_bc *bc = &s->bc[k];
   int G = s->n_grid;
   float time = (float)s->time;
+  orc_box bx = box_of(s);
   ORC_PARALLEL_FOR
-  for (int gx = 0; gx < G; ++gx)
-    for (int gy = 0; gy < G; ++gy)
-      for (int gz = 0; gz < G; ++gz) {
+  for (int gx = bx.lo[0]; gx <= bx.hi[0]; ++gx)
+    for (int gy = bx.lo[1]; gy <= bx.hi[1]; ++gy)
+      for (int gz = bx.lo[2]; gz <= bx.hi[2]; ++gz) {
         float *v = &s->grid_v_out[gidx(s, gx, gy, gz) * 3];
         if (bc->type == ORC_BC_SURFACE) {
           if (time >= bc->start_time && time < bc->end_time) {
@@ -873,6 +931,7 @@ void orc_p2g2p(orc_sim *s, double dt_host, const float *mesh_x, const float *mes
 #ifdef ORC_OMP
   if (s->n_threads > 0) omp_set_num_threads(s->n_threads);
 #endif
+  if (s->box_mode) box_from_particles(s);                             /* (mpm_oracle.h, ACTIVE BOX: not part of the algorithm) */
   orc_zero_grid(s);                                                   /* :244 */
   memset(s->vertex_force, 0, (size_t)s->n_vertices * 3 * sizeof(float)); /* :251 */
   orc_pre_p2g(s, dt);                                                 /* :260-279 */

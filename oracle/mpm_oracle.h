@@ -6,12 +6,19 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
  * this library. The product path (mpmavatar_amd/) never links, imports or calls it.
  *
- * PARITY UNPINNED: the reference path is NVIDIA-Warp DSL (warp-lang 0.10.1), which
- * is not installed in this image and cannot be (no network); the reference ships no
- * tests, fixtures or golden vectors for this path.  This restatement follows the
- * reference source line by line (citations at every function) and is pinned only
- * against analytic known-answer tests and an independent float64 NumPy twin
- * (oracle/twin.py), see tests/test_oracle_*.py.
+ * PINNING: the reference path is NVIDIA-Warp DSL (warp-lang 0.10.1), which is not
+ * installed in this image and cannot be (no network), and the reference ships no
+ * tests, fixtures or golden vectors for this path.  Its kernels are plain Python
+ * bodies, though: tests/golden/make_golden_ref.py imports the .py files of /root/reference/warp_mpm
+ * UNCHANGED over a NumPy stand-in of the `warp` module (tests/golden/warp_standin: serial
+ * `for tid`, one fp32 rounding per operation) and records single-substep traces and
+ * multi-substep sequences; this restatement reproduces them kernel by kernel and over
+ * whole sequences (tests/test_ref_golden.py, CPU suite) -- since round 2.  What that
+ * does NOT pin: wp.svd3 / wp.qr3 are the stand-in's own (two conventions each, agreeing
+ * to 2e-6 before a fixture is written): convention-pinned, not Warp-pinned.  Beside the
+ * fixtures: analytic known-answer tests and an independent float64 NumPy twin
+ * (oracle/twin.py), tests/test_oracle_*.py.  Every function cites the reference lines
+ * it follows.
  *
  * Layout = the reference's Warp layout: AoS, vec3 = 3 floats, mat33 = 9 floats
  * row-major, grids C-order [x][y][z].  Particle index classes:
@@ -123,6 +130,14 @@ typedef struct {
 
   double time; /* MPMWARP.time, python float (mpm_solver.py:28,536) */
   int32_t n_threads; /* 1 = serial oracle; >1 = OpenMP baseline (atomics) */
+  /* ACTIVE BOX (off by default; a speed option of the long ensemble runs of tests/test_gpu_fullsize.py, not part of the restated
+     algorithm): with box_mode != 0 orc_p2g2p takes the bounding box of ALL particles' 3x3x3 stencils at the head of the substep and
+     every grid-wide pass of that substep (the clears, normalisation, damping, collider, mover, BCs) visits the nodes of the box only;
+     a collider face's splat skips nodes outside it.  Nothing outside the box is read by p2g / g2p of that substep, and every node
+     inside it sees exactly the dense substep's operations, in the dense order per node: particle results are bit-identical to
+     box_mode = 0 in the serial build (tests/test_oracle_box.py).  Grid arrays hold stale values OUTSIDE the box afterwards. */
+  int32_t box_mode;
+  int32_t box_lo[3], box_hi[3];
 } orc_sim;
 
 /* individual kernels (exposed so tests can pin them one at a time) */

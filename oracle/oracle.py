@@ -2,8 +2,9 @@
 
 Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
 module.  It wraps ``oracle/mpm_oracle.c`` -- the serial fp32 restatement of the reference substep
-``MPMWARP.p2g2p`` (/root/reference/warp_mpm/mpm_solver.py:229-536).  PARITY UNPINNED: the reference is
-NVIDIA-Warp DSL and cannot run in this image; see the header of ``mpm_oracle.h``.
+``MPMWARP.p2g2p`` (/root/reference/warp_mpm/mpm_solver.py:229-536).  The reference is NVIDIA-Warp DSL and
+cannot run in this image; the restatement is pinned by fixtures the reference's own kernel bodies produced over a NumPy stand-in of
+the ``warp`` module (header of ``mpm_oracle.h``, PINNING; tests/test_ref_golden.py).
 
 All particle/grid memory is owned by NumPy arrays held on the :class:`OracleMPM` instance, in the
 reference's AoS layout, so tests can read/write any field between kernels.
@@ -72,6 +73,7 @@ class _Sim(C.Structure):
         ("n_bc", C.c_int32), ("bc", _BC * MAX_BC),
         ("n_pre", C.c_int32), ("pre", _Pre * MAX_PRE),
         ("time", C.c_double), ("n_threads", C.c_int32),
+        ("box_mode", C.c_int32), ("box_lo", C.c_int32 * 3), ("box_hi", C.c_int32 * 3),
     ]
 
 

@@ -2,8 +2,9 @@
 
 Independent of ``mpm_oracle.c``: it uses convention-free closed forms (Gram-Schmidt QR with
 q3 = q1 x q2, closed-form 2x2 polar rotation, LAPACK SVD) instead of restating Warp's qr3/svd3 +
-sign flips, and float64 throughout.  Agreement between the two (tests/test_oracle_twin.py) is what
-pins the fp32 C oracle in the absence of a runnable reference (PARITY UNPINNED, see mpm_oracle.h).
+sign flips, and float64 throughout.  Agreement between the two (tests/test_oracle_twin.py) was what
+pinned the fp32 C oracle in round 1; since round 2 the reference's own kernel bodies, run over a NumPy stand-in of the warp module,
+pin it (mpm_oracle.h, PINNING) and the twin is the second, convention-free witness.
 It also generates the committed golden fixtures (tests/golden/make_golden.py).
 
 Reference lines: stencil mpm_utils.py:499-526; p2g :484-557; grid update :561-572; g2p :716-857;

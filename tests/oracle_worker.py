@@ -26,6 +26,7 @@ def main():
     if gamma0:
         sc.gamma = 0.0
     o = oracle_from_scene(sc, omp=True, n_threads=threads, fma=fma)
+    o.sim.box_mode = 1   # grid-wide passes over the particles' bounding box only: same particles bit for bit (tests/test_oracle_box.py), 40 % less time
     res, done, t0 = {}, 0, time.time()
     for cp in cps:
         run_scene(o, sc, cp - done, k0=done)

@@ -1,6 +1,6 @@
 """GPU parity: the HIP solver (through the C ABI via the warp_mpm shim) against the serial fp32 CPU oracle
-on identical seeded inputs.  PARITY UNPINNED with respect to the reference itself (Warp not runnable here);
-the oracle is pinned by tests/test_oracle_*.py.
+on identical seeded inputs.  The reference itself cannot run here (Warp is NVIDIA-only); the oracle is pinned by
+fixtures the reference's own kernel bodies produced (tests/test_ref_golden.py) and by tests/test_oracle_*.py.
 
 Tolerances (BASELINE.json north_star: particle x / v within 1e-4 relative after N substeps):
   rel(a, b) = max|a-b| / max(max|b|, 1e-3).

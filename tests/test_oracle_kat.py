@@ -1,7 +1,8 @@
 """Known-answer tests that pin the CPU oracle.
 
-The reference ships no tests or golden vectors for this path and its Warp kernels cannot run here (PARITY UNPINNED);
-these analytic properties are what anchors the restatement in oracle/mpm_oracle.c.  Each test cites the reference
+The reference ships no tests or golden vectors for this path and its Warp kernels cannot run here; beside the fixtures its own kernel
+bodies produced over a NumPy stand-in of the warp module (tests/test_ref_golden.py), these analytic properties anchor the restatement in
+oracle/mpm_oracle.c.  Each test cites the reference
 lines whose behaviour it checks.
 """
 import math
