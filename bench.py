@@ -215,13 +215,18 @@ def _main(out_stream):
                      "the sharded run needs one GPU per rank")
         import socket
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        for attempt in range(3):   # (a free port found by bind(0) can be taken again before the launcher's store binds it: try another)
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            sys.stderr.write(r.stderr)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            lost_port = any(k in r.stderr.lower() for k in ("address already in use", "eaddrinuse", "failed to listen"))
+            if (r.returncode == 0 and lines) or not lost_port:
+                break
         if r.returncode != 0 or not lines:
             sys.exit(f"bench.py: the {args.gpus}-rank run failed (exit code {r.returncode})")
         print(lines[-1], file=out_stream, flush=True)

@@ -4,36 +4,20 @@ CPU (gloo, world_size 2 and 3): partition invariants, matching exchange lists, h
 twin.  GPU (two processes sharing cuda:0, gloo transport): the full sharded substep against a single context.
 """
 import os
-import socket
-import subprocess
 import sys
 
 import numpy as np
 import pytest
 
+from launch import torchrun
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
 def _launch(nproc, *args, timeout=600, extra_env=None):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"),
-           *map(str, args)]
     env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    infra = ("address already in use", "eaddrinuse", "rendezvous", "connection refused", "connection reset")
-    if r.returncode != 0 and any(k in (r.stdout + r.stderr).lower() for k in infra):
-        # the free port found above was taken before the launcher bound it (or its store died): that is the test
-        # harness, not the code under test -- one more try on another port
-        cmd[cmd.index("--master-port") + 1] = str(_free_port())
-        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    r = torchrun(nproc, WORKER, args, env=env, timeout=timeout)   # (tests/launch.py: a lost race for the port is retried, nothing else)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return r.stdout
 
@@ -95,9 +79,7 @@ def test_sharded_adaptive_collective_resort(scene, steps):
 def test_in_library_rccl_transport_single_rank_adaptive():
     """The same policy inside the library's RCCL loop (ncclAllReduce of the flag, read back with a lag), world size 1."""
     env = dict(os.environ, MPMHIP_DIST_TRANSPORT="rccl", MPMHIP_TEST_REBIN="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "gpu", "fastcube", "200"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    r = torchrun(1, WORKER, ["gpu", "fastcube", "200"], env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "max rel dx" in r.stdout
 
@@ -111,9 +93,7 @@ def test_nccl_backend_world_one_runs_every_collective(transport):
     world > 1."""
     env = dict(os.environ, MPMHIP_DIST_TRANSPORT=transport, MPMHIP_TEST_BACKEND="nccl", MPMHIP_TEST_REBIN="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "gpu", "garment", "40"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    r = torchrun(1, WORKER, ["gpu", "garment", "40"], env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "max rel dx" in r.stdout and f"({transport}" in r.stdout
 
@@ -123,9 +103,7 @@ def test_in_library_rccl_transport_single_rank():
     """World size 1 through the library's own RCCL communicator (dlopen, ncclCommInitRank, ncclAllGather of the block
     map, empty send/recv groups) -- the multi-rank send/recv itself cannot run on a one-GPU box."""
     env = dict(os.environ, MPMHIP_DIST_TRANSPORT="rccl")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "gpu", "garment", "40"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    r = torchrun(1, WORKER, ["gpu", "garment", "40"], env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "max rel dx" in r.stdout
 
@@ -139,9 +117,7 @@ def test_in_library_rccl_transport_two_ranks(scene, steps):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs")
     env = dict(os.environ, MPMHIP_DIST_TRANSPORT="rccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "gpu", scene, str(steps)]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    r = torchrun(2, WORKER, ["gpu", scene, str(steps)], env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "max rel dx" in r.stdout
 

@@ -56,12 +56,7 @@ def test_variant_slices_cover_the_four_runs_once():
 def test_sharded_training_step_matches_the_single_process_gloo():
     """world 2 (CPU, gloo): each rank evaluates its two variants, all-gather of the losses, identical Adam update."""
     import os
-    import socket
-    import subprocess
-    import sys
+    from launch import torchrun
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "tests", "fd_host_worker.py")]
-    r = subprocess.run(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    r = torchrun(2, os.path.join(root, "tests", "fd_host_worker.py"), env=dict(os.environ, OMP_NUM_THREADS="1"), timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]

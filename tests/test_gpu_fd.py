@@ -52,14 +52,9 @@ def test_fd_variants_sharded_over_ranks(world):
     (train_material_params.py:583: independent runs): ranks simulate their slice, all-gather four floats, apply the same
     update.  Here the ranks share the GPU (gloo); on a node each takes its own."""
     import os
-    import socket
-    import subprocess
-    import sys
+    from launch import torchrun
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "tests", "fd_worker.py")]
-    r = subprocess.run(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=900)
+    r = torchrun(world, os.path.join(root, "tests", "fd_worker.py"), env=dict(os.environ, OMP_NUM_THREADS="1"), timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert f"fd sharded over {world} ranks" in r.stdout
 
