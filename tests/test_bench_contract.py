@@ -30,7 +30,7 @@ def _check(o, n_gpus=1, with_cpu=True):
 
 
 def test_committed_bench_line_follows_the_contract():
-    o = json.load(open(os.path.join(ROOT, "profiles", "r05_sheet-500k_bench.json")))
+    o = json.load(open(os.path.join(ROOT, "profiles", "r06_sheet-500k_bench.json")))
     _check(o)
     # round 3: traffic-based fractions beside the algorithmic ones, the CPU baseline at a probed thread count and on one thread
     assert 0 < o["roofline"]["traffic_frac"] < 1 and all("traffic_frac" in k for k in o["kernels"] if "alg_bytes" in k)
