@@ -158,6 +158,11 @@ def _follow(name, checkpoints, gamma0=False, k_oracles=K_ORACLES, probe_pair=Fal
 
 
 MARGIN_AMPLIFYING = 10.0
+# x of an amplifying scene: where the oracle's own orders are further apart than a third of the north star's 1e-4, three times their
+# distance.  Seven runs (profiles/r06_fullsize_demo_samples.txt): at substep 1000 HIP sits at 0.91 .. 1.53 x the ensemble's own largest
+# pair distance (6.4e-5 .. 1.3e-4 against 5.1e-5 .. 1.2e-4; both are set by whichever run let one grain go another way), 1e-4 itself is
+# inside that range; at substeps 100 / 400 the plain 1e-4 decides (1.6e-7, 5e-6).
+MARGIN_X_AMPLIFYING = 3.0
 
 
 def _check(rows, what, amplifying=False):
@@ -178,8 +183,8 @@ def _check(rows, what, amplifying=False):
                          for i, n in enumerate(names))
         print(f"{what} substep {cp}: x {r['dx']:.1e}; |dv| HIP-vs-oracle (median of {len(hip)}) [oracle-vs-oracle range of {len(pairs)} pairs]: "
               f"{line}; top speed {r['vmax']:.2f}; one-substep map {r['one_step']}")
-        # x: the north star's 1e-4 -- for an amplifying scene, where the oracle's own orders are further apart than half of that, twice their distance
-        x_bound = max(1e-4, MARGIN * r["ens_dx"]) if amplifying else 1e-4
+        # x: the north star's 1e-4 -- for an amplifying scene, where the oracle's own orders are further apart than a third of that, three times their distance
+        x_bound = max(1e-4, MARGIN_X_AMPLIFYING * r["ens_dx"]) if amplifying else 1e-4
         assert r["dx"] < x_bound and r["ppx"] < x_bound, f"{what} substep {cp}: x {r['dx']:.2e} (per particle {r['ppx']:.2e}; ensemble's own {r['ens_dx']:.2e})"
         if r["ens_one"] is not None:
             print(f"{what} substep {cp}: one-substep perturbation HIP-vs-oracle {r['one_step'][1]:.1e} (max norm), between two orders of the oracle's sums {r['ens_one']:.1e}; "
